@@ -1,0 +1,600 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so) + a numpy composition that mirrors the reference's
+object graph (create_from_config -> Trainer -> NetworkWithInputEncoding -> Encoding + Network).
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product package (tiny-cuda-nn_amd/) never does.
+
+Reference call order restated here (paths relative to /root/reference):
+  config.h:53-63                         create_from_config
+  trainer.h:50-57, 68-87                 Trainer ctor: seed_seq{seed} -> pcg32, initialize_params, fp32 -> half cast
+  network_with_input_encoding.h:115-130  param order: network first, then encoding
+  trainer.h:163-190                      training_step = forward + loss + backward (+ optimizer step)
+  object.h:147-176                       inference = forward without intermediates, trim + cast to float
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "exponential": 3, "sine": 4, "sigmoid": 5, "squareplus": 6, "softplus": 7, "tanh": 8}
+GRID_TYPE = {"hash": 0, "dense": 1, "tiled": 2}
+HASH_TYPE = {"prime": 0, "coherentprime": 1, "reversedprime": 2, "rng": 3}
+INTERP = {"nearest": 0, "linear": 1, "smoothstep": 2}
+LOSS = {"l2": 0, "relativel2": 1}
+ACC_FP32, ACC_FP16 = 0, 1
+MAX_LEVELS = 128
+LOSS_SCALE = 128.0  # common.h:232 default_loss_scale<__half>
+BATCH_SIZE_GRANULARITY = 256  # common.h:235
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when the reference tree is present). Building the checker is not using it."""
+    src = os.path.join(_HERE, "tcnn_oracle.cpp")
+    hdr = os.path.join(_HERE, "tcnn_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref_hdr = "/root/reference/dependencies/pcg32/pcg32.h"
+    if os.path.exists(ref_hdr):
+        ref_so = os.path.join(_HERE, "_ref", "libref_pcg32.so")
+        if force or not os.path.exists(ref_so):
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class _Grid(C.Structure):
+    _fields_ = [
+        ("n_pos_dims", C.c_uint32), ("n_features_per_level", C.c_uint32), ("n_levels", C.c_uint32),
+        ("log2_hashmap_size", C.c_uint32), ("base_resolution", C.c_uint32), ("per_level_scale", C.c_float),
+        ("grid_type", C.c_uint32), ("hash_type", C.c_uint32), ("interpolation", C.c_uint32), ("stochastic_interpolation", C.c_uint32),
+        ("offsets", C.c_uint32 * (MAX_LEVELS + 1)), ("scales", C.c_float * MAX_LEVELS), ("resolutions", C.c_uint32 * MAX_LEVELS),
+        ("n_params", C.c_uint32),
+    ]
+
+
+class _Mlp(C.Structure):
+    _fields_ = [("in_width", C.c_uint32), ("width", C.c_uint32), ("out_width", C.c_uint32), ("n_hidden_layers", C.c_uint32),
+                ("activation", C.c_uint32), ("output_activation", C.c_uint32), ("acc_mode", C.c_uint32)]
+
+
+class _Adam(C.Structure):
+    _fields_ = [("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float), ("l2_reg", C.c_float),
+                ("relative_decay", C.c_float), ("absolute_decay", C.c_float), ("clipping_magnitude", C.c_float),
+                ("non_matrix_learning_rate_factor", C.c_float),
+                ("adabound", C.c_uint32), ("optimize_matrix_params", C.c_uint32), ("optimize_non_matrix_params", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp, u32, u64, f32, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
+        sig = {
+            "orc_float_to_half": (C.c_uint16, [f32]), "orc_half_to_float": (f32, [C.c_uint16]), "orc_double_to_half": (C.c_uint16, [C.c_double]),
+            "orc_cast_float_to_half": (None, [sz, vp, vp]), "orc_cast_half_to_float": (None, [sz, vp, vp]),
+            "orc_pcg32_seed": (None, [vp, u64, u64]), "orc_pcg32_next_uint": (u32, [vp]), "orc_pcg32_next_float": (f32, [vp]),
+            "orc_pcg32_advance": (None, [vp, C.c_int64]), "orc_seed_seq2": (None, [u32, vp]),
+            "orc_xavier_uniform": (None, [vp, vp, u32, u32, f32]), "orc_generate_random_uniform": (None, [vp, sz, vp, f32, f32]),
+            "orc_grid_setup": (C.c_int, [vp]), "orc_grid_hash": (u32, [u32, u32, vp]), "orc_grid_index": (u32, [u32, u32, u32, u32, u32, vp]),
+            "orc_pos_fract": (u32, [f32, f32, u32, vp, vp]),
+            "orc_grid_forward": (None, [vp, u32, vp, vp, vp, u32, vp, vp]),
+            "orc_grid_backward": (None, [vp, u32, vp, vp, u32, vp, vp]),
+            "orc_grid_backward_input": (None, [vp, u32, vp, u32, vp, vp]),
+            "orc_oneblob_forward": (None, [u32, u32, u32, vp, vp, u32]), "orc_oneblob_backward_input": (None, [u32, u32, u32, vp, vp, u32, vp]),
+            "orc_identity_forward": (None, [u32, u32, f32, f32, vp, vp, u32]), "orc_identity_backward_input": (None, [u32, u32, f32, vp, u32, vp]),
+            "orc_mlp_n_params": (sz, [vp]), "orc_mlp_init_params": (None, [vp, vp, vp, f32]),
+            "orc_mlp_forward": (None, [vp, u32, vp, vp, vp, vp]),
+            "orc_mlp_backward": (None, [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]),
+            "orc_loss": (None, [u32, u32, u32, u32, f32, vp, vp, vp, vp, vp]), "orc_reduce_sum": (C.c_double, [sz, vp]),
+            "orc_adam_defaults": (None, [vp]), "orc_adam_step": (None, [vp, sz, sz, f32, u32, vp, vp, vp, vp, vp, vp]),
+            "orc_activation": (C.c_uint16, [u32, C.c_uint16]), "orc_activation_backward": (C.c_uint16, [u32, C.c_uint16, C.c_uint16]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def half_bits(a_f32):
+    a = np.ascontiguousarray(a_f32, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint16)
+    lib().orc_cast_float_to_half(a.size, _p(a), _p(out))
+    return out
+
+
+def half_to_f32(bits):
+    b = np.ascontiguousarray(bits, dtype=np.uint16)
+    out = np.empty(b.shape, dtype=np.float32)
+    lib().orc_cast_half_to_float(b.size, _p(b), _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- rng
+class Pcg32:
+    """dependencies/pcg32/pcg32.h:40-166"""
+
+    def __init__(self, initstate=None, initseq=1):
+        self.st = np.zeros(2, dtype=np.uint64)
+        if initstate is not None:
+            lib().orc_pcg32_seed(_p(self.st), int(initstate), int(initseq))
+
+    @staticmethod
+    def trainer(seed=1337):
+        """trainer.h:52-55: std::seed_seq{seed}.generate(2) -> pcg32{words[0]}"""
+        w = np.zeros(2, dtype=np.uint32)
+        lib().orc_seed_seq2(seed, _p(w))
+        return Pcg32(int(w[0]))
+
+    def next_uint(self):
+        return int(lib().orc_pcg32_next_uint(_p(self.st)))
+
+    def next_float(self):
+        return float(lib().orc_pcg32_next_float(_p(self.st)))
+
+    def advance(self, delta):
+        lib().orc_pcg32_advance(_p(self.st), int(delta))
+
+    def floats(self, n):
+        return np.array([self.next_float() for _ in range(n)], dtype=np.float32)
+
+    def uniform_strided(self, n, lo=0.0, hi=1.0):
+        """random.h:40-70 generate_random_uniform (device fill order)"""
+        out = np.empty(n, dtype=np.float32)
+        lib().orc_generate_random_uniform(_p(self.st), n, _p(out), lo, hi)
+        return out
+
+
+def synthetic_batch(n, n_in, n_out, seed=42):
+    """Seeded synthetic inputs/targets shared by CPU oracle and GPU runs: x ~ U[0,1)^n_in, t ~ U[0,1)^n_out,
+    drawn with the strided device fill of random.h from pcg32{seed}."""
+    rng = Pcg32(seed)
+    x = rng.uniform_strided(n * n_in).reshape(n, n_in)
+    t = rng.uniform_strided(n * n_out).reshape(n, n_out)
+    return x, t
+
+
+def _ci(d, key, default):
+    """json .value(key, default)"""
+    return d[key] if key in d else default
+
+
+def _norm(s):
+    return str(s).lower()
+
+
+def next_multiple(v, d):
+    return (v + d - 1) // d * d
+
+
+# ----------------------------------------------------------------------------------------------- encodings
+class GridEncoding:
+    """encodings/grid.h:653-1141 (+ factories :1143-1208)"""
+
+    def __init__(self, n_in, cfg):
+        F = _ci(cfg, "n_features_per_level", 2)
+        if F not in (1, 2, 4, 8):
+            raise RuntimeError("GridEncoding: n_features_per_level must be 1, 2, 4, or 8.")
+        otype = _norm(_ci(cfg, "otype", "Grid"))
+        default_type = "Tiled" if otype == "tiledgrid" else ("Dense" if otype == "densegrid" else "Hash")
+        if "n_features" in cfg or "n_grid_features" in cfg:
+            if "n_levels" in cfg:
+                raise RuntimeError("GridEncoding: may not specify n_features and n_levels simultaneously (one determines the other)")
+            n_features = cfg["n_features"] if "n_features" in cfg else cfg["n_grid_features"]
+        else:
+            n_features = F * _ci(cfg, "n_levels", 16)
+        if n_features % F != 0:
+            raise RuntimeError("GridEncoding: n_features must be a multiple of N_FEATURES_PER_LEVEL")
+        if n_in not in (2, 3, 4):
+            raise RuntimeError("GridEncoding: number of input dims must be 2 or 3.")
+        n_levels = n_features // F
+        g = _Grid()
+        g.n_pos_dims = n_in
+        g.n_features_per_level = F
+        g.n_levels = n_levels
+        g.log2_hashmap_size = _ci(cfg, "log2_hashmap_size", 19)
+        g.base_resolution = _ci(cfg, "base_resolution", 16)
+        g.grid_type = GRID_TYPE[_norm(_ci(cfg, "type", default_type))]
+        if "per_level_scale" in cfg:
+            g.per_level_scale = cfg["per_level_scale"]
+        elif g.grid_type == GRID_TYPE["dense"]:
+            g.per_level_scale = float(np.exp(np.float32(np.log(np.float32(256.0) / np.float32(g.base_resolution))) / np.float32(n_levels - 1)))
+        else:
+            g.per_level_scale = 2.0
+        g.hash_type = HASH_TYPE[_norm(_ci(cfg, "hash", "CoherentPrime"))]
+        g.interpolation = INTERP[_norm(_ci(cfg, "interpolation", "Linear"))]
+        g.stochastic_interpolation = int(bool(_ci(cfg, "stochastic_interpolation", False)))
+        if lib().orc_grid_setup(C.byref(g)) != 0:
+            raise RuntimeError("GridEncoding: invalid configuration")
+        self.g = g
+        self.n_in = n_in
+        self.n_output_dims = n_features
+        self.n_to_pad = 0
+        self.n_params = int(g.n_params)
+        self.required_output_alignment = F
+
+    @property
+    def padded_output_width(self):
+        return self.n_output_dims + self.n_to_pad
+
+    def set_alignment(self, alignment):  # encoding.h:70-72
+        a = int(np.lcm(alignment, self.required_output_alignment))
+        self.n_to_pad = next_multiple(self.n_output_dims, a) - self.n_output_dims
+
+    @property
+    def offsets(self):
+        return np.array(self.g.offsets[: self.g.n_levels + 1], dtype=np.uint32)
+
+    @property
+    def scales(self):
+        return np.array(self.g.scales[: self.g.n_levels], dtype=np.float32)
+
+    @property
+    def resolutions(self):
+        return np.array(self.g.resolutions[: self.g.n_levels], dtype=np.uint32)
+
+    def initialize_params(self, rng, scale=1.0):  # grid.h:1059-1062
+        return rng.uniform_strided(self.n_params, -1e-4 * scale, 1e-4 * scale)
+
+    def forward(self, x, params_half, want_indices=False, want_dy_dx=False):
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((n, self.padded_output_width), dtype=np.uint16)
+        idx = np.empty((n, self.g.n_levels, 1 << self.n_in), dtype=np.uint32) if want_indices else None
+        dy_dx = np.empty((n, self.n_output_dims, self.n_in), dtype=np.float32) if want_dy_dx else None
+        lib().orc_grid_forward(C.byref(self.g), n, _p(x), _p(params_half), _p(out), out.shape[1], _p(idx), _p(dy_dx))
+        ctx = {"dy_dx": dy_dx, "indices": idx}
+        return out, ctx
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        """dL_dy: [n][padded] half bits. grad_half: accumulated in place (zero it for Overwrite)."""
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dL_dy = np.ascontiguousarray(dL_dy)
+        if grad_half is not None or grad_f32 is not None:
+            lib().orc_grid_backward(C.byref(self.g), n, _p(x), _p(dL_dy), dL_dy.shape[1], _p(grad_half), _p(grad_f32))
+        if want_dL_dx:
+            dL_dx = np.empty((n, self.n_in), dtype=np.float32)
+            lib().orc_grid_backward_input(C.byref(self.g), n, _p(dL_dy), dL_dy.shape[1], _p(ctx["dy_dx"]), _p(dL_dx))
+            return dL_dx
+        return None
+
+    def hyperparams(self):
+        r = {"otype": "Grid", "type": ["Hash", "Dense", "Tiled"][self.g.grid_type], "n_levels": int(self.g.n_levels),
+             "n_features_per_level": int(self.g.n_features_per_level), "base_resolution": int(self.g.base_resolution),
+             "per_level_scale": float(self.g.per_level_scale),
+             "interpolation": ["Nearest", "Linear", "Smoothstep"][self.g.interpolation],
+             "hash": ["Prime", "CoherentPrime", "ReversedPrime", "Rng"][self.g.hash_type]}
+        if self.g.grid_type == 0:
+            r["log2_hashmap_size"] = int(self.g.log2_hashmap_size)
+        return r
+
+
+class OneBlobEncoding:
+    """encodings/oneblob.h:167-307"""
+
+    def __init__(self, n_in, cfg):
+        self.n_bins = _ci(cfg, "n_bins", 16)
+        if self.n_bins & (self.n_bins - 1):
+            raise RuntimeError("Number of bins must be a power of 2")
+        self.n_in = n_in
+        self.n_output_dims = n_in * self.n_bins
+        self.n_to_pad = 0
+        self.n_params = 0
+        self.required_output_alignment = 1
+
+    padded_output_width = GridEncoding.padded_output_width
+    set_alignment = GridEncoding.set_alignment
+
+    def initialize_params(self, rng, scale=1.0):
+        return np.empty(0, dtype=np.float32)
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((n, self.padded_output_width), dtype=np.uint16)
+        lib().orc_oneblob_forward(n, self.n_in, self.n_bins, _p(x), _p(out), out.shape[1])
+        return out, {}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        if not want_dL_dx:
+            return None
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dL_dy = np.ascontiguousarray(dL_dy)
+        dL_dx = np.empty((n, self.n_in), dtype=np.float32)
+        lib().orc_oneblob_backward_input(n, self.n_in, self.n_bins, _p(x), _p(dL_dy), dL_dy.shape[1], _p(dL_dx))
+        return dL_dx
+
+    def hyperparams(self):
+        return {"otype": "OneBlob", "n_bins": self.n_bins}
+
+
+class IdentityEncoding:
+    """encodings/identity.h:88-190"""
+
+    def __init__(self, n_in, cfg):
+        self.scale = float(_ci(cfg, "scale", 1.0))
+        self.offset = float(_ci(cfg, "offset", 0.0))
+        self.n_in = n_in
+        self.n_output_dims = n_in
+        self.n_to_pad = 0
+        self.n_params = 0
+        self.required_output_alignment = 1
+
+    padded_output_width = GridEncoding.padded_output_width
+    set_alignment = GridEncoding.set_alignment
+
+    def initialize_params(self, rng, scale=1.0):
+        return np.empty(0, dtype=np.float32)
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((n, self.padded_output_width), dtype=np.uint16)
+        lib().orc_identity_forward(n, self.n_in, self.scale, self.offset, _p(x), _p(out), out.shape[1])
+        return out, {}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        if not want_dL_dx:
+            return None
+        n = x.shape[0]
+        dL_dy = np.ascontiguousarray(dL_dy)
+        dL_dx = np.empty((n, self.n_in), dtype=np.float32)
+        lib().orc_identity_backward_input(n, self.n_in, self.scale, _p(dL_dy), dL_dy.shape[1], _p(dL_dx))
+        return dL_dx
+
+    def hyperparams(self):
+        return {"otype": "Identity", "scale": self.scale, "offset": self.offset}
+
+
+def create_encoding(n_in, cfg, alignment=8):
+    """src/encoding.cu:144-158 (case-insensitive otype, default OneBlob)"""
+    name = _norm(_ci(cfg, "otype", "OneBlob"))
+    if name in ("grid", "hashgrid", "tiledgrid", "densegrid"):
+        enc = GridEncoding(n_in, cfg)
+    elif name == "oneblob":
+        enc = OneBlobEncoding(n_in, cfg)
+    elif name == "identity":
+        enc = IdentityEncoding(n_in, cfg)
+    else:
+        raise RuntimeError(f"Encoding '{cfg.get('otype')}' not found")
+    if alignment > 0:
+        enc.set_alignment(alignment)
+    return enc
+
+
+# ----------------------------------------------------------------------------------------------- network
+class Mlp:
+    """FullyFusedMLP / CutlassMLP (same function): fully_fused_mlp.cu:636-678, cutlass_mlp.cu:39-92"""
+
+    def __init__(self, cfg, acc_mode=ACC_FP32):
+        otype = _norm(_ci(cfg, "otype", "MLP"))
+        fully_fused = otype in ("fullyfusedmlp", "megakernelmlp")
+        if not fully_fused and otype not in ("mlp", "cutlassmlp"):
+            raise RuntimeError(f"Invalid network type: {cfg.get('otype')}")
+        m = _Mlp()
+        m.in_width = cfg["n_input_dims"]
+        m.width = _ci(cfg, "n_neurons", 128)
+        self.n_output_dims = cfg["n_output_dims"]
+        m.out_width = next_multiple(self.n_output_dims, 16)
+        m.n_hidden_layers = _ci(cfg, "n_hidden_layers", 5)
+        m.activation = ACT[_norm(_ci(cfg, "activation", "ReLU"))]
+        m.output_activation = ACT[_norm(_ci(cfg, "output_activation", "None"))]
+        m.acc_mode = acc_mode
+        if fully_fused:
+            if m.width not in (16, 32, 64, 128):
+                raise RuntimeError(f"FullyFusedMLP only supports 16, 32, 64, and 128 neurons, but got {m.width}.")
+            if m.n_hidden_layers <= 0:
+                raise RuntimeError("FullyFusedMLP requires at least 1 hidden layer (3 layers in total).")
+        self.m = m
+        self.fully_fused = fully_fused
+        self.n_params = int(lib().orc_mlp_n_params(C.byref(m)))
+
+    @property
+    def padded_output_width(self):
+        return int(self.m.out_width)
+
+    def layer_sizes(self):
+        m = self.m
+        if m.n_hidden_layers == 0:
+            return [(m.out_width, m.in_width)]
+        return [(m.width, m.in_width)] + [(m.width, m.width)] * (m.n_hidden_layers - 1) + [(m.out_width, m.width)]
+
+    def initialize_params(self, rng, scale=1.0):
+        out = np.empty(self.n_params, dtype=np.float32)
+        lib().orc_mlp_init_params(C.byref(self.m), _p(rng.st), _p(out), scale)
+        return out
+
+    def forward(self, x_half, params_half, keep_hidden=True):
+        n = x_half.shape[0]
+        x_half = np.ascontiguousarray(x_half)
+        hidden = np.empty((self.m.n_hidden_layers, n, self.m.width), dtype=np.uint16) if keep_hidden else None
+        out = np.empty((n, self.m.out_width), dtype=np.uint16)
+        lib().orc_mlp_forward(C.byref(self.m), n, _p(x_half), _p(params_half), _p(hidden), _p(out))
+        return out, hidden
+
+    def backward(self, x_half, params_half, hidden, out, dL_dout, want_dL_dx, grads_half=None, grads_f32=None, accumulate=False):
+        n = x_half.shape[0]
+        dL_dx = np.empty((n, self.m.in_width), dtype=np.uint16) if want_dL_dx else None
+        lib().orc_mlp_backward(C.byref(self.m), n, _p(np.ascontiguousarray(x_half)), _p(params_half), _p(hidden), _p(out),
+                               _p(np.ascontiguousarray(dL_dout)), _p(dL_dx), _p(grads_half), _p(grads_f32), int(accumulate))
+        return dL_dx
+
+    def hyperparams(self):
+        inv = {v: k for k, v in ACT.items()}
+        names = {"none": "None", "relu": "ReLU", "leakyrelu": "LeakyReLU", "exponential": "Exponential", "sine": "Sine",
+                 "sigmoid": "Sigmoid", "squareplus": "Squareplus", "softplus": "Softplus", "tanh": "Tanh"}
+        return {"otype": "FullyFusedMLP" if self.fully_fused else "CutlassMLP", "activation": names[inv[self.m.activation]],
+                "output_activation": names[inv[self.m.output_activation]], "n_neurons": int(self.m.width),
+                "n_hidden_layers": int(self.m.n_hidden_layers)}
+
+
+class NetworkWithInputEncoding:
+    """network_with_input_encoding.h:40-192"""
+
+    def __init__(self, n_in, n_out, enc_cfg, net_cfg, acc_mode=ACC_FP32):
+        self.encoding = create_encoding(n_in, enc_cfg, alignment=16)  # minimum_alignment(network) = 16 (network.cu:76-96)
+        cfg = dict(net_cfg)
+        cfg["n_input_dims"] = self.encoding.padded_output_width
+        cfg["n_output_dims"] = n_out
+        self.network = Mlp(cfg, acc_mode)
+        self.n_in = n_in
+        self.n_out = n_out
+
+    @property
+    def n_params(self):
+        return self.network.n_params + self.encoding.n_params
+
+    @property
+    def padded_output_width(self):
+        return self.network.padded_output_width
+
+    def initialize_params(self, rng, scale=1.0):
+        a = self.network.initialize_params(rng, scale)
+        b = self.encoding.initialize_params(rng, scale)
+        return np.concatenate([a, b]).astype(np.float32)
+
+    def _split(self, params):
+        return params[: self.network.n_params], params[self.network.n_params:]
+
+    def forward(self, x, params_half, prepare_input_gradients=False, keep_hidden=True):
+        net_p, enc_p = self._split(params_half)
+        enc_out, enc_ctx = self.encoding.forward(x, np.ascontiguousarray(enc_p), want_dy_dx=prepare_input_gradients)
+        out, hidden = self.network.forward(enc_out, np.ascontiguousarray(net_p), keep_hidden)
+        return out, {"network_input": enc_out, "hidden": hidden, "enc_ctx": enc_ctx}
+
+    def inference(self, x, params_half):
+        """object.h:147-176: padded half output -> trim -> float"""
+        out, _ = self.forward(x, params_half, keep_hidden=False)
+        return half_to_f32(out[:, : self.n_out])
+
+    def backward(self, x, params_half, ctx, out, dL_dout, want_dL_dx=False, grads_half=None, grads_f32=None, accumulate=False):
+        """grads_half: full-size half gradient buffer (network first, then encoding). Overwrite semantics unless accumulate."""
+        net_p, _ = self._split(params_half)
+        need_dnet_in = self.encoding.n_params > 0 or want_dL_dx  # network_with_input_encoding.h:93-96
+        gh_net = gh_enc = g32_net = g32_enc = None
+        if grads_half is not None:
+            gh_net, gh_enc = grads_half[: self.network.n_params], grads_half[self.network.n_params:]
+            if not accumulate:
+                gh_enc[:] = 0  # grid.h:858
+        if grads_f32 is not None:
+            g32_net, g32_enc = grads_f32[: self.network.n_params], grads_f32[self.network.n_params:]
+            g32_enc[:] = 0
+        dnet_in = self.network.backward(ctx["network_input"], np.ascontiguousarray(net_p), ctx["hidden"], out, dL_dout, need_dnet_in,
+                                        gh_net, g32_net, accumulate)
+        dL_dx = None
+        if need_dnet_in:
+            dL_dx = self.encoding.backward(x, ctx["enc_ctx"], dnet_in,
+                                           gh_enc if (gh_enc is not None and self.encoding.n_params > 0) else None,
+                                           want_dL_dx,
+                                           g32_enc if (g32_enc is not None and self.encoding.n_params > 0) else None)
+        return dL_dx, dnet_in
+
+    def hyperparams(self):
+        return {"otype": "NetworkWithInputEncoding", "encoding": self.encoding.hyperparams(), "network": self.network.hyperparams()}
+
+
+# ----------------------------------------------------------------------------------------------- loss / optimizer / trainer
+def loss_evaluate(loss_type, pred_half, target, loss_scale=LOSS_SCALE, data_pdf=None):
+    n, stride = pred_half.shape
+    dims = target.shape[1]
+    values = np.empty((n, stride), dtype=np.float32)
+    grads = np.empty((n, stride), dtype=np.uint16)
+    target = np.ascontiguousarray(target, dtype=np.float32)
+    lib().orc_loss(LOSS[_norm(loss_type)], n, stride, dims, loss_scale, _p(np.ascontiguousarray(pred_half)), _p(target), _p(values), _p(grads),
+                   _p(None if data_pdf is None else np.ascontiguousarray(data_pdf, dtype=np.float32)))
+    return values, grads
+
+
+class Adam:
+    """optimizers/adam.h:122-327"""
+
+    KEYS = {"beta1": "beta1", "beta2": "beta2", "epsilon": "epsilon", "learning_rate": "learning_rate", "l2_reg": "l2_reg",
+            "relative_decay": "relative_decay", "absolute_decay": "absolute_decay", "clipping_magnitude": "clipping_magnitude",
+            "non_matrix_learning_rate_factor": "non_matrix_learning_rate_factor"}
+    BOOLS = ("adabound", "optimize_matrix_params", "optimize_non_matrix_params")
+
+    def __init__(self, cfg):
+        self.a = _Adam()
+        lib().orc_adam_defaults(C.byref(self.a))
+        self.update_hyperparams(cfg)
+        self.current_step = 0
+
+    def update_hyperparams(self, cfg):
+        for k, f in self.KEYS.items():
+            if k in cfg:
+                setattr(self.a, f, float(cfg[k]))
+        for k in self.BOOLS:
+            if k in cfg:
+                setattr(self.a, k, int(bool(cfg[k])))
+
+    def allocate(self, n, layer_sizes):
+        self.n = n
+        self.m1 = np.zeros(n, dtype=np.float32)
+        self.m2 = np.zeros(n, dtype=np.float32)
+        self.steps = np.zeros(n, dtype=np.uint32)
+        self.n_matrix = int(sum(r * c for r, c in layer_sizes))
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        self.current_step += 1
+        lib().orc_adam_step(C.byref(self.a), self.n, self.n_matrix, loss_scale, self.current_step, _p(w_fp), _p(w_half), _p(g_half),
+                            _p(self.m1), _p(self.m2), _p(self.steps))
+
+
+class Trainer:
+    """trainer.h:48-363 + config.h:46-63 (create_from_config)"""
+
+    def __init__(self, n_in, n_out, config, seed=1337, acc_mode=ACC_FP32):
+        if isinstance(config, str):
+            config = json.loads(config)
+        loss_cfg = _ci(config, "loss", {})
+        opt_cfg = _ci(config, "optimizer", {})
+        self.loss_type = _ci(loss_cfg, "otype", "RelativeL2")
+        if _norm(self.loss_type) not in LOSS:
+            raise RuntimeError(f"Invalid loss type: {self.loss_type}")
+        if _norm(_ci(opt_cfg, "otype", "Adam")) != "adam":
+            raise RuntimeError(f"Invalid optimizer type: {opt_cfg.get('otype')}")
+        self.optimizer = Adam(opt_cfg)
+        self.model = NetworkWithInputEncoding(n_in, n_out, _ci(config, "encoding", {}), _ci(config, "network", {}), acc_mode)
+        self.rng = Pcg32.trainer(seed)
+        self.initialize_params()
+
+    def initialize_params(self):
+        n = self.model.n_params
+        self.optimizer.allocate(n, self.model.network.layer_sizes())
+        self.params_fp = self.model.initialize_params(self.rng)
+        self.params = half_bits(self.params_fp)
+        self.grads = np.zeros(n, dtype=np.uint16)
+
+    def training_step(self, x, target, run_optimizer=True, want_dL_dx=False, grads_f32=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        if n % BATCH_SIZE_GRANULARITY:
+            raise RuntimeError("batch size must be a multiple of 256")  # object.h:130
+        out, ctx = self.model.forward(x, self.params, prepare_input_gradients=want_dL_dx)
+        values, dL_dout = loss_evaluate(self.loss_type, out, target)
+        dL_dx, dnet_in = self.model.backward(x, self.params, ctx, out, dL_dout, want_dL_dx, self.grads, grads_f32)
+        if run_optimizer:
+            self.optimizer.step(LOSS_SCALE, self.params_fp, self.params, self.grads)
+        return {"output": out, "L": values, "dL_doutput": dL_dout, "dL_dinput": dL_dx, "dL_dnetwork_input": dnet_in, "ctx": ctx,
+                "loss": float(lib().orc_reduce_sum(values.size, _p(values)))}
+
+    def inference(self, x):
+        return self.model.inference(np.ascontiguousarray(x, dtype=np.float32), self.params)

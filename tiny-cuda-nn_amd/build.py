@@ -1,0 +1,53 @@
+"""Build libtcnn_amd.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+    python tiny-cuda-nn_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU; the .so lands next to this file (git-ignored, but it travels to the GPU box).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libtcnn_amd.so")
+SOURCES = ["k_grid.hip", "k_mlp.hip", "k_misc.hip", "capi.cpp"]
+HEADERS = ["tcnn_common.h", "model.h", "json_lite.h", os.path.join("..", "..", "include", "tcnn_amd.h")]
+# -ffp-contract=off: fused multiply-adds only where the source says fma (bit-exact grid arithmetic, see k_grid.hip)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-unused-result",
+         "-munsafe-fp-atomics"]
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+    if os.path.exists(obj) and os.path.getmtime(obj) >= _newest(deps):
+        return obj, False
+    cmd = ["hipcc"] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    subprocess.check_call(cmd)
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(_compile, SOURCES))
+    objs = [r[0] for r in results]
+    if any(r[1] for r in results) or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        if verbose:
+            print("linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,283 @@
+// capi.cpp -- the extern "C" boundary of libtcnn_amd.so (declared in include/tcnn_amd.h).
+//
+// Mirrors the reference's plugin interface tcnn::cpp (include/tiny-cuda-nn/cpp_api.h:50-115, src/cpp_api.cu:39-167) and its
+// create_from_config / Trainer surface (config.h:46-63, trainer.h:48-363): same names, same argument meaning, and C++
+// exceptions translated into TCNN_ERROR + tcnn_last_error().
+#include "../../include/tcnn_amd.h"
+
+#include "model.h"
+
+#include <string>
+
+using namespace tcnn_amd;
+
+namespace {
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F&& f) {
+	try {
+		f();
+		return TCNN_OK;
+	} catch (const std::exception& e) {
+		g_last_error = e.what();
+		log_message(TCNN_LOG_ERROR, g_last_error);
+		return TCNN_ERROR;
+	} catch (...) {
+		g_last_error = "unknown error";
+		return TCNN_ERROR;
+	}
+}
+
+Json parse_or_empty(const char* text) {
+	if (!text || !*text) return Json::object();
+	return Json::parse(text);
+}
+} // namespace
+
+struct tcnn_module_s {
+	std::unique_ptr<Model> model;
+	std::string hyperparams_text;
+	std::string name_text;
+};
+
+struct tcnn_context_s {
+	std::unique_ptr<ModelContext> ctx;
+};
+
+struct tcnn_trainer_s {
+	std::unique_ptr<Trainer> trainer;
+	std::string hyperparams_text;
+	std::string network_hyperparams_text;
+};
+
+struct tcnn_train_ctx_s {
+	std::unique_ptr<TrainContext> ctx;
+};
+
+extern "C" {
+
+const char* tcnn_last_error(void) { return g_last_error.c_str(); }
+const char* tcnn_version(void) { return "tcnn_amd 0.1 (gfx950)"; }
+
+uint32_t tcnn_batch_size_granularity(void) { return BATCH_SIZE_GRANULARITY; }
+
+int tcnn_device(int* device_out) {
+	return guarded([&] { HIP_CHECK_THROW(hipGetDevice(device_out)); });
+}
+
+int tcnn_set_device(int device) {
+	return guarded([&] { HIP_CHECK_THROW(hipSetDevice(device)); });
+}
+
+void tcnn_free_temporary_memory(void) { Arena::instance().release_all(); }
+int tcnn_has_networks(void) { return 1; }
+float tcnn_default_loss_scale(int precision) { return precision == TCNN_PRECISION_FP32 ? 1.0f : LOSS_SCALE_FP16; }
+int tcnn_preferred_precision(void) { return TCNN_PRECISION_FP16; }
+
+void tcnn_set_log_callback(void (*callback)(int, const char*, void*), void* user) {
+	log_sink().callback = callback;
+	log_sink().user = user;
+}
+
+int tcnn_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims, const char* encoding_json, const char* network_json, tcnn_module_t* out) {
+	return guarded([&] {
+		CHECK_THROW(out != nullptr);
+		auto m = std::make_unique<tcnn_module_s>();
+		m->model.reset(new NetworkWithInputEncoding{n_input_dims, n_output_dims, parse_or_empty(encoding_json), parse_or_empty(network_json)});
+		*out = m.release();
+	});
+}
+
+int tcnn_create_network(uint32_t n_input_dims, uint32_t n_output_dims, const char* network_json, tcnn_module_t* out) {
+	// cpp_api.cu:151-153: Identity encoding + network
+	return tcnn_create_network_with_input_encoding(n_input_dims, n_output_dims, "{\"otype\": \"Identity\"}", network_json, out);
+}
+
+int tcnn_create_encoding(uint32_t n_input_dims, const char* encoding_json, int precision, tcnn_module_t* out) {
+	return guarded([&] {
+		CHECK_THROW(out != nullptr);
+		auto m = std::make_unique<tcnn_module_s>();
+		m->model.reset(new EncodingModel{n_input_dims, parse_or_empty(encoding_json), precision == TCNN_PRECISION_FP32 ? Precision::Fp32 : Precision::Fp16});
+		*out = m.release();
+	});
+}
+
+void tcnn_module_destroy(tcnn_module_t module) { delete module; }
+
+int tcnn_module_inference(tcnn_module_t m, tcnn_stream_t stream, uint32_t n, const float* input, void* output, void* params) {
+	return guarded([&] {
+		CHECK_THROW(m && m->model);
+		m->model->inference((hipStream_t)stream, n, MatView{input, m->model->input_width(), 1u}, output, params);
+	});
+}
+
+int tcnn_module_forward(tcnn_module_t m, tcnn_stream_t stream, uint32_t n, const float* input, void* output, void* params, int prepare_input_gradients, tcnn_context_t* ctx_out) {
+	return guarded([&] {
+		CHECK_THROW(m && m->model && ctx_out);
+		auto c = std::make_unique<tcnn_context_s>();
+		c->ctx = m->model->forward((hipStream_t)stream, n, MatView{input, m->model->input_width(), 1u}, output, params, prepare_input_gradients != 0);
+		*ctx_out = c.release();
+	});
+}
+
+int tcnn_module_backward(tcnn_module_t m, tcnn_stream_t stream, tcnn_context_t ctx, uint32_t n, float* dL_dinput, const void* dL_doutput, void* dL_dparams,
+                         const float* input, const void* output, const void* params) {
+	return guarded([&] {
+		CHECK_THROW(m && m->model);
+		if (!ctx || !ctx->ctx) throw std::runtime_error{"Module::bwd: called with invalid context. fwd likely (mistakenly) ran in inference mode."};
+		MatViewMut dx{dL_dinput, m->model->input_width(), 1u};
+		m->model->backward((hipStream_t)stream, *ctx->ctx, n, MatView{input, m->model->input_width(), 1u}, output, dL_doutput, dL_dinput ? &dx : nullptr, params,
+		                   dL_dparams, dL_dparams ? GradientMode::Overwrite : GradientMode::Ignore); // cpp_api.cu:108
+	});
+}
+
+int tcnn_module_backward_backward_input(tcnn_module_t, tcnn_stream_t, tcnn_context_t, uint32_t, const float*, const float*, const void*, void*, void*, float*, const void*) {
+	g_last_error = "backward_backward_input (second-order input gradients) is not implemented in this build";
+	return TCNN_ERROR;
+}
+
+void tcnn_context_destroy(tcnn_context_t ctx) { delete ctx; }
+
+uint32_t tcnn_module_n_input_dims(tcnn_module_t m) { return m->model->input_width(); }
+uint32_t tcnn_module_n_output_dims(tcnn_module_t m) { return m->model->padded_output_width(); }
+size_t tcnn_module_n_params(tcnn_module_t m) { return m->model->n_params(); }
+int tcnn_module_param_precision(tcnn_module_t m) { return (int)m->model->precision(); }
+int tcnn_module_output_precision(tcnn_module_t m) { return (int)m->model->precision(); }
+
+int tcnn_module_initialize_params(tcnn_module_t m, uint64_t seed, float* params_full_precision, float scale) {
+	return guarded([&] {
+		CHECK_THROW(m && m->model);
+		Pcg32 rng{seed}; // cpp_api.cu:134
+		m->model->initialize_params(rng, params_full_precision, scale);
+		HIP_CHECK_THROW(hipDeviceSynchronize());
+	});
+}
+
+const char* tcnn_module_hyperparams(tcnn_module_t m) {
+	m->hyperparams_text = m->model->hyperparams().dump();
+	return m->hyperparams_text.c_str();
+}
+
+const char* tcnn_module_name(tcnn_module_t m) {
+	m->name_text = m->model->name();
+	return m->name_text.c_str();
+}
+
+// ---------------------------------------------------------------------------------------------------------- trainer
+int tcnn_create_from_config_seeded(uint32_t n_input_dims, uint32_t n_output_dims, const char* config_json, uint32_t seed, tcnn_trainer_t* out) {
+	return guarded([&] {
+		CHECK_THROW(out != nullptr);
+		auto t = std::make_unique<tcnn_trainer_s>();
+		t->trainer.reset(new Trainer{n_input_dims, n_output_dims, parse_or_empty(config_json), seed});
+		*out = t.release();
+	});
+}
+
+int tcnn_create_from_config(uint32_t n_input_dims, uint32_t n_output_dims, const char* config_json, tcnn_trainer_t* out) {
+	return tcnn_create_from_config_seeded(n_input_dims, n_output_dims, config_json, 1337, out);
+}
+
+void tcnn_trainer_destroy(tcnn_trainer_t t) { delete t; }
+
+int tcnn_trainer_training_step(tcnn_trainer_t t, tcnn_stream_t stream, uint32_t n, const float* input, int input_layout, const float* target, const float* data_pdf,
+                               int run_optimizer, float* dL_dinput, int use_inference_params, int gradient_mode, const void* external_dL_dy, tcnn_train_ctx_t* ctx_out) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer && ctx_out);
+		Trainer& tr = *t->trainer;
+		const uint32_t w = tr.model().input_width();
+		MatViewMut dx = make_view_mut(dL_dinput, w, n, input_layout);
+		auto c = std::make_unique<tcnn_train_ctx_s>();
+		c->ctx = tr.training_step((hipStream_t)stream, n, make_view(input, w, n, input_layout), target, data_pdf, run_optimizer != 0, dL_dinput ? &dx : nullptr,
+		                          use_inference_params != 0, (GradientMode)gradient_mode, external_dL_dy);
+		*ctx_out = c.release();
+	});
+}
+
+int tcnn_trainer_loss(tcnn_trainer_t t, tcnn_stream_t stream, tcnn_train_ctx_t ctx, float* loss_out) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer && ctx && ctx->ctx && loss_out);
+		*loss_out = t->trainer->loss((hipStream_t)stream, *ctx->ctx);
+	});
+}
+
+int tcnn_trainer_forward(tcnn_trainer_t t, tcnn_stream_t stream, float loss_scale, uint32_t n, const float* input, int input_layout, const float* target, const float* data_pdf,
+                         int use_inference_params, int prepare_input_gradients, const void* external_dL_dy, tcnn_train_ctx_t* ctx_out) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer && ctx_out);
+		Trainer& tr = *t->trainer;
+		auto c = std::make_unique<tcnn_train_ctx_s>();
+		c->ctx = tr.forward((hipStream_t)stream, loss_scale, n, make_view(input, tr.model().input_width(), n, input_layout), target, data_pdf, use_inference_params != 0,
+		                    prepare_input_gradients != 0, external_dL_dy);
+		*ctx_out = c.release();
+	});
+}
+
+int tcnn_trainer_backward(tcnn_trainer_t t, tcnn_stream_t stream, tcnn_train_ctx_t ctx, uint32_t n, const float* input, int input_layout, float* dL_dinput,
+                          int use_inference_params, int gradient_mode) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer && ctx && ctx->ctx);
+		Trainer& tr = *t->trainer;
+		const uint32_t w = tr.model().input_width();
+		MatViewMut dx = make_view_mut(dL_dinput, w, n, input_layout);
+		tr.backward((hipStream_t)stream, *ctx->ctx, n, make_view(input, w, n, input_layout), dL_dinput ? &dx : nullptr, use_inference_params != 0, (GradientMode)gradient_mode);
+	});
+}
+
+int tcnn_trainer_optimizer_step(tcnn_trainer_t t, tcnn_stream_t stream, float loss_scale) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer);
+		t->trainer->optimizer_step((hipStream_t)stream, loss_scale);
+	});
+}
+
+void tcnn_train_ctx_destroy(tcnn_train_ctx_t ctx) { delete ctx; }
+const void* tcnn_train_ctx_output(tcnn_train_ctx_t ctx) { return ctx->ctx->output.data(); }
+const void* tcnn_train_ctx_dL_doutput(tcnn_train_ctx_t ctx) { return ctx->ctx->dL_doutput_ptr; }
+const float* tcnn_train_ctx_L(tcnn_train_ctx_t ctx) { return ctx->ctx->L.as<float>(); }
+
+int tcnn_trainer_inference(tcnn_trainer_t t, tcnn_stream_t stream, uint32_t n, const float* input, int input_layout, float* output, int output_layout, int use_inference_params) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer);
+		Trainer& tr = *t->trainer;
+		tr.inference((hipStream_t)stream, n, make_view(input, tr.model().input_width(), n, input_layout), make_view_mut(output, tr.model().output_width(), n, output_layout),
+		             use_inference_params != 0);
+	});
+}
+
+size_t tcnn_trainer_n_params(tcnn_trainer_t t) { return t->trainer->n_params(); }
+uint32_t tcnn_trainer_padded_output_width(tcnn_trainer_t t) { return t->trainer->model().padded_output_width(); }
+float* tcnn_trainer_params_full_precision(tcnn_trainer_t t) { return t->trainer->params_full_precision(); }
+void* tcnn_trainer_params(tcnn_trainer_t t) { return t->trainer->params(); }
+void* tcnn_trainer_params_inference(tcnn_trainer_t t) { return t->trainer->params(); }
+void* tcnn_trainer_param_gradients(tcnn_trainer_t t) { return t->trainer->param_gradients(); }
+
+int tcnn_trainer_set_params_full_precision(tcnn_trainer_t t, const float* params, size_t n_params, int device_ptr) {
+	return guarded([&] { t->trainer->set_params_full_precision(params, n_params, device_ptr != 0); });
+}
+
+int tcnn_trainer_set_params(tcnn_trainer_t t, const void* params_half, size_t n_params, int device_ptr) {
+	return guarded([&] { t->trainer->set_params(params_half, n_params, device_ptr != 0); });
+}
+
+int tcnn_trainer_initialize_params(tcnn_trainer_t t) {
+	return guarded([&] { t->trainer->initialize_params(); });
+}
+
+int tcnn_trainer_update_hyperparams(tcnn_trainer_t t, const char* json) {
+	return guarded([&] { t->trainer->update_hyperparams(parse_or_empty(json)); });
+}
+
+const char* tcnn_trainer_hyperparams(tcnn_trainer_t t) {
+	t->hyperparams_text = t->trainer->hyperparams().dump();
+	return t->hyperparams_text.c_str();
+}
+
+const char* tcnn_trainer_network_hyperparams(tcnn_trainer_t t) {
+	t->network_hyperparams_text = t->trainer->model().hyperparams().dump();
+	return t->network_hyperparams_text.c_str();
+}
+
+uint32_t tcnn_trainer_optimizer_step_count(tcnn_trainer_t t) { return t->trainer->optimizer().step_count(); }
+
+} // extern "C"

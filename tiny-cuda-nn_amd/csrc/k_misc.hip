@@ -1,0 +1,436 @@
+// k_misc.hip -- streaming kernels around the MLP: OneBlob / Identity encodings, losses, sum reduction, Adam,
+// parameter initialisation and dtype plumbing.  All HBM-bound: 16-byte accesses, wave64 reductions.
+//
+// Replaces (reference, /root/reference/include/tiny-cuda-nn):
+//   encodings/oneblob.h:47-164   kernel_one_blob / _backward          -> k_oneblob_fwd / k_oneblob_bwd_input
+//   encodings/identity.h:46-85   identity / identity_backward         -> k_identity_fwd / k_identity_bwd_input
+//   losses/l2.h:40-74, losses/relative_l2.h:40-75                     -> k_loss
+//   reduce_sum.h:52-157          block_reduce + atomicAdd             -> k_reduce_stage1 / k_reduce_stage2 (deterministic)
+//   optimizers/adam.h:48-119     adam_step                            -> k_adam
+//   random.h:40-55               generate_random_kernel               -> k_random_uniform
+//   common_device.h:990-1014     trim_and_cast / cast / cast_from     -> k_trim_and_cast / k_cast_*
+#include "tcnn_common.h"
+
+#include <hip/hip_fp16.h>
+
+#include <limits>
+
+namespace tcnn_amd {
+namespace {
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// ---- quartic kernel, common_device.h:905-920
+__device__ inline float quartic(float x, float inv_radius) {
+	const float u = x * inv_radius;
+	const float tmp = fmaxf(1 - u * u, 0.0f);
+	return ((float)15 / 16) * tmp * tmp;
+}
+__device__ inline float quartic_cdf_deriv(float x, float inv_radius) { return quartic(x, inv_radius) * inv_radius; }
+__device__ inline float quartic_cdf(float x, float inv_radius) {
+	const float u = x * inv_radius;
+	const float u2 = u * u;
+	const float u4 = u2 * u2;
+	return fmaxf(0.0f, fminf(1.0f, ((float)15 / 16) * u * (1 - ((float)2 / 3) * u2 + ((float)1 / 5) * u4) + 0.5f));
+}
+
+// OneBlob, definition form of oneblob.h:47-67: bin k = C(l_{k+1}) - C(l_k), C(l) = cdf(l-x) + cdf(l-x-1) + cdf(l-x+1),
+// the last bin's right edge is bin 0's left edge + 1 (wrap-around).  One thread per output element (AoS).
+template <typename T>
+__global__ void __launch_bounds__(256) k_oneblob_fwd(const uint32_t n, const uint32_t n_dims, const uint32_t log2_bins, const MatView x, T* __restrict__ out, const uint32_t out_stride) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t i = gid / out_stride;
+	if (i >= n) return;
+	const uint32_t j = gid - i * out_stride;
+	const uint32_t n_bins = 1u << log2_bins;
+	if (j >= n_dims * n_bins) { // oneblob.h:207-209
+		out[gid] = (T)1.0f;
+		return;
+	}
+	const uint32_t dim = j >> log2_bins, bin = j & (n_bins - 1);
+	const float xv = x.data[(size_t)i * x.stride_sample + (size_t)dim * x.stride_dim];
+	const float nb = (float)n_bins;
+	const float lb = scalbnf((float)bin, -(int)log2_bins);
+	const float l = quartic_cdf(lb - xv, nb) + quartic_cdf(lb - xv - 1.0f, nb) + quartic_cdf(lb - xv + 1.0f, nb);
+	const float rb = scalbnf((float)((bin + 1) & (n_bins - 1)), -(int)log2_bins);
+	float r = quartic_cdf(rb - xv, nb) + quartic_cdf(rb - xv - 1.0f, nb) + quartic_cdf(rb - xv + 1.0f, nb);
+	if (bin == n_bins - 1) r += 1;
+	out[gid] = (T)(r - l);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(128) k_oneblob_bwd_input(const uint32_t n, const uint32_t n_dims, const uint32_t log2_bins, const MatView x, const T* __restrict__ dL_dy, const uint32_t dy_stride, const MatViewMut dL_dx) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t i = gid / n_dims;
+	if (i >= n) return;
+	const uint32_t j = gid - i * n_dims;
+	const uint32_t n_bins = 1u << log2_bins;
+	const float nb = (float)n_bins;
+	const float xv = x.data[(size_t)i * x.stride_sample + (size_t)j * x.stride_dim];
+	float result = 0;
+	float left = quartic_cdf_deriv(-xv, nb) + quartic_cdf_deriv(-xv - 1.0f, nb) + quartic_cdf_deriv(-xv + 1.0f, nb);
+	for (uint32_t k = 0; k < n_bins; ++k) {
+		const float rb = scalbnf((float)(k + 1), -(int)log2_bins);
+		const float right = quartic_cdf_deriv(rb - xv, nb) + quartic_cdf_deriv(rb - xv - 1.0f, nb) + quartic_cdf_deriv(rb - xv + 1.0f, nb);
+		const float deriv = left - right;
+		left = right;
+		result += (float)dL_dy[(size_t)i * dy_stride + j * n_bins + k] * deriv;
+	}
+	dL_dx.data[(size_t)i * dL_dx.stride_sample + (size_t)j * dL_dx.stride_dim] = result;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_identity_fwd(const uint32_t n, const uint32_t n_dims, const float scale, const float offset, const MatView x, T* __restrict__ out, const uint32_t out_stride) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t i = gid / out_stride;
+	if (i >= n) return;
+	const uint32_t j = gid - i * out_stride;
+	out[gid] = j >= n_dims ? (T)1.0f : (T)(x.data[(size_t)i * x.stride_sample + (size_t)j * x.stride_dim] * scale + offset);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_identity_bwd_input(const uint32_t n, const uint32_t n_dims, const float scale, const T* __restrict__ dL_dy, const uint32_t dy_stride, const MatViewMut dL_dx) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t i = gid / n_dims;
+	if (i >= n) return;
+	const uint32_t j = gid - i * n_dims;
+	dL_dx.data[(size_t)i * dL_dx.stride_sample + (size_t)j * dL_dx.stride_dim] = (float)(T)((float)dL_dy[(size_t)i * dy_stride + j] * scale);
+}
+
+// ---- loss: one thread per padded output element, l2.h:40-74 / relative_l2.h:40-75
+__global__ void __launch_bounds__(256) k_loss(
+	const uint32_t type, const uint32_t n_elements, const uint32_t stride, const uint32_t dims, const float loss_scale,
+	const half_t* __restrict__ predictions, const float* __restrict__ targets, float* __restrict__ values, half_t* __restrict__ gradients, const float* __restrict__ data_pdf
+) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	const uint32_t intra = i % stride;
+	const uint32_t inter = i / stride;
+	if (intra >= dims) {
+		values[i] = 0;
+		gradients[i] = (half_t)0.0f;
+		return;
+	}
+	const uint32_t target_idx = inter * dims + intra;
+	const uint32_t n_total = n_elements / stride * dims;
+	const float prediction = (float)predictions[i];
+	const float pdf = data_pdf ? data_pdf[target_idx] : 1;
+	const float difference = prediction - targets[target_idx];
+	float value, gradient;
+	if (type == (uint32_t)LossType::RelativeL2) {
+		const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
+		value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
+		gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+	} else {
+		value = difference * difference / pdf / n_total;
+		gradient = 2 * difference / pdf;
+	}
+	values[i] = value;
+	gradients[i] = (half_t)(loss_scale * gradient / n_total);
+}
+
+// ---- deterministic two-stage sum: stage 1 = one partial per block (fixed grid), stage 2 = one block sums the partials
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+__device__ inline float block_sum_256(float v, float* smem4) {
+	v = wave_sum(v);
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0) smem4[w] = v;
+	__syncthreads();
+	return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+
+__global__ void __launch_bounds__(256) k_reduce_stage1(const size_t n, const float* __restrict__ values, float* __restrict__ partials) {
+	__shared__ float sm[4];
+	float acc = 0.0f;
+	const size_t n4 = n / 4;
+	const float4* v4 = (const float4*)values;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+		const float4 v = v4[i];
+		acc += (v.x + v.y) + (v.z + v.w);
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) acc += values[n4 * 4 + threadIdx.x];
+	const float s = block_sum_256(acc, sm);
+	if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_reduce_stage2(const uint32_t n_partials, const float* __restrict__ partials, float* __restrict__ result) {
+	__shared__ float sm[4];
+	float acc = 0.0f;
+	for (uint32_t i = threadIdx.x; i < n_partials; i += 256) acc += partials[i];
+	const float s = block_sum_256(acc, sm);
+	if (threadIdx.x == 0) *result = s;
+}
+
+// ---- Adam, adam.h:48-119.  4 parameters per thread, 16-byte accesses; 36 B/param of HBM traffic is the floor.
+struct AdamArgs {
+	float relative_weight_decay, absolute_weight_decay, weight_clipping_magnitude, loss_scale, learning_rate, non_matrix_learning_rate_factor;
+	float beta1, beta2, epsilon, lower_lr_bound, upper_lr_bound, l2_reg;
+	uint32_t optimize_matrix_params, optimize_non_matrix_params;
+};
+
+__device__ inline void adam_one(const AdamArgs& a, const bool is_matrix, const half_t g_h, float& w_fp, half_t& w_h, float& m1, float& m2, uint32_t& step) {
+	float gradient = (float)g_h / a.loss_scale;
+	if (!is_matrix) {
+		if (!a.optimize_non_matrix_params || gradient == 0) return;
+	} else {
+		if (!a.optimize_matrix_params) return;
+	}
+	const float weight_fp = w_fp;
+	if (is_matrix) gradient += a.l2_reg * weight_fp;
+	const float gradient_sq = gradient * gradient;
+	const float first_moment = m1 = a.beta1 * m1 + (1 - a.beta1) * gradient;
+	const float second_moment = m2 = a.beta2 * m2 + (1 - a.beta2) * gradient_sq;
+	float learning_rate = a.learning_rate;
+	if (!is_matrix) learning_rate *= a.non_matrix_learning_rate_factor;
+	const uint32_t current_step = ++step;
+	learning_rate *= sqrtf(1 - powf(a.beta2, (float)current_step)) / (1 - powf(a.beta1, (float)current_step));
+	const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), a.lower_lr_bound), a.upper_lr_bound);
+	// weight_decay(rel * lr, abs * lr, w), common_device.h:870-873
+	const float decayed_weight = (1 - a.relative_weight_decay * learning_rate) * weight_fp - copysignf(a.absolute_weight_decay * learning_rate, weight_fp);
+	float new_weight = decayed_weight - effective_learning_rate * first_moment;
+	if (a.weight_clipping_magnitude != 0.0f) new_weight = fminf(fmaxf(new_weight, -a.weight_clipping_magnitude), a.weight_clipping_magnitude);
+	w_fp = new_weight;
+	w_h = (half_t)new_weight;
+}
+
+__global__ void __launch_bounds__(256) k_adam(
+	const AdamArgs a, const size_t n, const size_t n_matrix,
+	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps
+) {
+	const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (i4 >= n) return;
+	if (i4 + 4 <= n) {
+		const h4 gv = *(const h4*)(g + i4);
+		// grid (non-matrix) entries whose 4 gradients are all zero are skipped without touching the other 32 B/param
+		const bool all_non_matrix = i4 >= n_matrix;
+		if (all_non_matrix && gv[0] == (half_t)0.0f && gv[1] == (half_t)0.0f && gv[2] == (half_t)0.0f && gv[3] == (half_t)0.0f) return;
+		float4 wf = *(const float4*)(w_fp + i4);
+		float4 a1 = *(const float4*)(m1 + i4);
+		float4 a2 = *(const float4*)(m2 + i4);
+		uint4 st = *(const uint4*)(steps + i4);
+		const h4 wh = *(const h4*)(w + i4);
+		half_t w0 = wh[0], w1 = wh[1], w2 = wh[2], w3 = wh[3];
+		adam_one(a, i4 + 0 < n_matrix, gv[0], wf.x, w0, a1.x, a2.x, st.x);
+		adam_one(a, i4 + 1 < n_matrix, gv[1], wf.y, w1, a1.y, a2.y, st.y);
+		adam_one(a, i4 + 2 < n_matrix, gv[2], wf.z, w2, a1.z, a2.z, st.z);
+		adam_one(a, i4 + 3 < n_matrix, gv[3], wf.w, w3, a1.w, a2.w, st.w);
+		*(float4*)(w_fp + i4) = wf;
+		*(float4*)(m1 + i4) = a1;
+		*(float4*)(m2 + i4) = a2;
+		*(uint4*)(steps + i4) = st;
+		*(h4*)(w + i4) = h4{w0, w1, w2, w3};
+	} else {
+		for (size_t i = i4; i < n; ++i) adam_one(a, i < n_matrix, g[i], w_fp[i], w[i], m1[i], m2[i], steps[i]);
+	}
+}
+
+// ---- pcg32 strided uniform fill, random.h:40-55 (N_TO_GENERATE = 4, thread i advances a copy of the rng by 4 i)
+__global__ void __launch_bounds__(128) k_random_uniform(const size_t n, const uint64_t state, const uint64_t inc, float* __restrict__ out, const float lower, const float upper) {
+	const uint64_t MULT = 0x5851f42d4c957f2dULL;
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t n_threads = (size_t)blockDim.x * gridDim.x;
+	// advance(4 i)
+	uint64_t cur_mult = MULT, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+	uint64_t delta = (uint64_t)i * 4;
+	while (delta > 0) {
+		if (delta & 1) {
+			acc_mult *= cur_mult;
+			acc_plus = acc_plus * cur_mult + cur_plus;
+		}
+		cur_plus = (cur_mult + 1) * cur_plus;
+		cur_mult *= cur_mult;
+		delta /= 2;
+	}
+	uint64_t st = acc_mult * state + acc_plus;
+	for (size_t j = 0; j < 4; ++j) {
+		const size_t idx = i + n_threads * j;
+		if (idx >= n) return;
+		const uint64_t old = st;
+		st = old * MULT + inc;
+		const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+		const uint32_t rot = (uint32_t)(old >> 59u);
+		const uint32_t u = ((xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31)));
+		const float f = __uint_as_float((u >> 9) | 0x3f800000u) - 1.0f;
+		out[idx] = f * (upper - lower) + lower;
+	}
+}
+
+__global__ void __launch_bounds__(256) k_cast_f2h(const size_t n, const float* __restrict__ in, half_t* __restrict__ out) {
+	const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (i + 4 <= n) {
+		const float4 v = *(const float4*)(in + i);
+		*(h4*)(out + i) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+	} else {
+		for (size_t k = i; k < n; ++k) out[k] = (half_t)in[k];
+	}
+}
+
+__global__ void __launch_bounds__(256) k_cast_h2f(const size_t n, const half_t* __restrict__ in, float* __restrict__ out) {
+	const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (i + 4 <= n) {
+		const h4 v = *(const h4*)(in + i);
+		*(float4*)(out + i) = float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+	} else {
+		for (size_t k = i; k < n; ++k) out[k] = (float)in[k];
+	}
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_trim_and_cast(const uint32_t n, const uint32_t in_stride, const uint32_t dims, const T* __restrict__ in, const MatViewMut out) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t i = gid / dims;
+	if (i >= n) return;
+	const uint32_t d = gid - i * dims;
+	out.data[(size_t)i * out.stride_sample + (size_t)d * out.stride_dim] = (float)in[(size_t)i * in_stride + d];
+}
+
+__global__ void __launch_bounds__(256) k_fill_half(const size_t n, half_t* __restrict__ out, const half_t v) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = v;
+}
+
+inline uint32_t log2_exact(uint32_t v) {
+	uint32_t l = 0;
+	while ((1u << l) < v) ++l;
+	return l;
+}
+
+inline uint32_t blocks_for(uint64_t total, uint32_t threads) {
+	const uint64_t b = (total + threads - 1) / threads;
+	CHECK_THROW(b < (1ull << 31));
+	return (uint32_t)b;
+}
+
+} // namespace
+
+void oneblob_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, uint32_t n_bins, MatView x, void* out, uint32_t out_stride) {
+	const uint64_t total = (uint64_t)n * out_stride;
+	if (total == 0) return;
+	CHECK_THROW(total < (1ull << 32));
+	const uint32_t lb = log2_exact(n_bins);
+	if (fp32) hipLaunchKernelGGL(k_oneblob_fwd<float>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, n_dims, lb, x, (float*)out, out_stride);
+	else hipLaunchKernelGGL(k_oneblob_fwd<half_t>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, n_dims, lb, x, (half_t*)out, out_stride);
+}
+
+void oneblob_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, uint32_t n_bins, MatView x, const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx) {
+	const uint64_t total = (uint64_t)n * n_dims;
+	if (total == 0) return;
+	const uint32_t lb = log2_exact(n_bins);
+	if (fp32) hipLaunchKernelGGL(k_oneblob_bwd_input<float>, dim3(blocks_for(total, 128)), dim3(128), 0, stream, n, n_dims, lb, x, (const float*)dL_dy, dy_stride, dL_dx);
+	else hipLaunchKernelGGL(k_oneblob_bwd_input<half_t>, dim3(blocks_for(total, 128)), dim3(128), 0, stream, n, n_dims, lb, x, (const half_t*)dL_dy, dy_stride, dL_dx);
+}
+
+void identity_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, float scale, float offset, MatView x, void* out, uint32_t out_stride) {
+	const uint64_t total = (uint64_t)n * out_stride;
+	if (total == 0) return;
+	CHECK_THROW(total < (1ull << 32));
+	if (fp32) hipLaunchKernelGGL(k_identity_fwd<float>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, n_dims, scale, offset, x, (float*)out, out_stride);
+	else hipLaunchKernelGGL(k_identity_fwd<half_t>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, n_dims, scale, offset, x, (half_t*)out, out_stride);
+}
+
+void identity_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, float scale, const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx) {
+	const uint64_t total = (uint64_t)n * n_dims;
+	if (total == 0) return;
+	if (fp32) hipLaunchKernelGGL(k_identity_bwd_input<float>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, n_dims, scale, (const float*)dL_dy, dy_stride, dL_dx);
+	else hipLaunchKernelGGL(k_identity_bwd_input<half_t>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, n_dims, scale, (const half_t*)dL_dy, dy_stride, dL_dx);
+}
+
+void loss_evaluate(hipStream_t stream, LossType type, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale,
+                   const void* pred_half, const float* target, float* values, void* grads_half, const float* data_pdf) {
+	const uint64_t total = (uint64_t)n * stride;
+	if (total == 0) return;
+	CHECK_THROW(total < (1ull << 32));
+	hipLaunchKernelGGL(k_loss, dim3(blocks_for(total, 256)), dim3(256), 0, stream, (uint32_t)type, (uint32_t)total, stride, dims, loss_scale,
+	                   (const half_t*)pred_half, target, values, (half_t*)grads_half, data_pdf);
+}
+
+void reduce_sum(hipStream_t stream, size_t n, const float* values, float* partials, float* result_dev) {
+	uint32_t blocks = blocks_for((n + 3) / 4, 256);
+	if (blocks > 1024) blocks = 1024;
+	if (blocks == 0) blocks = 1;
+	hipLaunchKernelGGL(k_reduce_stage1, dim3(blocks), dim3(256), 0, stream, n, values, partials);
+	hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(256), 0, stream, blocks, partials, result_dev);
+}
+
+void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
+               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps) {
+	if (n == 0) return;
+	AdamArgs a;
+	a.relative_weight_decay = h.relative_decay;
+	a.absolute_weight_decay = h.absolute_decay;
+	a.weight_clipping_magnitude = h.clipping_magnitude;
+	a.loss_scale = loss_scale;
+	a.learning_rate = h.learning_rate;
+	a.non_matrix_learning_rate_factor = h.non_matrix_learning_rate_factor;
+	a.beta1 = h.beta1;
+	a.beta2 = h.beta2;
+	a.epsilon = h.epsilon;
+	a.lower_lr_bound = 0;
+	a.upper_lr_bound = std::numeric_limits<float>::max();
+	if (h.adabound) { // adam.h:157-160
+		a.lower_lr_bound = 0.1f - 0.1f / ((1 - h.beta2) * (float)current_step + 1);
+		a.upper_lr_bound = 0.1f + 0.1f / ((1 - h.beta2) * (float)current_step);
+	}
+	a.l2_reg = h.l2_reg;
+	a.optimize_matrix_params = h.optimize_matrix_params;
+	a.optimize_non_matrix_params = h.optimize_non_matrix_params;
+	hipLaunchKernelGGL(k_adam, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps);
+}
+
+namespace {
+void pcg32_advance_host(uint64_t* st, uint64_t delta) {
+	const uint64_t MULT = 0x5851f42d4c957f2dULL;
+	uint64_t cur_mult = MULT, cur_plus = st[1], acc_mult = 1u, acc_plus = 0u;
+	while (delta > 0) {
+		if (delta & 1) {
+			acc_mult *= cur_mult;
+			acc_plus = acc_plus * cur_mult + cur_plus;
+		}
+		cur_plus = (cur_mult + 1) * cur_plus;
+		cur_mult *= cur_mult;
+		delta /= 2;
+	}
+	st[0] = acc_mult * st[0] + acc_plus;
+}
+} // namespace
+
+void generate_random_uniform(hipStream_t stream, uint64_t* state_inc_host, size_t n, float* out, float lower, float upper) {
+	if (n > 0) {
+		const size_t n_threads = (n + 3) / 4;
+		const uint32_t blocks = blocks_for(n_threads, 128); // n_blocks_linear(n_threads), N_THREADS_LINEAR = 128 (common.h:236-245)
+		hipLaunchKernelGGL(k_random_uniform, dim3(blocks), dim3(128), 0, stream, n, state_inc_host[0], state_inc_host[1], out, lower, upper);
+	}
+	pcg32_advance_host(state_inc_host, (uint64_t)n); // random.h:64
+}
+
+void cast_float_to_half(hipStream_t stream, size_t n, const float* in, void* out) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_cast_f2h, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, stream, n, in, (half_t*)out);
+}
+
+void cast_half_to_float(hipStream_t stream, size_t n, const void* in, float* out) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_cast_h2f, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, stream, n, (const half_t*)in, out);
+}
+
+void trim_and_cast(hipStream_t stream, bool fp32, uint32_t n, uint32_t in_stride, uint32_t dims, const void* in, MatViewMut out) {
+	const uint64_t total = (uint64_t)n * dims;
+	if (total == 0) return;
+	CHECK_THROW(total < (1ull << 32));
+	if (fp32) hipLaunchKernelGGL(k_trim_and_cast<float>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, in_stride, dims, (const float*)in, out);
+	else hipLaunchKernelGGL(k_trim_and_cast<half_t>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, in_stride, dims, (const half_t*)in, out);
+}
+
+void fill_half(hipStream_t stream, size_t n, void* out, float value) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_fill_half, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, (half_t*)out, (half_t)value);
+}
+
+} // namespace tcnn_amd

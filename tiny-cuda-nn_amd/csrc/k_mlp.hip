@@ -1,0 +1,590 @@
+// k_mlp.hip -- fully fused fp16 MLP for gfx950 (wave64, MFMA 16x16x32 f16, fp32 accumulate).
+//
+// Replaces (reference, /root/reference):
+//   src/fully_fused_mlp.cu:500-557  kernel_mlp_fused            -> k_mlp_fwd
+//   src/fully_fused_mlp.cu:151-259  kernel_mlp_fused_backward   -> k_mlp_bwd
+//   src/fully_fused_mlp.cu:785,819,828 + include/tiny-cuda-nn/cutlass_matmul.h:438-479 (split-K weight gradients)
+//                                                               -> k_wgrad + k_wgrad_reduce
+//
+// Design (NOT the reference's tiling -- see DESIGN.md "MLP"):
+//   Activations are kept TRANSPOSED: H[feature][sample].  One MFMA computes a 16(feature) x 16(sample) tile
+//       D[f][s] = sum_k W[f][k] * H_prev[k][s]        A = weights, B = previous activations.
+//   With v_mfma_f32_16x16x32_f16 the result tile has the SAMPLE on the lane (lane & 15) and 4 consecutive features in
+//   the lane's 4 accumulator registers (feature = 16*tile + 4*(lane >> 4) + reg).  That is exactly the B-operand
+//   register layout of the NEXT layer's MFMA (k on registers, column on the lane) up to a fixed permutation of k --
+//   so a wave chains all layers of the network in registers: no LDS round trip, no barrier, no cross-wave traffic.
+//   The k permutation is absorbed into the A operand: weights are pre-permuted once per call into "fragment images"
+//   (k_mlp_prep), 1 KiB per (16-row tile, 32-deep k-step), read with one 16-byte load per lane.
+//
+//   k order of a chained layer, k-step s, lane quarter q = lane >> 4, element j = 0..7:
+//       k(s, q, j) = 32 s + 16 (j >> 2) + 4 q + (j & 3)
+//   (elements 0..3 come from accumulator tile 2s, elements 4..7 from tile 2s+1.)
+//   Layer 0 reads its B operand from memory ([n][in] half, 16 bytes per lane) in natural order k = 32 s + 8 q + j.
+#include "tcnn_common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace tcnn_amd {
+namespace {
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr float K_ACT = 10.0f;
+
+__device__ inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// common_device.h:102-160, applied to the fp16-rounded accumulator like the reference's warp_activation
+__device__ inline half_t activation_fwd(uint32_t act, half_t pre) {
+	const float x = (float)pre;
+	switch (act) {
+		case (uint32_t)Activation::ReLU: return x > 0.0f ? pre : (half_t)0.0f;
+		case (uint32_t)Activation::LeakyReLU: return pre * (half_t)(x > 0.0f ? 1.0f : 0.01f);
+		case (uint32_t)Activation::Exponential: return (half_t)expf(x);
+		case (uint32_t)Activation::Sine: return (half_t)sinf(x);
+		case (uint32_t)Activation::Sigmoid: return (half_t)logistic(x);
+		case (uint32_t)Activation::Squareplus: { const float y = x * K_ACT; return (half_t)(0.5f * (y + sqrtf(y * y + 4)) / K_ACT); }
+		case (uint32_t)Activation::Softplus: return (half_t)(logf(expf(x * K_ACT) + 1.0f) / K_ACT);
+		case (uint32_t)Activation::Tanh: return (half_t)tanhf(x);
+		default: return pre;
+	}
+}
+
+// common_device.h:241-297: derivative from the forward OUTPUT
+__device__ inline half_t activation_bwd(uint32_t act, half_t grad, half_t fwd) {
+	const float y = (float)fwd;
+	switch (act) {
+		case (uint32_t)Activation::ReLU: return y > 0.0f ? grad : grad * (half_t)0.0f;
+		case (uint32_t)Activation::LeakyReLU: return grad * (half_t)(y > 0.0f ? 1.0f : 0.01f);
+		case (uint32_t)Activation::Exponential: return grad * fwd;
+		case (uint32_t)Activation::Sigmoid: return grad * (half_t)(fwd * (half_t)(1.0f - y));
+		case (uint32_t)Activation::Squareplus: { const float t = y * K_ACT; return grad * (half_t)(t * t / (t * t + 1)); }
+		case (uint32_t)Activation::Softplus: return grad * (half_t)(1.0f - expf(-y * K_ACT));
+		case (uint32_t)Activation::Tanh: return grad * (half_t)(1.0f - (y * y));
+		default: return grad; // None; Sine is unsupported from outputs (common_device.h:261-265)
+	}
+}
+
+template <int ACT> __device__ inline half_t act_fwd_t(uint32_t act, half_t v) {
+	if constexpr (ACT == (int)Activation::ReLU) return v > (half_t)0.0f ? v : (half_t)0.0f;
+	else if constexpr (ACT == (int)Activation::None) return v;
+	else return activation_fwd(act, v);
+}
+template <int ACT> __device__ inline half_t act_bwd_t(uint32_t act, half_t g, half_t fwd) {
+	if constexpr (ACT == (int)Activation::ReLU) return fwd > (half_t)0.0f ? g : g * (half_t)0.0f;
+	else if constexpr (ACT == (int)Activation::None) return g;
+	else return activation_bwd(act, g, fwd);
+}
+
+__device__ inline f4 mfma(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// k index of element j of a chained-layer fragment
+__host__ __device__ inline uint32_t k_chain(uint32_t s, uint32_t q, uint32_t j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
+__host__ __device__ inline uint32_t k_natural(uint32_t s, uint32_t q, uint32_t j) { return 32 * s + 8 * q + j; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// weights (row-major half) -> fragment images.  One thread per image element.
+// forward fragment (layer l, row tile t, k-step s), lane (r = lane & 15, q = lane >> 4), element j:
+//     W_l[16 t + r][k]           k = natural or chained order, 0 beyond the matrix
+// backward fragment (A = W_l^T; row tile t over the COLUMNS of W_l, k over its ROWS):
+//     W_l[k_chain(s, q, j)][16 t + r]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mlp_prep(const MlpDesc d, const half_t* __restrict__ params, half_t* __restrict__ image, const uint32_t n_frags_total) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= n_frags_total * 512) return;
+	uint32_t frag = gid >> 9;
+	const uint32_t lane = (gid >> 3) & 63;
+	const uint32_t j = gid & 7;
+	const uint32_t r = lane & 15, q = lane >> 4;
+
+	const bool bwd = frag >= d.n_frags_fwd;
+	if (bwd) frag -= d.n_frags_fwd;
+	uint32_t l = 0;
+	for (uint32_t i = 1; i < d.n_layers; ++i) {
+		if (frag >= (bwd ? d.layers[i].bwd_off : d.layers[i].fwd_off)) l = i;
+	}
+	const MlpLayer L = d.layers[l];
+	const half_t* W = params + L.w_off;
+	half_t v = (half_t)0.0f;
+	if (!bwd) {
+		const uint32_t local = frag - L.fwd_off;
+		const uint32_t t = local / L.ks_fwd, s = local - t * L.ks_fwd;
+		const uint32_t row = 16 * t + r;
+		const uint32_t k = L.natural_k ? k_natural(s, q, j) : k_chain(s, q, j);
+		if (row < L.rows && k < L.cols) v = W[(size_t)row * L.cols + k];
+	} else {
+		const uint32_t local = frag - L.bwd_off;
+		const uint32_t t = local / L.ks_bwd, s = local - t * L.ks_bwd;
+		const uint32_t col = 16 * t + r;
+		const uint32_t k = k_chain(s, q, j);
+		if (col < L.cols && k < L.rows) v = W[(size_t)k * L.cols + col];
+	}
+	image[gid] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+	const half_t* x;      // [n][in_width]
+	half_t* out;          // [n][out_width]
+	half_t* hidden;       // optional [n_hidden][n][width]
+	const h8* image;      // forward fragments
+	uint32_t n;
+};
+
+// pack NB accumulator column blocks of T row tiles into chained B fragments (KS k-steps), applying the activation
+template <int T, int KS, int NB, int ACT>
+__device__ inline void activate_pack(const f4 (&acc)[T][NB], h8 (&hf)[KS][NB], uint32_t act) {
+#pragma unroll
+	for (int s = 0; s < KS; ++s) {
+#pragma unroll
+		for (int b = 0; b < NB; ++b) {
+			h8 v;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				v[r] = act_fwd_t<ACT>(act, (half_t)acc[2 * s][b][r]);
+				if (2 * s + 1 < T) v[4 + r] = act_fwd_t<ACT>(act, (half_t)acc[(2 * s + 1 < T) ? 2 * s + 1 : 0][b][r]);
+				else v[4 + r] = (half_t)0.0f;
+			}
+			hf[s][b] = v;
+		}
+	}
+}
+
+template <int W, int NB, int ACT>
+__global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
+	constexpr int T = W / 16;
+	constexpr int KS = (T + 1) / 2;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t c = lane & 15, q = lane >> 4;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t n_iters = a.n / (16 * NB);
+	const uint32_t in_w = d.in_width, out_w = d.out_width;
+
+	for (uint32_t it = wave; it < n_iters; it += n_waves) {
+		const uint32_t s0 = it * 16 * NB;
+
+		// ---- layer 0: B operand straight from memory, natural k order
+		f4 acc[T][NB];
+#pragma unroll
+		for (int t = 0; t < T; ++t)
+#pragma unroll
+			for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+		{
+			const uint32_t ks0 = d.layers[0].ks_fwd;
+			const h8* img = a.image + (size_t)d.layers[0].fwd_off * 64 + lane;
+			for (uint32_t s = 0; s < ks0; ++s) {
+				h8 bf[NB];
+				const uint32_t k0 = 32 * s + 8 * q;
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					if (k0 < in_w) bf[b] = *(const h8*)(a.x + (size_t)(s0 + 16 * b + c) * in_w + k0);
+					else bf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+				}
+#pragma unroll
+				for (int t = 0; t < T; ++t) {
+					const h8 af = img[(size_t)(t * ks0 + s) * 64];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, bf[b], acc[t][b]);
+				}
+			}
+		}
+		h8 hf[KS][NB];
+		activate_pack<T, KS, NB, ACT>(acc, hf, d.activation);
+
+		auto store_hidden = [&](uint32_t l) {
+			if (!a.hidden) return;
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					h4 v;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) v[r] = hf[t / 2][b][(t & 1) * 4 + r];
+					*(h4*)(a.hidden + ((size_t)l * a.n + s0 + 16 * b + c) * W + 16 * t + 4 * q) = v;
+				}
+		};
+		store_hidden(0);
+
+		// ---- hidden layers 1 .. n_hidden-1: chained in registers
+		for (uint32_t l = 1; l < d.n_hidden; ++l) {
+			const h8* img = a.image + (size_t)d.layers[l].fwd_off * 64 + lane;
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+#pragma unroll
+				for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+#pragma unroll
+			for (int s = 0; s < KS; ++s) {
+#pragma unroll
+				for (int t = 0; t < T; ++t) {
+					const h8 af = img[(size_t)(t * KS + s) * 64];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
+				}
+			}
+			activate_pack<T, KS, NB, ACT>(acc, hf, d.activation);
+			store_hidden(l);
+		}
+
+		// ---- output layer: out_width / 16 row tiles
+		{
+			const MlpLayer Lo = d.layers[d.n_layers - 1];
+			const h8* img = a.image + (size_t)Lo.fwd_off * 64 + lane;
+			for (uint32_t to = 0; to < out_w / 16; ++to) {
+				f4 o[NB];
+#pragma unroll
+				for (int b = 0; b < NB; ++b) o[b] = f4{0, 0, 0, 0};
+#pragma unroll
+				for (int s = 0; s < KS; ++s) {
+					const h8 af = img[(size_t)(to * KS + s) * 64];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], o[b]);
+				}
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					h4 v;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) v[r] = activation_fwd(d.output_activation, (half_t)o[b][r]);
+					*(h4*)(a.out + (size_t)(s0 + 16 * b + c) * out_w + 16 * to + 4 * q) = v;
+				}
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward (data gradients), reference-shaped: reads the stored forward activations, writes dL/dhidden for the
+// weight-gradient kernel.  (The fused trainer path in k_train.hip never materialises either.)
+// ------------------------------------------------------------------------------------------------------------------
+struct BwdArgs {
+	const half_t* dL_dout; // [n][out_width]
+	const half_t* out;     // [n][out_width]   (only read when output_activation != None)
+	const half_t* hidden;  // [n_hidden][n][width]
+	half_t* dhidden;       // [n_hidden][n][width]
+	half_t* dL_dx;         // optional [n][in_width]
+	const h8* image;       // backward fragments
+	uint32_t n;
+};
+
+template <int W, int NB, int ACT>
+__global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs a) {
+	constexpr int T = W / 16;
+	constexpr int KS = (T + 1) / 2;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t c = lane & 15, q = lane >> 4;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	const uint32_t n_iters = a.n / (16 * NB);
+	const uint32_t in_w = d.in_width, out_w = d.out_width;
+	const uint32_t nh = d.n_hidden;
+
+	for (uint32_t it = wave; it < n_iters; it += n_waves) {
+		const uint32_t s0 = it * 16 * NB;
+		f4 acc[T][NB];
+#pragma unroll
+		for (int t = 0; t < T; ++t)
+#pragma unroll
+			for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+
+		// ---- dH_last (pre-activation-derivative) = Wout^T * dY ; dY loaded in chained k order (two 8-byte loads)
+		{
+			const MlpLayer Lo = d.layers[d.n_layers - 1];
+			const uint32_t kso = Lo.ks_bwd;
+			const h8* img = a.image + (size_t)Lo.bwd_off * 64 + lane;
+			for (uint32_t s = 0; s < kso; ++s) {
+				h8 bf[NB];
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					const size_t row = (size_t)(s0 + 16 * b + c) * out_w;
+					h4 lo = h4{0, 0, 0, 0}, hi = h4{0, 0, 0, 0};
+					const uint32_t k_lo = 32 * s + 4 * q, k_hi = 32 * s + 16 + 4 * q;
+					if (k_lo < out_w) {
+						lo = *(const h4*)(a.dL_dout + row + k_lo);
+						if (d.output_activation != (uint32_t)Activation::None) {
+							const h4 ov = *(const h4*)(a.out + row + k_lo);
+#pragma unroll
+							for (int r = 0; r < 4; ++r) lo[r] = activation_bwd(d.output_activation, lo[r], ov[r]);
+						}
+					}
+					if (k_hi < out_w) {
+						hi = *(const h4*)(a.dL_dout + row + k_hi);
+						if (d.output_activation != (uint32_t)Activation::None) {
+							const h4 ov = *(const h4*)(a.out + row + k_hi);
+#pragma unroll
+							for (int r = 0; r < 4; ++r) hi[r] = activation_bwd(d.output_activation, hi[r], ov[r]);
+						}
+					}
+					bf[b] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+				}
+#pragma unroll
+				for (int t = 0; t < T; ++t) {
+					const h8 af = img[(size_t)(t * kso + s) * 64];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, bf[b], acc[t][b]);
+				}
+			}
+		}
+
+		h8 hf[KS][NB];
+		for (int l = (int)nh - 1; l >= 0; --l) {
+			// acc = W_{l+1}^T dH_{l+1}; multiply by act'(H_l) (from the stored forward output), store, pack
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					const size_t off = ((size_t)l * a.n + s0 + 16 * b + c) * W + 16 * t + 4 * q;
+					const h4 hv = *(const h4*)(a.hidden + off);
+					h4 g;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) g[r] = act_bwd_t<ACT>(d.activation, (half_t)acc[t][b][r], hv[r]);
+					*(h4*)(a.dhidden + off) = g;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) hf[t / 2][b][(t & 1) * 4 + r] = g[r];
+				}
+			if constexpr (T & 1) {
+#pragma unroll
+				for (int b = 0; b < NB; ++b)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) hf[KS - 1][b][4 + r] = (half_t)0.0f;
+			}
+			if (l > 0) {
+				const h8* img = a.image + (size_t)d.layers[l].bwd_off * 64 + lane;
+#pragma unroll
+				for (int t = 0; t < T; ++t)
+#pragma unroll
+					for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+#pragma unroll
+				for (int s = 0; s < KS; ++s) {
+#pragma unroll
+					for (int t = 0; t < T; ++t) {
+						const h8 af = img[(size_t)(t * KS + s) * 64];
+#pragma unroll
+						for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
+					}
+				}
+			}
+		}
+
+		// ---- dX = W0^T dH_0, in_width / 16 row tiles
+		if (a.dL_dx) {
+			const h8* img = a.image + (size_t)d.layers[0].bwd_off * 64 + lane;
+			for (uint32_t ti = 0; ti < in_w / 16; ++ti) {
+				f4 o[NB];
+#pragma unroll
+				for (int b = 0; b < NB; ++b) o[b] = f4{0, 0, 0, 0};
+#pragma unroll
+				for (int s = 0; s < KS; ++s) {
+					const h8 af = img[(size_t)(ti * KS + s) * 64];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], o[b]);
+				}
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					const h4 v = h4{(half_t)o[b][0], (half_t)o[b][1], (half_t)o[b][2], (half_t)o[b][3]};
+					*(h4*)(a.dL_dx + (size_t)(s0 + 16 * b + c) * in_w + 16 * ti + 4 * q) = v;
+				}
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradients: dW[R x C] = sum_i dO[i][R]^T In[i][C].
+// Chunks of 64 samples are staged in LDS as [sample][feature] rows; MFMA operands need [feature on lane][8 samples in
+// registers], which is exactly what gfx950's transposing LDS read (ds_read_b64_tr_b16) delivers from that image.
+// Each workgroup accumulates a private partial in registers over its chunks and writes one fp32 slab; k_wgrad_reduce
+// sums the slabs in a fixed order (bitwise reproducible, no atomics).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WG_CHUNK = 64;       // samples per staged chunk (2 k-steps)
+constexpr int WG_MAX_TILES = 16;   // accumulator tiles per wave: R*C <= 128*128 with 4 waves
+constexpr int WG_PAD = 8;          // halfs of row padding in LDS (keeps rows 16-byte aligned, breaks the power-of-2 stride)
+
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__device__ inline h4 lds_read_tr(const half_t* p) {
+	fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((fp16x4 __attribute__((address_space(3)))*)p);
+	return __builtin_bit_cast(h4, v);
+}
+
+__global__ void __launch_bounds__(256) k_wgrad(
+	const uint32_t n, const half_t* __restrict__ dO, const uint32_t ldo, const uint32_t R,
+	const half_t* __restrict__ In, const uint32_t ldi, const uint32_t C, float* __restrict__ slabs
+) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const uint32_t rp = R + WG_PAD, cp = C + WG_PAD; // padded row lengths (halfs)
+	half_t* P = (half_t*)smem;                        // [WG_CHUNK][rp]
+	half_t* Q = P + (size_t)WG_CHUNK * rp;            // [WG_CHUNK][cp]
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63, w = tid >> 6;
+	const uint32_t grp = lane >> 4, li = lane & 15; // 16-lane group / lane within the group
+	const uint32_t TR = R / 16, TC = C / 16;
+	const uint32_t n_tiles = TR * TC;
+	const uint32_t per = (n_tiles + 3) / 4;
+	const uint32_t tile0 = w * per;
+
+	f4 acc[WG_MAX_TILES];
+#pragma unroll
+	for (int i = 0; i < WG_MAX_TILES; ++i) acc[i] = f4{0, 0, 0, 0};
+
+	const uint32_t n_chunks = n / WG_CHUNK;
+	for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+		const size_t base = (size_t)ch * WG_CHUNK;
+		// stage: 16-byte pieces, rows are contiguous in global memory
+		const uint32_t ppr = R / 8, pqr = C / 8;
+		for (uint32_t p = tid; p < WG_CHUNK * ppr; p += 256) {
+			const uint32_t row = p / ppr, col = (p - row * ppr) * 8;
+			*(h8*)(P + (size_t)row * rp + col) = *(const h8*)(dO + (base + row) * ldo + col);
+		}
+		for (uint32_t p = tid; p < WG_CHUNK * pqr; p += 256) {
+			const uint32_t row = p / pqr, col = (p - row * pqr) * 8;
+			*(h8*)(Q + (size_t)row * cp + col) = *(const h8*)(In + (base + row) * ldi + col);
+		}
+		__syncthreads();
+
+#pragma unroll
+		for (int i = 0; i < WG_MAX_TILES; ++i) {
+			const uint32_t tile = tile0 + i;
+			if (i < (int)per && tile < n_tiles) { // wave-uniform
+				const uint32_t tr = tile / TC, tc = tile - tr * TC;
+#pragma unroll
+				for (int ks = 0; ks < WG_CHUNK / 32; ++ks) {
+					// lane (li = 4*qq + p) supplies the address of sample row (.. + qq), feature columns 4p..4p+3;
+					// lane li receives feature column li of the 4 sample rows.
+					const uint32_t row_lo = 32 * ks + 8 * grp + (li >> 2);
+					const uint32_t colo = 4 * (li & 3);
+					const h4 a_lo = lds_read_tr(P + (size_t)row_lo * rp + 16 * tr + colo);
+					const h4 a_hi = lds_read_tr(P + (size_t)(row_lo + 4) * rp + 16 * tr + colo);
+					const h4 b_lo = lds_read_tr(Q + (size_t)row_lo * cp + 16 * tc + colo);
+					const h4 b_hi = lds_read_tr(Q + (size_t)(row_lo + 4) * cp + 16 * tc + colo);
+					const h8 af = h8{a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+					const h8 bf = h8{b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+					acc[i] = mfma(af, bf, acc[i]);
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	float* slab = slabs + (size_t)blockIdx.x * R * C;
+#pragma unroll
+	for (int i = 0; i < WG_MAX_TILES; ++i) {
+		const uint32_t tile = tile0 + i;
+		if (i < (int)per && tile < n_tiles) {
+			const uint32_t tr = tile / TC, tc = tile - tr * TC;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) slab[(size_t)(16 * tr + 4 * grp + r) * C + 16 * tc + li] = acc[i][r];
+		}
+	}
+}
+
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const uint32_t n_elems, const uint32_t cols, const uint32_t ldg, const uint32_t n_slabs, const float* __restrict__ slabs, half_t* __restrict__ grad, const int accumulate) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elems) return;
+	float s = 0.0f;
+	for (uint32_t k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * n_elems + i];
+	const uint32_t row = i / cols, col = i - row * cols;
+	half_t* g = grad + (size_t)row * ldg + col;
+	if (accumulate) s += (float)*g;
+	*g = (half_t)s;
+}
+
+// kernel_activation_backward_output (common_device.h:748): dL/d(pre-activation output) from the forward OUTPUT values
+__global__ void __launch_bounds__(256) k_act_bwd_output(const uint32_t n_elems, const uint32_t act, const half_t* __restrict__ dL_dout, const half_t* __restrict__ out, half_t* __restrict__ result) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elems) return;
+	result[i] = activation_bwd(act, dL_dout[i], out[i]);
+}
+
+inline uint32_t wgrad_grid(uint32_t n) {
+	const uint32_t n_chunks = n / WG_CHUNK;
+	return n_chunks < 256 ? (n_chunks ? n_chunks : 1) : 256;
+}
+
+template <int W, int NB>
+void launch_fwd_act(hipStream_t stream, const MlpDesc& d, const FwdArgs& a, uint32_t grid) {
+	if (d.activation == (uint32_t)Activation::ReLU) hipLaunchKernelGGL((k_mlp_fwd<W, NB, (int)Activation::ReLU>), dim3(grid), dim3(256), 0, stream, d, a);
+	else if (d.activation == (uint32_t)Activation::None) hipLaunchKernelGGL((k_mlp_fwd<W, NB, (int)Activation::None>), dim3(grid), dim3(256), 0, stream, d, a);
+	else hipLaunchKernelGGL((k_mlp_fwd<W, NB, -1>), dim3(grid), dim3(256), 0, stream, d, a);
+}
+
+template <int W, int NB>
+void launch_bwd_act(hipStream_t stream, const MlpDesc& d, const BwdArgs& a, uint32_t grid) {
+	if (d.activation == (uint32_t)Activation::ReLU) hipLaunchKernelGGL((k_mlp_bwd<W, NB, (int)Activation::ReLU>), dim3(grid), dim3(256), 0, stream, d, a);
+	else if (d.activation == (uint32_t)Activation::None) hipLaunchKernelGGL((k_mlp_bwd<W, NB, (int)Activation::None>), dim3(grid), dim3(256), 0, stream, d, a);
+	else hipLaunchKernelGGL((k_mlp_bwd<W, NB, -1>), dim3(grid), dim3(256), 0, stream, d, a);
+}
+
+// column blocks (of 16 samples) a wave processes per iteration
+constexpr int nb_for_width(int W) { return W >= 128 ? 2 : 4; }
+
+inline uint32_t mlp_grid(uint32_t n, int nb) {
+	const uint32_t n_iters = n / (16 * nb);
+	const uint32_t wgs = div_round_up(n_iters, 4);
+	const uint32_t cap = 256 * 8;
+	return wgs < cap ? (wgs ? wgs : 1) : cap;
+}
+
+} // namespace
+
+size_t mlp_image_bytes(const MlpDesc& d) { return (size_t)(d.n_frags_fwd + d.n_frags_bwd) * 1024; }
+
+void mlp_prepare_weights(hipStream_t stream, const MlpDesc& d, const void* params, void* image, bool want_bwd) {
+	const uint32_t n_frags = d.n_frags_fwd + (want_bwd ? d.n_frags_bwd : 0);
+	const uint32_t total = n_frags * 512;
+	hipLaunchKernelGGL(k_mlp_prep, dim3(div_round_up(total, 256)), dim3(256), 0, stream, d, (const half_t*)params, (half_t*)image, n_frags);
+}
+
+void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, void* out, void* hidden) {
+	CHECK_THROW(n % BATCH_SIZE_GRANULARITY == 0);
+	CHECK_THROW(d.n_hidden >= 1);
+	if (n == 0) return;
+	FwdArgs a{(const half_t*)x, (half_t*)out, (half_t*)hidden, (const h8*)image, n};
+	switch (d.width) {
+		case 16: return launch_fwd_act<16, nb_for_width(16)>(stream, d, a, mlp_grid(n, nb_for_width(16)));
+		case 32: return launch_fwd_act<32, nb_for_width(32)>(stream, d, a, mlp_grid(n, nb_for_width(32)));
+		case 64: return launch_fwd_act<64, nb_for_width(64)>(stream, d, a, mlp_grid(n, nb_for_width(64)));
+		case 128: return launch_fwd_act<128, nb_for_width(128)>(stream, d, a, mlp_grid(n, nb_for_width(128)));
+		default: throw std::runtime_error{"FullyFusedMLP only supports 16, 32, 64, and 128 neurons."};
+	}
+}
+
+void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* dL_dout, const void* out, const void* hidden, void* dhidden, void* dL_dx) {
+	CHECK_THROW(n % BATCH_SIZE_GRANULARITY == 0);
+	CHECK_THROW(d.n_hidden >= 1);
+	if (n == 0) return;
+	BwdArgs a{(const half_t*)dL_dout, (const half_t*)out, (const half_t*)hidden, (half_t*)dhidden, (half_t*)dL_dx,
+	          (const h8*)((const char*)image + (size_t)d.n_frags_fwd * 1024), n};
+	switch (d.width) {
+		case 16: return launch_bwd_act<16, nb_for_width(16)>(stream, d, a, mlp_grid(n, nb_for_width(16)));
+		case 32: return launch_bwd_act<32, nb_for_width(32)>(stream, d, a, mlp_grid(n, nb_for_width(32)));
+		case 64: return launch_bwd_act<64, nb_for_width(64)>(stream, d, a, mlp_grid(n, nb_for_width(64)));
+		case 128: return launch_bwd_act<128, nb_for_width(128)>(stream, d, a, mlp_grid(n, nb_for_width(128)));
+		default: throw std::runtime_error{"FullyFusedMLP only supports 16, 32, 64, and 128 neurons."};
+	}
+}
+
+void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32_t activation, const void* dL_dout, const void* out, void* result) {
+	if (n_elems == 0) return;
+	hipLaunchKernelGGL(k_act_bwd_output, dim3(div_round_up(n_elems, 256)), dim3(256), 0, stream, n_elems, activation, (const half_t*)dL_dout, (const half_t*)out, (half_t*)result);
+}
+
+size_t wgrad_workspace_floats(uint32_t rows, uint32_t cols, uint32_t n) { return (size_t)wgrad_grid(n) * rows * cols; }
+
+void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uint32_t rows, const void* In, uint32_t ldi, uint32_t cols,
+               void* grad_half, uint32_t ldg, bool accumulate, float* workspace) {
+	CHECK_THROW(n % WG_CHUNK == 0);
+	CHECK_THROW(rows % 16 == 0 && cols % 16 == 0);
+	CHECK_THROW((rows / 16) * (cols / 16) <= 4 * WG_MAX_TILES);
+	const uint32_t grid = wgrad_grid(n);
+	const size_t shmem = (size_t)WG_CHUNK * ((rows + WG_PAD) + (cols + WG_PAD)) * sizeof(half_t);
+	hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, (const half_t*)dO, ldo, rows, (const half_t*)In, ldi, cols, workspace);
+	const uint32_t n_elems = rows * cols;
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_elems, 256)), dim3(256), 0, stream, n_elems, cols, ldg, grid, workspace, (half_t*)grad_half, accumulate ? 1 : 0);
+}
+
+} // namespace tcnn_amd

@@ -1,0 +1,1047 @@
+// model.h -- host-side object model of libtcnn_amd: the MI355X counterpart of the reference's
+// Encoding / Network / NetworkWithInputEncoding / Loss / Optimizer / Trainer classes, reduced to the hot path
+// (SURVEY.md section 8).  Everything here is orchestration: which kernel runs on which buffer in which order.
+//
+// Reference files restated (relative to /root/reference):
+//   include/tiny-cuda-nn/encodings/grid.h:653-1208, oneblob.h:167-307, identity.h:88-190, src/encoding.cu:144-158
+//   src/fully_fused_mlp.cu:636-891, src/network.cu:48-137
+//   include/tiny-cuda-nn/network_with_input_encoding.h:40-192
+//   include/tiny-cuda-nn/losses/{l2,relative_l2}.h, src/loss.cu:85-93
+//   include/tiny-cuda-nn/optimizers/adam.h:122-327, src/optimizer.cu:50-82
+//   include/tiny-cuda-nn/trainer.h:48-363, config.h:46-63, object.h:120-270
+#pragma once
+
+#include "json_lite.h"
+#include "tcnn_common.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <random>
+#include <unordered_map>
+#include <vector>
+
+namespace tcnn_amd {
+
+// ------------------------------------------------------------------------------------------------------------------
+// logging (common_host.h:46-69)
+// ------------------------------------------------------------------------------------------------------------------
+struct LogSink {
+	void (*callback)(int, const char*, void*) = nullptr;
+	void* user = nullptr;
+};
+inline LogSink& log_sink() { static LogSink s; return s; }
+inline void log_message(int severity, const std::string& msg) {
+	LogSink& s = log_sink();
+	if (s.callback) s.callback(severity, msg.c_str(), s.user);
+}
+
+inline std::string to_lower(std::string s) {
+	for (auto& ch : s) ch = (char)std::tolower((unsigned char)ch);
+	return s;
+}
+inline bool equals_case_insensitive(const std::string& a, const std::string& b) { return to_lower(a) == to_lower(b); } // common_host.h:238-246
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stream-ordered caching arena (the role of GPUMemoryArena, gpu_memory.h:426-720): blocks are handed out per stream and
+// returned to that stream's free list when their owner dies, so reuse is ordered by the stream itself.
+// ------------------------------------------------------------------------------------------------------------------
+class Arena {
+public:
+	static Arena& instance() { static Arena a; return a; }
+
+	void* alloc(hipStream_t stream, size_t bytes, size_t* capacity_out) {
+		bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
+		std::lock_guard<std::mutex> lock{m_mutex};
+		int dev = 0;
+		HIP_CHECK_THROW(hipGetDevice(&dev));
+		auto& fl = m_free[key(dev, stream)];
+		auto it = fl.lower_bound(bytes);
+		if (it != fl.end() && it->first <= bytes * 2 + (1u << 20)) {
+			void* p = it->second;
+			*capacity_out = it->first;
+			fl.erase(it);
+			return p;
+		}
+		void* p = nullptr;
+		hipError_t err = hipMalloc(&p, bytes);
+		if (err != hipSuccess) {
+			release_locked();
+			HIP_CHECK_THROW(hipMalloc(&p, bytes));
+		}
+		m_total += bytes;
+		*capacity_out = bytes;
+		return p;
+	}
+
+	void free(hipStream_t stream, int dev, void* p, size_t capacity) {
+		std::lock_guard<std::mutex> lock{m_mutex};
+		m_free[key(dev, stream)].emplace(capacity, p);
+	}
+
+	void release_all() { // free_all_gpu_memory_arenas, gpu_memory.h:751
+		std::lock_guard<std::mutex> lock{m_mutex};
+		release_locked();
+	}
+
+	size_t total_bytes() const { return m_total; }
+
+private:
+	static std::pair<int, hipStream_t> key(int dev, hipStream_t s) { return {dev, s}; }
+	void release_locked() {
+		(void)hipDeviceSynchronize();
+		for (auto& kv : m_free) {
+			for (auto& blk : kv.second) {
+				(void)hipFree(blk.second);
+				m_total -= blk.first;
+			}
+			kv.second.clear();
+		}
+	}
+	std::mutex m_mutex;
+	std::map<std::pair<int, hipStream_t>, std::multimap<size_t, void*>> m_free;
+	size_t m_total = 0;
+};
+
+class ArenaBuf {
+public:
+	ArenaBuf() = default;
+	ArenaBuf(hipStream_t stream, size_t bytes) : m_stream{stream}, m_bytes{bytes} {
+		if (bytes == 0) return;
+		HIP_CHECK_THROW(hipGetDevice(&m_dev));
+		m_ptr = Arena::instance().alloc(stream, bytes, &m_capacity);
+	}
+	~ArenaBuf() { reset(); }
+	ArenaBuf(const ArenaBuf&) = delete;
+	ArenaBuf& operator=(const ArenaBuf&) = delete;
+	ArenaBuf(ArenaBuf&& o) noexcept { *this = std::move(o); }
+	ArenaBuf& operator=(ArenaBuf&& o) noexcept {
+		if (this != &o) {
+			reset();
+			m_ptr = o.m_ptr; m_stream = o.m_stream; m_bytes = o.m_bytes; m_capacity = o.m_capacity; m_dev = o.m_dev;
+			o.m_ptr = nullptr; o.m_bytes = 0;
+		}
+		return *this;
+	}
+	void reset() {
+		if (m_ptr) Arena::instance().free(m_stream, m_dev, m_ptr, m_capacity);
+		m_ptr = nullptr;
+		m_bytes = 0;
+	}
+	void* data() const { return m_ptr; }
+	template <typename T> T* as() const { return (T*)m_ptr; }
+	size_t bytes() const { return m_bytes; }
+	explicit operator bool() const { return m_ptr != nullptr; }
+private:
+	void* m_ptr = nullptr;
+	hipStream_t m_stream = nullptr;
+	size_t m_bytes = 0, m_capacity = 0;
+	int m_dev = 0;
+};
+
+// Persistent device allocation (GPUMemory<T>, gpu_memory.h:60-392)
+class DeviceBuf {
+public:
+	DeviceBuf() = default;
+	explicit DeviceBuf(size_t bytes) { resize(bytes); }
+	~DeviceBuf() { if (m_ptr) (void)hipFree(m_ptr); }
+	DeviceBuf(const DeviceBuf&) = delete;
+	DeviceBuf& operator=(const DeviceBuf&) = delete;
+	void resize(size_t bytes) {
+		if (bytes == m_bytes) return;
+		if (m_ptr) { (void)hipFree(m_ptr); m_ptr = nullptr; }
+		m_bytes = bytes;
+		if (bytes) HIP_CHECK_THROW(hipMalloc(&m_ptr, bytes));
+	}
+	void memset(int v) { if (m_bytes) HIP_CHECK_THROW(hipMemset(m_ptr, v, m_bytes)); }
+	void* data() const { return m_ptr; }
+	template <typename T> T* as() const { return (T*)m_ptr; }
+	size_t bytes() const { return m_bytes; }
+private:
+	void* m_ptr = nullptr;
+	size_t m_bytes = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// pcg32 (dependencies/pcg32/pcg32.h:40-166, the published PCG-XSH-RR 64/32 generator)
+// ------------------------------------------------------------------------------------------------------------------
+struct Pcg32 {
+	uint64_t st[2] = {0x853c49e6748fea9bULL, 0xda3e39cb94b95bdbULL};
+	static constexpr uint64_t MULT = 0x5851f42d4c957f2dULL;
+	Pcg32() = default;
+	explicit Pcg32(uint64_t initstate, uint64_t initseq = 1) {
+		st[0] = 0;
+		st[1] = (initseq << 1u) | 1u;
+		next_uint();
+		st[0] += initstate;
+		next_uint();
+	}
+	uint32_t next_uint() {
+		const uint64_t old = st[0];
+		st[0] = old * MULT + st[1];
+		const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+		const uint32_t rot = (uint32_t)(old >> 59u);
+		return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+	}
+	float next_float() {
+		const uint32_t u = (next_uint() >> 9) | 0x3f800000u;
+		float f;
+		memcpy(&f, &u, 4);
+		return f - 1.0f;
+	}
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Encodings
+// ------------------------------------------------------------------------------------------------------------------
+struct EncodingContext {
+	ArenaBuf dy_dx; // grid only: float [n][L*F][D]
+};
+
+class Encoding {
+public:
+	virtual ~Encoding() {}
+	virtual uint32_t input_width() const = 0;
+	virtual uint32_t output_width() const = 0; // unpadded
+	uint32_t padded_output_width() const { return output_width() + m_n_to_pad; }
+	virtual uint32_t required_output_alignment() const { return 1; }
+	void set_alignment(uint32_t alignment) { // encoding.h:70-72
+		const uint32_t a = std::lcm(alignment, required_output_alignment());
+		m_n_to_pad = next_multiple(output_width(), a) - output_width();
+	}
+	virtual size_t n_params() const { return 0; }
+	virtual void initialize_params(Pcg32& rng, float* params_full_precision, float scale) {}
+	// out: [n][padded_output_width] T (T = float if fp32 else half)
+	virtual EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients) = 0;
+	// dL_dy [n][padded] T; grads: T[n_params] or nullptr (Ignore)
+	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) = 0;
+	virtual Json hyperparams() const = 0;
+	bool fp32() const { return m_fp32; }
+protected:
+	explicit Encoding(bool fp32) : m_fp32{fp32} {}
+	bool m_fp32;
+	uint32_t m_n_to_pad = 0;
+};
+
+inline GridType string_to_grid_type(const std::string& s) {
+	if (equals_case_insensitive(s, "Hash")) return GridType::Hash;
+	if (equals_case_insensitive(s, "Dense")) return GridType::Dense;
+	if (equals_case_insensitive(s, "Tiled") || equals_case_insensitive(s, "Tile")) return GridType::Tiled;
+	throw std::runtime_error{"Invalid grid type: " + s};
+}
+inline HashType string_to_hash_type(const std::string& s) {
+	if (equals_case_insensitive(s, "Prime")) return HashType::Prime;
+	if (equals_case_insensitive(s, "CoherentPrime")) return HashType::CoherentPrime;
+	if (equals_case_insensitive(s, "ReversedPrime")) return HashType::ReversedPrime;
+	if (equals_case_insensitive(s, "Rng")) return HashType::Rng;
+	throw std::runtime_error{"Invalid hash type: " + s};
+}
+inline InterpolationType string_to_interpolation_type(const std::string& s) {
+	if (equals_case_insensitive(s, "Nearest")) return InterpolationType::Nearest;
+	if (equals_case_insensitive(s, "Linear")) return InterpolationType::Linear;
+	if (equals_case_insensitive(s, "Smoothstep")) return InterpolationType::Smoothstep;
+	throw std::runtime_error{"Invalid interpolation type: " + s};
+}
+
+class GridEncoding : public Encoding {
+public:
+	GridEncoding(uint32_t n_dims_to_encode, const Json& enc, bool fp32) : Encoding{fp32} { // grid.h:1143-1208 + :668-730
+		const uint32_t F = enc.value("n_features_per_level", 2u);
+		if (F != 1 && F != 2 && F != 4 && F != 8) throw std::runtime_error{"GridEncoding: n_features_per_level must be 1, 2, 4, or 8."};
+		const uint32_t log2_hashmap_size = enc.value("log2_hashmap_size", 19u);
+		const std::string encoding_type = enc.value("otype", "Grid");
+		const std::string default_type = equals_case_insensitive(encoding_type, "TiledGrid") ? "Tiled" : (equals_case_insensitive(encoding_type, "DenseGrid") ? "Dense" : "Hash");
+		uint32_t n_features;
+		if (enc.contains("n_features") || enc.contains("n_grid_features")) {
+			n_features = enc.contains("n_features") ? enc.value("n_features", 0u) : enc.value("n_grid_features", 0u);
+			if (enc.contains("n_levels")) throw std::runtime_error{"GridEncoding: may not specify n_features and n_levels simultaneously (one determines the other)"};
+		} else {
+			n_features = F * enc.value("n_levels", 16u);
+		}
+		const uint32_t n_levels = n_features / F;
+		const GridType grid_type = string_to_grid_type(enc.value("type", default_type));
+		const uint32_t base_resolution = enc.value("base_resolution", 16u);
+		const float per_level_scale = enc.value("per_level_scale", grid_type == GridType::Dense ? std::exp(std::log(256.0f / (float)base_resolution) / (n_levels - 1)) : 2.0f);
+		const HashType hash_type = string_to_hash_type(enc.value("hash", "CoherentPrime"));
+		m_stochastic_interpolation = enc.value("stochastic_interpolation", false);
+		if (m_stochastic_interpolation) throw std::runtime_error{"GridEncoding: stochastic_interpolation is not supported by this build"};
+		if (n_dims_to_encode < 2 || n_dims_to_encode > 4) throw std::runtime_error{"GridEncoding: number of input dims must be 2 or 3."};
+		if (n_levels > MAX_N_LEVELS) throw std::runtime_error{"GridEncoding: m_n_levels must be at most MAX_N_LEVELS=128"};
+		if (n_features % F != 0) throw std::runtime_error{"GridEncoding: n_features must be a multiple of N_FEATURES_PER_LEVEL"};
+
+		m_n_features = n_features;
+		m_log2_hashmap_size = log2_hashmap_size;
+		m_base_resolution = base_resolution;
+		m_per_level_scale = per_level_scale;
+
+		memset(&m_meta, 0, sizeof(m_meta));
+		m_meta.n_pos_dims = n_dims_to_encode;
+		m_meta.n_features_per_level = F;
+		m_meta.n_levels = n_levels;
+		m_meta.grid_type = (uint32_t)grid_type;
+		m_meta.hash_type = (uint32_t)hash_type;
+		m_meta.interpolation = (uint32_t)string_to_interpolation_type(enc.value("interpolation", "Linear"));
+		static const uint32_t prime[7] = {1958374283u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+		static const uint32_t coherent[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+		static const uint32_t reversed[7] = {2165219737u, 1434869437u, 2097192037u, 3674653429u, 805459861u, 2654435761u, 1958374283u};
+		const uint32_t* primes = hash_type == HashType::Prime ? prime : (hash_type == HashType::ReversedPrime ? reversed : coherent);
+		for (uint32_t d = 0; d < 4; ++d) m_meta.primes[d] = primes[d]; // common_device.h:645-661
+
+		const float log2_scale = std::log2(per_level_scale); // float overload (grid.h:694)
+		uint32_t offset = 0;
+		for (uint32_t i = 0; i < n_levels; ++i) {
+			const float scale = exp2f(i * log2_scale) * base_resolution - 1.0f; // common_device.h:709-714
+			const uint32_t resolution = (uint32_t)ceilf(scale) + 1;             // :716-718
+			const uint32_t max_params = std::numeric_limits<uint32_t>::max() / 2;
+			uint32_t params_in_level = std::pow((float)resolution, n_dims_to_encode) > (float)max_params ? max_params : powi(resolution, n_dims_to_encode);
+			params_in_level = next_multiple(params_in_level, 8u);
+			if (grid_type == GridType::Tiled) params_in_level = std::min(params_in_level, powi(base_resolution, n_dims_to_encode));
+			else if (grid_type == GridType::Hash) params_in_level = std::min(params_in_level, 1u << log2_hashmap_size);
+
+			GridLevel& lv = m_meta.levels[i];
+			lv.offset = offset;
+			lv.size = params_in_level;
+			lv.scale = scale;
+			// grid_index's stride loop (common_device.h:692-704), evaluated once here, uint32 wrap-around included
+			uint32_t stride = 1;
+			for (uint32_t d = 0; d < 4; ++d) lv.stride[d] = 0;
+			for (uint32_t d = 0; d < n_dims_to_encode && stride <= params_in_level; ++d) {
+				lv.stride[d] = stride;
+				stride *= resolution;
+			}
+			lv.hashed = (grid_type == GridType::Hash && params_in_level < stride) ? 1u : 0u;
+			lv.size_mask = (params_in_level & (params_in_level - 1)) == 0 ? params_in_level - 1 : 0;
+			m_resolutions.push_back(resolution);
+			offset += params_in_level;
+		}
+		m_n_entries = offset;
+		m_n_params = (size_t)offset * F;
+	}
+
+	// device copy of the level table, uploaded on first use (construction itself never touches the GPU)
+	const GridMeta* dev_meta() {
+		if (!m_dev_meta.data()) {
+			m_dev_meta.resize(sizeof(GridMeta));
+			HIP_CHECK_THROW(hipMemcpy(m_dev_meta.data(), &m_meta, sizeof(GridMeta), hipMemcpyHostToDevice));
+		}
+		return (const GridMeta*)m_dev_meta.data();
+	}
+
+	static uint32_t powi(uint32_t base, uint32_t exponent) {
+		uint32_t result = 1;
+		for (uint32_t i = 0; i < exponent; ++i) result *= base;
+		return result;
+	}
+
+	uint32_t input_width() const override { return m_meta.n_pos_dims; }
+	uint32_t output_width() const override { return m_n_features; }
+	uint32_t required_output_alignment() const override { return m_meta.n_features_per_level; }
+	size_t n_params() const override { return m_n_params; }
+	const GridMeta& meta() const { return m_meta; }
+	const std::vector<uint32_t>& resolutions() const { return m_resolutions; }
+
+	void initialize_params(Pcg32& rng, float* params_full_precision, float scale) override { // grid.h:1059-1062
+		generate_random_uniform(nullptr, rng.st, n_params(), params_full_precision, -1e-4f * scale, 1e-4f * scale);
+	}
+
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients) override {
+		EncodingContext ctx;
+		if ((!out && !prepare_input_gradients) || padded_output_width() == 0 || n == 0) return ctx;
+		if (prepare_input_gradients) ctx.dy_dx = ArenaBuf{stream, (size_t)n * m_n_features * m_meta.n_pos_dims * sizeof(float)};
+		grid_forward(stream, m_meta, dev_meta(), m_fp32, n, x, params, out, padded_output_width(), ctx.dy_dx.as<float>());
+		return ctx;
+	}
+
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) override {
+		if ((!dL_dx && mode == GradientMode::Ignore) || n == 0) return;
+		const size_t elem = m_fp32 ? 4 : 2;
+		if (mode != GradientMode::Ignore) {
+			CHECK_THROW(grads != nullptr);
+			const bool scratch32 = !m_fp32 && m_meta.n_features_per_level == 1; // grid.h:660: F == 1 accumulates in fp32
+			if (scratch32) {
+				ArenaBuf tmp{stream, n_params() * sizeof(float)};
+				if (mode == GradientMode::Overwrite) HIP_CHECK_THROW(hipMemsetAsync(tmp.data(), 0, n_params() * sizeof(float), stream));
+				else cast_half_to_float(stream, n_params(), grads, tmp.as<float>());
+				grid_backward(stream, m_meta, dev_meta(), true, n, x, dL_dy, false, padded_output_width(), tmp.data());
+				cast_float_to_half(stream, n_params(), tmp.as<float>(), grads);
+			} else {
+				if (mode == GradientMode::Overwrite) HIP_CHECK_THROW(hipMemsetAsync(grads, 0, n_params() * elem, stream)); // grid.h:858
+				grid_backward(stream, m_meta, dev_meta(), m_fp32, n, x, dL_dy, m_fp32, padded_output_width(), grads);
+			}
+		}
+		if (dL_dx) {
+			CHECK_THROW(ctx.dy_dx);
+			grid_backward_input(stream, m_meta, m_fp32, n, dL_dy, padded_output_width(), ctx.dy_dx.as<float>(), *dL_dx);
+		}
+	}
+
+	Json hyperparams() const override { // grid.h:1098-1115
+		static const char* types[] = {"Hash", "Dense", "Tiled"};
+		static const char* interps[] = {"Nearest", "Linear", "Smoothstep"};
+		static const char* hashes[] = {"Prime", "CoherentPrime", "ReversedPrime", "Rng"};
+		Json j = Json::object();
+		j["otype"] = "Grid";
+		j["type"] = types[m_meta.grid_type];
+		j["n_levels"] = m_meta.n_levels;
+		j["n_features_per_level"] = m_meta.n_features_per_level;
+		j["base_resolution"] = m_base_resolution;
+		j["per_level_scale"] = m_per_level_scale;
+		j["interpolation"] = interps[m_meta.interpolation];
+		j["hash"] = hashes[m_meta.hash_type];
+		if (m_meta.grid_type == (uint32_t)GridType::Hash) j["log2_hashmap_size"] = m_log2_hashmap_size;
+		return j;
+	}
+
+private:
+	GridMeta m_meta;
+	DeviceBuf m_dev_meta;
+	std::vector<uint32_t> m_resolutions;
+	uint32_t m_n_features, m_log2_hashmap_size, m_base_resolution, m_n_entries;
+	float m_per_level_scale;
+	bool m_stochastic_interpolation;
+	size_t m_n_params;
+};
+
+class OneBlobEncoding : public Encoding {
+public:
+	OneBlobEncoding(uint32_t n_bins, uint32_t n_dims_to_encode, bool fp32) : Encoding{fp32}, m_n_bins{n_bins}, m_n_dims{n_dims_to_encode} {
+		if ((n_bins & (n_bins - 1)) != 0 || n_bins == 0) throw std::runtime_error{"Number of bins must be a power of 2"}; // oneblob.h:173-177
+	}
+	uint32_t input_width() const override { return m_n_dims; }
+	uint32_t output_width() const override { return m_n_dims * m_n_bins; }
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients) override {
+		if (out && padded_output_width() > 0) oneblob_forward(stream, m_fp32, n, m_n_dims, m_n_bins, x, out, padded_output_width());
+		return {};
+	}
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) override {
+		if (!dL_dx) return;
+		oneblob_backward_input(stream, m_fp32, n, m_n_dims, m_n_bins, x, dL_dy, padded_output_width(), *dL_dx);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "OneBlob";
+		j["n_bins"] = m_n_bins;
+		return j;
+	}
+private:
+	uint32_t m_n_bins, m_n_dims;
+};
+
+class IdentityEncoding : public Encoding {
+public:
+	IdentityEncoding(uint32_t n_dims_to_encode, float scale, float offset, bool fp32) : Encoding{fp32}, m_n_dims{n_dims_to_encode}, m_scale{scale}, m_offset{offset} {}
+	uint32_t input_width() const override { return m_n_dims; }
+	uint32_t output_width() const override { return m_n_dims; }
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients) override {
+		if (out && padded_output_width() > 0) identity_forward(stream, m_fp32, n, m_n_dims, m_scale, m_offset, x, out, padded_output_width());
+		return {};
+	}
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) override {
+		if (!dL_dx) return;
+		identity_backward_input(stream, m_fp32, n, m_n_dims, m_scale, dL_dy, padded_output_width(), *dL_dx);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "Identity";
+		j["scale"] = m_scale;
+		j["offset"] = m_offset;
+		return j;
+	}
+private:
+	uint32_t m_n_dims;
+	float m_scale, m_offset;
+};
+
+// src/encoding.cu:144-158 (case-insensitive registry :48-54; default otype OneBlob)
+inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, const Json& enc, uint32_t alignment, bool fp32) {
+	const std::string name = to_lower(enc.value("otype", "OneBlob"));
+	std::unique_ptr<Encoding> result;
+	if (name == "grid" || name == "hashgrid" || name == "tiledgrid" || name == "densegrid") {
+		result.reset(new GridEncoding{n_dims_to_encode, enc, fp32});
+	} else if (name == "oneblob") {
+		result.reset(new OneBlobEncoding{enc.value("n_bins", 16u), n_dims_to_encode, fp32});
+	} else if (name == "identity") {
+		result.reset(new IdentityEncoding{n_dims_to_encode, enc.value("scale", 1.0f), enc.value("offset", 0.0f), fp32});
+	} else {
+		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity)"};
+	}
+	if (alignment > 0) result->set_alignment(alignment);
+	return result;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Network: FullyFusedMLP (and CutlassMLP configs that the fused kernels cover; identical math)
+// ------------------------------------------------------------------------------------------------------------------
+inline Activation string_to_activation(const std::string& s) {
+	static const std::pair<const char*, Activation> table[] = {
+		{"None", Activation::None}, {"ReLU", Activation::ReLU}, {"LeakyReLU", Activation::LeakyReLU}, {"Exponential", Activation::Exponential},
+		{"Sine", Activation::Sine}, {"Sigmoid", Activation::Sigmoid}, {"Squareplus", Activation::Squareplus}, {"Softplus", Activation::Softplus},
+		{"Tanh", Activation::Tanh}};
+	for (const auto& kv : table) if (equals_case_insensitive(s, kv.first)) return kv.second;
+	throw std::runtime_error{"Invalid activation name: " + s};
+}
+inline const char* to_string(Activation a) {
+	static const char* names[] = {"None", "ReLU", "LeakyReLU", "Exponential", "Sine", "Sigmoid", "Squareplus", "Softplus", "Tanh"};
+	return names[(uint32_t)a];
+}
+
+struct NetworkContext {
+	ArenaBuf hidden; // half [n_hidden][n][width]
+};
+
+class Network {
+public:
+	static constexpr uint32_t REQUIRED_ALIGNMENT = 16; // fully_fused_mlp.h:108-110, cutlass_mlp.h:115-121
+
+	explicit Network(const Json& net) { // network.cu:48-137
+		const std::string otype = net.value("otype", "MLP");
+		m_fully_fused = equals_case_insensitive(otype, "MegakernelMLP") || equals_case_insensitive(otype, "FullyFusedMLP");
+		const bool cutlass = equals_case_insensitive(otype, "MLP") || equals_case_insensitive(otype, "CutlassMLP");
+		if (!m_fully_fused && !cutlass) throw std::runtime_error{"Invalid network type: " + otype};
+		if (!net.contains("n_input_dims") || !net.contains("n_output_dims")) throw std::runtime_error{"network config needs n_input_dims and n_output_dims"};
+		m_input_width = net.value("n_input_dims", 0u);
+		m_output_width = net.value("n_output_dims", 0u);
+		m_width = net.value("n_neurons", 128u);
+		m_n_hidden = net.value("n_hidden_layers", 5u);
+		m_activation = string_to_activation(net.value("activation", "ReLU"));
+		m_output_activation = string_to_activation(net.value("output_activation", "None"));
+		if (m_width != 16 && m_width != 32 && m_width != 64 && m_width != 128) {
+			throw std::runtime_error{"FullyFusedMLP only supports 16, 32, 64, and 128 neurons, but got " + std::to_string(m_width) + ". (CutlassMLP widths outside that set are not provided by this build.)"};
+		}
+		if (m_n_hidden <= 0) throw std::runtime_error{"FullyFusedMLP requires at least 1 hidden layer (3 layers in total)."};
+		if (m_n_hidden + 1 > MAX_MLP_LAYERS) throw std::runtime_error{"MLP: too many layers for this build"};
+		if (m_activation == Activation::Sine) throw std::runtime_error{"FullyFusedMLP: Sine activation is not supported in the fused kernels"};
+		if (m_input_width % 16 != 0) throw std::runtime_error{"MLP: input width must be a multiple of 16"};
+		m_padded_output_width = next_multiple(m_output_width, REQUIRED_ALIGNMENT);
+
+		// matrices: fully_fused_mlp.cu:659-671
+		memset(&m_desc, 0, sizeof(m_desc));
+		m_desc.in_width = m_input_width;
+		m_desc.width = m_width;
+		m_desc.out_width = m_padded_output_width;
+		m_desc.n_hidden = m_n_hidden;
+		m_desc.n_layers = m_n_hidden + 1;
+		m_desc.activation = (uint32_t)m_activation;
+		m_desc.output_activation = (uint32_t)m_output_activation;
+		uint32_t w_off = 0, f_off = 0, b_off = 0;
+		for (uint32_t l = 0; l < m_desc.n_layers; ++l) {
+			MlpLayer& L = m_desc.layers[l];
+			L.rows = l == m_desc.n_layers - 1 ? m_padded_output_width : m_width;
+			L.cols = l == 0 ? m_input_width : m_width;
+			L.w_off = w_off;
+			L.ks_fwd = div_round_up(L.cols, 32);
+			L.ks_bwd = div_round_up(L.rows, 32);
+			L.natural_k = l == 0 ? 1u : 0u;
+			L.fwd_off = f_off;
+			L.bwd_off = b_off;
+			f_off += (L.rows / 16) * L.ks_fwd;
+			b_off += (L.cols / 16) * L.ks_bwd;
+			w_off += L.rows * L.cols;
+		}
+		m_desc.n_frags_fwd = f_off;
+		m_desc.n_frags_bwd = b_off;
+		m_n_params = w_off;
+	}
+
+	uint32_t input_width() const { return m_input_width; }
+	uint32_t output_width() const { return m_output_width; }
+	uint32_t padded_output_width() const { return m_padded_output_width; }
+	uint32_t width() const { return m_width; }
+	uint32_t n_hidden() const { return m_n_hidden; }
+	size_t n_params() const { return m_n_params; }
+	const MlpDesc& desc() const { return m_desc; }
+
+	std::vector<std::pair<uint32_t, uint32_t>> layer_sizes() const {
+		std::vector<std::pair<uint32_t, uint32_t>> r;
+		for (uint32_t l = 0; l < m_desc.n_layers; ++l) r.emplace_back(m_desc.layers[l].rows, m_desc.layers[l].cols);
+		return r;
+	}
+
+	void initialize_params(Pcg32& rng, float* params_full_precision, float scale) { // fully_fused_mlp.cu:866-891, gpu_matrix.h:284-299
+		std::vector<float> host(m_n_params);
+		for (uint32_t l = 0; l < m_desc.n_layers; ++l) {
+			const MlpLayer& L = m_desc.layers[l];
+			const float s = scale * std::sqrt(6.0f / (float)(L.cols + L.rows));
+			float* w = host.data() + L.w_off;
+			for (size_t i = 0; i < (size_t)L.rows * L.cols; ++i) w[i] = rng.next_float() * 2.0f * s - s;
+		}
+		HIP_CHECK_THROW(hipMemcpy(params_full_precision, host.data(), m_n_params * sizeof(float), hipMemcpyHostToDevice));
+	}
+
+	// images: [fwd][bwd] fragment images of `params`
+	ArenaBuf prepare(hipStream_t stream, const void* params, bool want_bwd) const {
+		ArenaBuf image{stream, mlp_image_bytes(m_desc)};
+		mlp_prepare_weights(stream, m_desc, params, image.data(), want_bwd);
+		return image;
+	}
+
+	void inference(hipStream_t stream, uint32_t n, const void* input, void* output, const void* params) const {
+		ArenaBuf image = prepare(stream, params, false);
+		mlp_forward(stream, m_desc, image.data(), n, input, output, nullptr);
+	}
+
+	NetworkContext forward(hipStream_t stream, uint32_t n, const void* input, void* output, const void* params) const {
+		NetworkContext ctx;
+		ctx.hidden = ArenaBuf{stream, (size_t)m_n_hidden * n * m_width * 2};
+		ArenaBuf image = prepare(stream, params, false);
+		mlp_forward(stream, m_desc, image.data(), n, input, output, ctx.hidden.data());
+		return ctx;
+	}
+
+	// dL_dinput: optional half [n][in_width]; gradients: half[n_params] or nullptr
+	void backward(hipStream_t stream, const NetworkContext& ctx, uint32_t n, const void* input, const void* output, const void* dL_doutput,
+	              void* dL_dinput, const void* params, void* gradients, GradientMode mode) const {
+		ArenaBuf image = prepare(stream, params, true);
+		ArenaBuf dhidden{stream, (size_t)m_n_hidden * n * m_width * 2};
+		// output-activation transfer, computed once up front like the reference (fully_fused_mlp.cu:757-762)
+		const void* dY = dL_doutput;
+		ArenaBuf dY_tmp;
+		MlpDesc desc = m_desc;
+		if (m_output_activation != Activation::None) {
+			dY_tmp = ArenaBuf{stream, (size_t)n * m_padded_output_width * 2};
+			mlp_activation_backward_output(stream, n * m_padded_output_width, (uint32_t)m_output_activation, dL_doutput, output, dY_tmp.data());
+			dY = dY_tmp.data();
+			desc.output_activation = (uint32_t)Activation::None;
+		}
+		mlp_backward(stream, desc, image.data(), n, dY, output, ctx.hidden.data(), dhidden.data(), dL_dinput);
+		if (mode == GradientMode::Ignore) return;
+		CHECK_THROW(gradients != nullptr);
+
+		size_t ws_floats = 0;
+		for (uint32_t l = 0; l < m_desc.n_layers; ++l) ws_floats = std::max(ws_floats, wgrad_workspace_floats(m_desc.layers[l].rows, std::min(m_desc.layers[l].cols, 128u), n));
+		ArenaBuf ws{stream, ws_floats * sizeof(float)};
+		const bool accumulate = mode == GradientMode::Accumulate;
+		const size_t hstride = (size_t)n * m_width; // elements per hidden layer
+		for (uint32_t l = 0; l < m_desc.n_layers; ++l) {
+			const MlpLayer& L = m_desc.layers[l];
+			const _Float16* dO = l == m_desc.n_layers - 1 ? (const _Float16*)dY : dhidden.as<_Float16>() + hstride * l;
+			const uint32_t ldo = l == m_desc.n_layers - 1 ? m_padded_output_width : m_width;
+			const _Float16* In = l == 0 ? (const _Float16*)input : ctx.hidden.as<_Float16>() + hstride * (l - 1);
+			const uint32_t ldi = l == 0 ? m_input_width : m_width;
+			_Float16* g = (_Float16*)gradients + L.w_off;
+			for (uint32_t r0 = 0; r0 < L.rows; r0 += 128) {
+				const uint32_t rr = std::min(128u, L.rows - r0);
+				for (uint32_t c0 = 0; c0 < L.cols; c0 += 128) { // column panels of at most 128
+					const uint32_t cc = std::min(128u, L.cols - c0);
+					mlp_wgrad(stream, n, dO + r0, ldo, rr, In + c0, ldi, cc, g + (size_t)r0 * L.cols + c0, L.cols, accumulate, ws.as<float>());
+				}
+			}
+		}
+	}
+
+	Json hyperparams() const { // fully_fused_mlp.h:137-145
+		Json j = Json::object();
+		j["otype"] = m_fully_fused ? "FullyFusedMLP" : "CutlassMLP";
+		j["activation"] = to_string(m_activation);
+		j["output_activation"] = to_string(m_output_activation);
+		j["n_neurons"] = m_width;
+		j["n_hidden_layers"] = m_n_hidden;
+		return j;
+	}
+
+private:
+	bool m_fully_fused;
+	uint32_t m_input_width, m_output_width, m_padded_output_width, m_width, m_n_hidden;
+	Activation m_activation, m_output_activation;
+	MlpDesc m_desc;
+	size_t m_n_params;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Model = DifferentiableObject<float, T, T> (object.h:120-270)
+// ------------------------------------------------------------------------------------------------------------------
+struct ModelContext {
+	virtual ~ModelContext() {}
+};
+
+class Model {
+public:
+	virtual ~Model() {}
+	virtual uint32_t input_width() const = 0;
+	virtual uint32_t output_width() const = 0;
+	virtual uint32_t padded_output_width() const = 0;
+	virtual size_t n_params() const = 0;
+	virtual Precision precision() const = 0;
+	virtual std::vector<std::pair<uint32_t, uint32_t>> layer_sizes() const = 0;
+	virtual void initialize_params(Pcg32& rng, float* params_full_precision, float scale) = 0;
+	virtual void inference(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params) = 0;
+	virtual std::unique_ptr<ModelContext> forward(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params, bool prepare_input_gradients) = 0;
+	virtual void backward(hipStream_t stream, const ModelContext& ctx, uint32_t n, MatView input, const void* output, const void* dL_doutput,
+	                      MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) = 0;
+	virtual Json hyperparams() const = 0;
+	std::string name() const { return hyperparams().value("otype", "<Unknown>"); } // object.h:51-53
+
+	static void check_batch(uint32_t n) { // object.h:130,150,197,246
+		if (n % BATCH_SIZE_GRANULARITY != 0) throw std::runtime_error{"batch size " + std::to_string(n) + " is not a multiple of BATCH_SIZE_GRANULARITY = 256"};
+	}
+};
+
+class NetworkWithInputEncoding : public Model {
+public:
+	NetworkWithInputEncoding(uint32_t n_dims_to_encode, uint32_t n_output_dims, const Json& encoding, const Json& network) {
+		// network_with_input_encoding.h:45-56: encoding aligned to the network's minimum alignment (16), network sized from it
+		m_encoding = create_encoding(n_dims_to_encode, encoding, Network::REQUIRED_ALIGNMENT, false);
+		Json local = network.is_object() ? network : Json::object();
+		local["n_input_dims"] = m_encoding->padded_output_width();
+		local["n_output_dims"] = n_output_dims;
+		m_network.reset(new Network{local});
+	}
+
+	uint32_t input_width() const override { return m_encoding->input_width(); }
+	uint32_t output_width() const override { return m_network->output_width(); }
+	uint32_t padded_output_width() const override { return m_network->padded_output_width(); }
+	size_t n_params() const override { return m_network->n_params() + m_encoding->n_params(); }
+	Precision precision() const override { return Precision::Fp16; }
+	std::vector<std::pair<uint32_t, uint32_t>> layer_sizes() const override { return m_network->layer_sizes(); }
+	Encoding& encoding() { return *m_encoding; }
+	Network& network() { return *m_network; }
+
+	void initialize_params(Pcg32& rng, float* params_full_precision, float scale) override { // :124-130, network first
+		m_network->initialize_params(rng, params_full_precision, scale);
+		m_encoding->initialize_params(rng, params_full_precision + m_network->n_params(), scale);
+	}
+
+	void inference(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params) override {
+		check_batch(n);
+		if (n == 0) return;
+		const _Float16* p = (const _Float16*)params;
+		ArenaBuf network_input{stream, (size_t)n * m_encoding->padded_output_width() * 2};
+		m_encoding->forward(stream, n, input, p + m_network->n_params(), network_input.data(), false);
+		m_network->inference(stream, n, network_input.data(), output, p);
+	}
+
+	struct Ctx : public ModelContext {
+		ArenaBuf network_input;
+		EncodingContext encoding_ctx;
+		NetworkContext network_ctx;
+	};
+
+	std::unique_ptr<ModelContext> forward(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params, bool prepare_input_gradients) override {
+		check_batch(n);
+		auto ctx = std::make_unique<Ctx>();
+		if (n == 0) return ctx;
+		const _Float16* p = (const _Float16*)params;
+		ctx->network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
+		ctx->encoding_ctx = m_encoding->forward(stream, n, input, p + m_network->n_params(), ctx->network_input.data(), prepare_input_gradients);
+		ctx->network_ctx = m_network->forward(stream, n, ctx->network_input.data(), output, p);
+		return ctx;
+	}
+
+	void backward(hipStream_t stream, const ModelContext& mctx, uint32_t n, MatView input, const void* output, const void* dL_doutput,
+	              MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) override {
+		check_batch(n);
+		if (n == 0) return;
+		const Ctx& ctx = dynamic_cast<const Ctx&>(mctx);
+		const _Float16* p = (const _Float16*)params;
+		_Float16* g = (_Float16*)gradients;
+		ArenaBuf dL_dnetwork_input;
+		if (m_encoding->n_params() > 0 || dL_dinput) { // :93-96
+			dL_dnetwork_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
+		}
+		m_network->backward(stream, ctx.network_ctx, n, ctx.network_input.data(), output, dL_doutput, dL_dnetwork_input.data(), p, g, mode);
+		if (dL_dnetwork_input) {
+			m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + m_network->n_params(),
+			                     g ? g + m_network->n_params() : nullptr, mode);
+		}
+	}
+
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "NetworkWithInputEncoding";
+		j["encoding"] = m_encoding->hyperparams();
+		j["network"] = m_network->hyperparams();
+		return j;
+	}
+
+private:
+	std::unique_ptr<Encoding> m_encoding;
+	std::unique_ptr<Network> m_network;
+};
+
+// standalone encoding as a Module (cpp_api.cu:156-165: alignment 0 -> no padding)
+class EncodingModel : public Model {
+public:
+	EncodingModel(uint32_t n_dims_to_encode, const Json& encoding, Precision precision) : m_precision{precision} {
+		m_encoding = create_encoding(n_dims_to_encode, encoding, 0, precision == Precision::Fp32);
+	}
+	uint32_t input_width() const override { return m_encoding->input_width(); }
+	uint32_t output_width() const override { return m_encoding->padded_output_width(); }
+	uint32_t padded_output_width() const override { return m_encoding->padded_output_width(); }
+	size_t n_params() const override { return m_encoding->n_params(); }
+	Precision precision() const override { return m_precision; }
+	std::vector<std::pair<uint32_t, uint32_t>> layer_sizes() const override { return {}; }
+	void initialize_params(Pcg32& rng, float* params_full_precision, float scale) override { m_encoding->initialize_params(rng, params_full_precision, scale); }
+
+	struct Ctx : public ModelContext {
+		EncodingContext encoding_ctx;
+	};
+	void inference(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params) override {
+		check_batch(n);
+		m_encoding->forward(stream, n, input, params, output, false);
+	}
+	std::unique_ptr<ModelContext> forward(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params, bool prepare_input_gradients) override {
+		check_batch(n);
+		auto ctx = std::make_unique<Ctx>();
+		ctx->encoding_ctx = m_encoding->forward(stream, n, input, params, output, prepare_input_gradients);
+		return ctx;
+	}
+	void backward(hipStream_t stream, const ModelContext& mctx, uint32_t n, MatView input, const void* output, const void* dL_doutput,
+	              MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) override {
+		check_batch(n);
+		const Ctx& ctx = dynamic_cast<const Ctx&>(mctx);
+		m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_doutput, dL_dinput, params, gradients, mode);
+	}
+	Json hyperparams() const override { return m_encoding->hyperparams(); }
+private:
+	Precision m_precision;
+	std::unique_ptr<Encoding> m_encoding;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Loss (src/loss.cu:85-93) and Adam (optimizers/adam.h:122-327, src/optimizer.cu:50-82)
+// ------------------------------------------------------------------------------------------------------------------
+inline LossType create_loss(const Json& loss) {
+	const std::string otype = loss.value("otype", "RelativeL2");
+	if (equals_case_insensitive(otype, "L2")) return LossType::L2;
+	if (equals_case_insensitive(otype, "RelativeL2")) return LossType::RelativeL2;
+	throw std::runtime_error{"Invalid loss type: " + otype + " (this build provides L2 and RelativeL2)"};
+}
+inline const char* to_string(LossType t) { return t == LossType::L2 ? "L2" : "RelativeL2"; }
+
+class AdamOptimizer {
+public:
+	explicit AdamOptimizer(const Json& params) {
+		const std::string otype = params.value("otype", "Adam");
+		if (!equals_case_insensitive(otype, "Adam")) throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam)"};
+		update_hyperparams(params);
+	}
+
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) { // adam.h:128-148
+		m_n_weights = n_weights;
+		if (n_weights * sizeof(float) > m_first_moments.bytes()) {
+			m_first_moments.resize(n_weights * sizeof(float));
+			m_second_moments.resize(n_weights * sizeof(float));
+			m_param_steps.resize(n_weights * sizeof(uint32_t));
+		}
+		m_first_moments.memset(0);
+		m_second_moments.memset(0);
+		m_param_steps.memset(0);
+		m_n_matrix = 0;
+		for (const auto& ls : layer_sizes) m_n_matrix += (size_t)ls.first * ls.second;
+	}
+
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) { // adam.h:150-188
+		++m_current_step;
+		adam_step(stream, m_h, m_n_weights, m_n_matrix, loss_scale, m_current_step, weights_full_precision, weights, gradients,
+		          m_first_moments.as<float>(), m_second_moments.as<float>(), m_param_steps.as<uint32_t>());
+	}
+
+	void update_hyperparams(const Json& p) { // adam.h:210-258
+		if (!p.is_object()) return;
+		if (p.contains("beta1")) m_h.beta1 = (float)p["beta1"].as_double();
+		if (p.contains("beta2")) m_h.beta2 = (float)p["beta2"].as_double();
+		if (p.contains("epsilon")) m_h.epsilon = (float)p["epsilon"].as_double();
+		if (p.contains("learning_rate")) m_h.learning_rate = (float)p["learning_rate"].as_double();
+		if (p.contains("l2_reg")) m_h.l2_reg = (float)p["l2_reg"].as_double();
+		if (p.contains("adabound")) m_h.adabound = p["adabound"].as_bool();
+		if (p.contains("relative_decay")) m_h.relative_decay = (float)p["relative_decay"].as_double();
+		if (p.contains("absolute_decay")) m_h.absolute_decay = (float)p["absolute_decay"].as_double();
+		if (p.contains("clipping_magnitude")) m_h.clipping_magnitude = (float)p["clipping_magnitude"].as_double();
+		if (p.contains("non_matrix_learning_rate_factor")) m_h.non_matrix_learning_rate_factor = (float)p["non_matrix_learning_rate_factor"].as_double();
+		if (p.contains("optimize_matrix_params")) m_h.optimize_matrix_params = p["optimize_matrix_params"].as_bool();
+		if (p.contains("optimize_non_matrix_params")) m_h.optimize_non_matrix_params = p["optimize_non_matrix_params"].as_bool();
+	}
+
+	Json hyperparams() const { // adam.h:260-276
+		Json j = Json::object();
+		j["otype"] = "Adam";
+		j["beta1"] = m_h.beta1;
+		j["beta2"] = m_h.beta2;
+		j["epsilon"] = m_h.epsilon;
+		j["learning_rate"] = m_h.learning_rate;
+		j["l2_reg"] = m_h.l2_reg;
+		j["adabound"] = m_h.adabound;
+		j["relative_decay"] = m_h.relative_decay;
+		j["absolute_decay"] = m_h.absolute_decay;
+		j["clipping_magnitude"] = m_h.clipping_magnitude;
+		j["non_matrix_learning_rate_factor"] = m_h.non_matrix_learning_rate_factor;
+		j["optimize_matrix_params"] = m_h.optimize_matrix_params;
+		j["optimize_non_matrix_params"] = m_h.optimize_non_matrix_params;
+		return j;
+	}
+
+	uint32_t step_count() const { return m_current_step; }
+	const AdamHyper& hyper() const { return m_h; }
+	float* first_moments() const { return m_first_moments.as<float>(); }
+	float* second_moments() const { return m_second_moments.as<float>(); }
+	uint32_t* param_steps() const { return m_param_steps.as<uint32_t>(); }
+	size_t n_matrix() const { return m_n_matrix; }
+
+private:
+	AdamHyper m_h;
+	size_t m_n_weights = 0, m_n_matrix = 0;
+	DeviceBuf m_first_moments, m_second_moments, m_param_steps;
+	uint32_t m_current_step = 0;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Trainer (trainer.h:48-363) + create_from_config (config.h:53-63)
+// ------------------------------------------------------------------------------------------------------------------
+struct TrainContext { // Trainer::ForwardContext, trainer.h:89-95
+	ArenaBuf output;      // half  [n][padded_out]
+	ArenaBuf dL_doutput;  // half  [n][padded_out]
+	const void* dL_doutput_ptr = nullptr; // = dL_doutput or the caller's external_dL_dy
+	ArenaBuf L;           // float [n][padded_out]
+	std::unique_ptr<ModelContext> model_ctx;
+	uint32_t n = 0;
+};
+
+inline MatView make_view(const float* data, uint32_t width, uint32_t n, int layout) {
+	return layout == 1 ? MatView{data, width, 1u} : MatView{data, 1u, n};
+}
+inline MatViewMut make_view_mut(float* data, uint32_t width, uint32_t n, int layout) {
+	return layout == 1 ? MatViewMut{data, width, 1u} : MatViewMut{data, 1u, n};
+}
+
+class Trainer {
+public:
+	Trainer(uint32_t n_input_dims, uint32_t n_output_dims, const Json& config, uint32_t seed) {
+		// config.h:53-63
+		const Json encoding = config.value("encoding", Json::object());
+		const Json loss = config.value("loss", Json::object());
+		const Json optimizer = config.value("optimizer", Json::object());
+		const Json network = config.value("network", Json::object());
+		m_loss = create_loss(loss);
+		m_optimizer.reset(new AdamOptimizer{optimizer});
+		m_model.reset(new NetworkWithInputEncoding{n_input_dims, n_output_dims, encoding, network});
+		// trainer.h:52-55
+		std::seed_seq seq{seed};
+		std::vector<uint32_t> seeds(2);
+		seq.generate(std::begin(seeds), std::end(seeds));
+		m_rng = Pcg32{seeds.front()};
+		m_scalar.resize(sizeof(float) * 2048);
+		initialize_params();
+	}
+
+	void initialize_params() { // trainer.h:68-87
+		const size_t n = m_model->n_params();
+		m_optimizer->allocate(n, m_model->layer_sizes());
+		m_params_fp.resize(n * sizeof(float));
+		m_params.resize(n * 2);
+		m_grads.resize(n * 2);
+		m_params_fp.memset(0);
+		m_params.memset(0);
+		m_grads.memset(0);
+		m_model->initialize_params(m_rng, m_params_fp.as<float>(), 1.0f);
+		cast_float_to_half(nullptr, n, m_params_fp.as<float>(), m_params.data());
+		HIP_CHECK_THROW(hipDeviceSynchronize());
+	}
+
+	std::unique_ptr<TrainContext> forward(hipStream_t stream, float loss_scale, uint32_t n, MatView input, const float* target, const float* data_pdf,
+	                                      bool use_inference_params, bool prepare_input_gradients, const void* external_dL_dy) { // trainer.h:97-141
+		auto ctx = std::make_unique<TrainContext>();
+		ctx->n = n;
+		const uint32_t pw = m_model->padded_output_width();
+		ctx->output = ArenaBuf{stream, (size_t)n * pw * 2};
+		ctx->model_ctx = m_model->forward(stream, n, input, ctx->output.data(), m_params.data(), prepare_input_gradients);
+		ctx->L = ArenaBuf{stream, (size_t)n * pw * sizeof(float)};
+		if (external_dL_dy) {
+			ctx->dL_doutput_ptr = external_dL_dy;
+			// the reference leaves L uninitialised in this case; zero it so that loss() is defined
+			HIP_CHECK_THROW(hipMemsetAsync(ctx->L.data(), 0, ctx->L.bytes(), stream));
+		} else {
+			CHECK_THROW(target != nullptr);
+			ctx->dL_doutput = ArenaBuf{stream, (size_t)n * pw * 2};
+			ctx->dL_doutput_ptr = ctx->dL_doutput.data();
+			loss_evaluate(stream, m_loss, n, pw, m_model->output_width(), loss_scale, ctx->output.data(), target, ctx->L.as<float>(), ctx->dL_doutput.data(), data_pdf);
+		}
+		return ctx;
+	}
+
+	void backward(hipStream_t stream, const TrainContext& ctx, uint32_t n, MatView input, MatViewMut* dL_dinput, bool use_inference_params, GradientMode mode) { // trainer.h:147-149
+		m_model->backward(stream, *ctx.model_ctx, n, input, ctx.output.data(), ctx.dL_doutput_ptr, dL_dinput, m_params.data(), m_grads.data(), mode);
+	}
+
+	void optimizer_step(hipStream_t stream, float loss_scale) { // trainer.h:155-157
+		m_optimizer->step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data());
+	}
+
+	std::unique_ptr<TrainContext> training_step(hipStream_t stream, uint32_t n, MatView input, const float* target, const float* data_pdf, bool run_optimizer,
+	                                            MatViewMut* dL_dinput, bool use_inference_params, GradientMode mode, const void* external_dL_dy) { // trainer.h:163-190
+		const float loss_scale = LOSS_SCALE_FP16;
+		auto ctx = forward(stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy);
+		backward(stream, *ctx, n, input, dL_dinput, use_inference_params, mode);
+		if (run_optimizer) optimizer_step(stream, loss_scale);
+		return ctx;
+	}
+
+	float loss(hipStream_t stream, const TrainContext& ctx) { // trainer.h:205-207 + reduce_sum.h:140-151
+		float* partials = m_scalar.as<float>();
+		float* result = partials + 1024;
+		reduce_sum(stream, (size_t)ctx.n * m_model->padded_output_width(), ctx.L.as<float>(), partials, result);
+		float host = 0;
+		HIP_CHECK_THROW(hipMemcpyAsync(&host, result, sizeof(float), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK_THROW(hipStreamSynchronize(stream));
+		return host;
+	}
+
+	void inference(hipStream_t stream, uint32_t n, MatView input, MatViewMut output, bool use_inference_params) { // object.h:147-176
+		Model::check_batch(n);
+		if (n == 0) return;
+		const uint32_t pw = m_model->padded_output_width();
+		ArenaBuf tmp{stream, (size_t)n * pw * 2};
+		m_model->inference(stream, n, input, tmp.data(), m_params.data());
+		trim_and_cast(stream, false, n, pw, m_model->output_width(), tmp.data(), output);
+	}
+
+	void set_params_full_precision(const float* params, size_t n_params, bool device_ptr) { // trainer.h:242-254
+		if (n_params != m_model->n_params()) throw std::runtime_error{"Can't set fp params because buffer has the wrong size."};
+		HIP_CHECK_THROW(hipMemcpy(m_params_fp.data(), params, sizeof(float) * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+		cast_float_to_half(nullptr, n_params, m_params_fp.as<float>(), m_params.data());
+		HIP_CHECK_THROW(hipDeviceSynchronize());
+	}
+
+	void set_params(const void* params, size_t n_params, bool device_ptr) { // trainer.h:256-269
+		if (n_params != m_model->n_params()) throw std::runtime_error{"Can't set params because buffer has the wrong size."};
+		HIP_CHECK_THROW(hipMemcpy(m_params.data(), params, 2 * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+		cast_half_to_float(nullptr, n_params, m_params.data(), m_params_fp.as<float>());
+		HIP_CHECK_THROW(hipDeviceSynchronize());
+	}
+
+	void update_hyperparams(const Json& params) { // trainer.h:213-216
+		m_optimizer->update_hyperparams(params.value("optimizer", Json::object()));
+	}
+
+	Json hyperparams() const { // trainer.h:218-224
+		Json j = Json::object();
+		j["otype"] = "Trainer";
+		j["optimizer"] = m_optimizer->hyperparams();
+		Json l = Json::object();
+		l["otype"] = to_string(m_loss);
+		j["loss"] = l;
+		return j;
+	}
+
+	NetworkWithInputEncoding& model() { return *m_model; }
+	AdamOptimizer& optimizer() { return *m_optimizer; }
+	size_t n_params() const { return m_model->n_params(); }
+	float* params_full_precision() const { return m_params_fp.as<float>(); }
+	void* params() const { return m_params.data(); }
+	void* param_gradients() const { return m_grads.data(); }
+
+private:
+	std::unique_ptr<NetworkWithInputEncoding> m_model;
+	std::unique_ptr<AdamOptimizer> m_optimizer;
+	LossType m_loss;
+	Pcg32 m_rng;
+	DeviceBuf m_params_fp, m_params, m_grads, m_scalar;
+};
+
+} // namespace tcnn_amd

@@ -1,0 +1,147 @@
+// tcnn_common.h -- shared enums, error macros and kernel-launcher declarations of libtcnn_amd (gfx950 only).
+//
+// Names follow the reference's vocabulary (include/tiny-cuda-nn/common.h:112-170) so that the host object model in
+// module.cpp reads like the reference's; the numbering is ours.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace tcnn_amd {
+
+enum class Activation : uint32_t { None = 0, ReLU = 1, LeakyReLU = 2, Exponential = 3, Sine = 4, Sigmoid = 5, Squareplus = 6, Softplus = 7, Tanh = 8 };
+enum class GridType : uint32_t { Hash = 0, Dense = 1, Tiled = 2 };
+enum class HashType : uint32_t { Prime = 0, CoherentPrime = 1, ReversedPrime = 2, Rng = 3 };
+enum class InterpolationType : uint32_t { Nearest = 0, Linear = 1, Smoothstep = 2 };
+enum class LossType : uint32_t { L2 = 0, RelativeL2 = 1 };
+enum class Precision : uint32_t { Fp32 = 0, Fp16 = 1 };      // cpp_api.h:69-72
+enum class GradientMode : uint32_t { Ignore = 0, Overwrite = 1, Accumulate = 2 }; // common.h GradientMode
+
+constexpr uint32_t BATCH_SIZE_GRANULARITY = 256; // common.h:235
+constexpr float LOSS_SCALE_FP16 = 128.0f;        // common.h:232
+constexpr uint32_t MAX_N_LEVELS = 128;           // grid_interface.h:84
+constexpr uint32_t MAX_MLP_LAYERS = 16;
+
+#define TCNN_STR2(x) #x
+#define TCNN_STR(x) TCNN_STR2(x)
+#define CHECK_THROW(x) \
+	do { if (!(x)) throw std::runtime_error{std::string{__FILE__ ":" TCNN_STR(__LINE__) " check failed: " #x}}; } while (0)
+#define HIP_CHECK_THROW(x) \
+	do { hipError_t _e = (x); if (_e != hipSuccess) throw std::runtime_error{std::string{__FILE__ ":" TCNN_STR(__LINE__) " " #x " failed: "} + hipGetErrorString(_e)}; } while (0)
+
+inline uint32_t div_round_up(uint32_t v, uint32_t d) { return (v + d - 1) / d; }
+inline uint32_t next_multiple(uint32_t v, uint32_t d) { return div_round_up(v, d) * d; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Grid encoding: per-level table precomputed on the HOST (so host and device agree bit-for-bit on scale/resolution,
+// SURVEY 7 "hard parts"); the encoding keeps one device copy (6 KiB, too large for the kernarg segment).
+// ------------------------------------------------------------------------------------------------------------------
+struct GridLevel {
+	uint32_t offset;      // first entry of the level (in entries, grid.h:714)
+	uint32_t size;        // hashmap_size = entries in the level
+	float    scale;       // grid_scale(level) (common_device.h:709-714)
+	uint32_t hashed;      // 1: index = hash(cell) ; 0: index = sum cell_d * stride[d]   (common_device.h:690-707)
+	uint32_t stride[4];   // per-dim stride of the dense index INCLUDING the uint32 wrap-around / early-exit behaviour
+	uint32_t size_mask;   // size-1 if size is a power of two, else 0 (then a real modulo is used)
+	uint32_t pad[3];
+};
+
+struct GridMeta {
+	uint32_t n_pos_dims;
+	uint32_t n_features_per_level;
+	uint32_t n_levels;
+	uint32_t grid_type;
+	uint32_t hash_type;
+	uint32_t interpolation;
+	uint32_t primes[4];
+	GridLevel levels[MAX_N_LEVELS];
+};
+
+// input matrix addressing: element (dim d, sample i) at data[i * stride_sample + d * stride_dim]
+struct MatView {
+	const float* data;
+	uint32_t stride_sample;
+	uint32_t stride_dim;
+};
+struct MatViewMut {
+	float* data;
+	uint32_t stride_sample;
+	uint32_t stride_dim;
+};
+
+// half data travels as void* on the host side
+void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx);
+// grad: T[n_params] accumulated in place (caller zeroes it).  For F == 1 && !fp32 the caller passes an fp32 scratch as `grad` with grad_is_fp32_scratch = true.
+void grid_backward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32_grad, uint32_t n, MatView x, const void* dL_dy, bool dy_fp32, uint32_t dy_stride, void* grad);
+void grid_backward_input(hipStream_t stream, const GridMeta& meta, bool fp32, uint32_t n, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
+
+// OneBlob / Identity (AoS output, T = half or float)
+void oneblob_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, uint32_t n_bins, MatView x, void* out, uint32_t out_stride);
+void oneblob_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, uint32_t n_bins, MatView x, const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx);
+void identity_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, float scale, float offset, MatView x, void* out, uint32_t out_stride);
+void identity_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, float scale, const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx);
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fully fused MLP.  Weight matrices are row-major [fan_out][fan_in] half, contiguous (fully_fused_mlp.cu:656-671).
+// The kernels consume "fragment images": the weights pre-permuted into MFMA A-operand order (see k_mlp.hip).
+// ------------------------------------------------------------------------------------------------------------------
+struct MlpLayer {
+	uint32_t rows, cols;    // fan_out, fan_in
+	uint32_t w_off;         // element offset of the matrix inside the parameter vector
+	uint32_t fwd_off;       // first fragment of the forward image (A = W)
+	uint32_t bwd_off;       // first fragment of the backward image (A = W^T)
+	uint32_t ks_fwd;        // k-steps (of 32) of the forward product = ceil(cols / 32)
+	uint32_t ks_bwd;        // k-steps of the backward product = ceil(rows / 32)
+	uint32_t natural_k;     // 1: forward fragments use natural k order (layer 0, B operand loaded from memory)
+};
+
+struct MlpDesc {
+	uint32_t in_width, width, out_width, n_hidden, n_layers;
+	uint32_t activation, output_activation;
+	uint32_t n_frags_fwd, n_frags_bwd;
+	MlpLayer layers[MAX_MLP_LAYERS];
+};
+
+size_t mlp_image_bytes(const MlpDesc& d);   // bytes of fwd+bwd images
+// params (half, row-major matrices) -> images.  image = [fwd frags][bwd frags], 1 KiB per fragment.
+void mlp_prepare_weights(hipStream_t stream, const MlpDesc& d, const void* params, void* image, bool want_bwd);
+// x: [n][in_width] half AoS; out: [n][out_width] half; hidden (optional): [n_hidden][n][width] half post-activation
+void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, void* out, void* hidden);
+// Reference-shaped backward: dL_dout [n][out_width]; hidden from mlp_forward; writes dhidden [n_hidden][n][width] and (optional) dL_dx [n][in_width]
+void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* dL_dout, const void* out, const void* hidden, void* dhidden, void* dL_dx);
+// fully_fused_mlp.cu:757-762: result = dL_dout * act'(out), elementwise over n_elems halfs
+void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32_t activation, const void* dL_dout, const void* out, void* result);
+// dW[rows x cols] = sum_i dO[i][rows]^T In[i][cols]; result written as half into grad (overwrite or accumulate). workspace: float[wgrad_workspace_floats()]
+size_t wgrad_workspace_floats(uint32_t rows, uint32_t cols, uint32_t n);
+void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uint32_t rows, const void* In, uint32_t ldi, uint32_t cols,
+               void* grad_half, uint32_t ldg, bool accumulate, float* workspace);
+
+// ------------------------------------------------------------------------------------------------------------------
+// loss / reduction / optimizer / init plumbing
+// ------------------------------------------------------------------------------------------------------------------
+void loss_evaluate(hipStream_t stream, LossType type, uint32_t n, uint32_t stride, uint32_t dims, float loss_scale,
+                   const void* pred_half, const float* target, float* values, void* grads_half, const float* data_pdf);
+// sum of n floats -> *result_dev (device float, overwritten). workspace-free: uses a two-stage reduction through `partials` (>= 1024 floats)
+void reduce_sum(hipStream_t stream, size_t n, const float* values, float* partials, float* result_dev);
+
+struct AdamHyper {
+	float learning_rate = 1e-3f, beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-8f, l2_reg = 1e-8f;
+	float relative_decay = 0.0f, absolute_decay = 0.0f, clipping_magnitude = 0.0f, non_matrix_learning_rate_factor = 1.0f;
+	bool adabound = false, optimize_matrix_params = true, optimize_non_matrix_params = true;
+};
+void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
+               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps);
+
+// random.h:40-70: strided uniform fill from a pcg32 state; advances (state, inc) on the host copy by n
+void generate_random_uniform(hipStream_t stream, uint64_t* state_inc_host, size_t n, float* out, float lower, float upper);
+void cast_float_to_half(hipStream_t stream, size_t n, const float* in, void* out);
+void cast_half_to_float(hipStream_t stream, size_t n, const void* in, float* out);
+// object.cu:61-67: [n][in_stride] T -> float out(dim, sample) = out.data[i*stride_sample + d*stride_dim], d < dims
+void trim_and_cast(hipStream_t stream, bool fp32, uint32_t n, uint32_t in_stride, uint32_t dims, const void* in, MatViewMut out);
+void fill_half(hipStream_t stream, size_t n, void* out, float value);
+
+} // namespace tcnn_amd
