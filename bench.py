@@ -1,0 +1,185 @@
+"""bench.py -- headline benchmark: trainer->training_step() throughput (samples/s) of HashGrid + 64-wide FullyFusedMLP at
+batch 256k (BASELINE.json `metric`, configs[2] = SURVEY C3a), one replica per GPU.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3a|c3b|c2|c5]
+
+For N > 1 the driver launches one process per GPU with torch.distributed.run; training does not shard in the reference
+("replicas only"), so every rank trains its own replica on its own synthetic batch -- weak scaling, no
+data-path collective; the only collectives are the timing barrier and the MAX over ranks.
+
+The JSON line carries `roofline` for the dominant kernel (fused Adam over all parameters: HBM-bound, 36 B/param,
+adam.h:48-119), timed live with HIP events on the launch stream inside the timed region, and `cpu_baseline`: the CPU
+oracle (a port of the reference algorithm, the reference has no CPU path) timed on a bounded sample on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tiny-cuda-nn_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+WORKLOADS = {
+    # name: (n_in, n_out, batch, config)
+    "c3a": (2, 3, 1 << 18, {
+        "loss": {"otype": "RelativeL2"},
+        "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
+        "encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
+    }),
+    "c3b": (2, 3, 1 << 18, {
+        "loss": {"otype": "RelativeL2"},
+        "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
+        "encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 15, "base_resolution": 16, "per_level_scale": 1.5},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
+    }),
+    "c2": (2, 3, 1 << 16, {
+        "loss": {"otype": "RelativeL2"},
+        "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-8, "l2_reg": 1e-8},
+        "encoding": {"otype": "OneBlob", "n_bins": 64},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
+    }),
+    "c5": (3, 3, 1 << 19, {
+        "loss": {"otype": "RelativeL2"},
+        "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
+        "encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 4, "log2_hashmap_size": 22, "base_resolution": 16, "per_level_scale": 2.0},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 2},
+    }),
+}
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+ADAM_BYTES_PER_PARAM = 36  # half grad r 2 + fp32 w/m/v r+w 24 + u32 step r+w 8 + half w write 2
+
+
+def cpu_baseline(name, budget_s=15.0):
+    """The CPU oracle (port of the reference algorithm) timed on a bounded sample of the same workload."""
+    import oracle as orc
+
+    n_in, n_out, batch, cfg = WORKLOADS[name]
+    sample_batch = min(batch, 1 << 14)
+    x, t = orc.synthetic_batch(sample_batch, n_in, n_out, seed=42)
+    tr = orc.Trainer(n_in, n_out, cfg, seed=1337)
+    tr.training_step(x, t)  # warm-up (page faults, OpenMP pool)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        tr.training_step(x, t)
+        steps += 1
+        if time.perf_counter() - t0 > budget_s or steps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": steps * sample_batch / dt,
+        "unit": "samples/s",
+        "cores": os.cpu_count() if os.environ.get("OMP_NUM_THREADS") is None else int(os.environ["OMP_NUM_THREADS"]),
+        "kind": "port",
+        "sample": f"{steps} training_step(s) of the CPU oracle at batch {sample_batch} (full Adam over all {tr.model.n_params} parameters each step)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="c3a", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    import tinycudann as tcnn
+
+    n_in, n_out, batch, cfg = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(42 + rank)
+    x = torch.rand((batch, n_in), device="cuda", generator=gen)
+    t = torch.rand((batch, n_out), device="cuda", generator=gen)
+
+    tr = tcnn.Trainer(n_in, n_out, cfg, seed=1337)
+    n_params = tr.n_params
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx = None
+    for _ in range(args.warmup):
+        ctx = tr.training_step(x, t, run_optimizer=False)
+        tr.optimizer_step()
+    loss0 = tr.loss(ctx) if ctx is not None else float("nan")
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        # == trainer->training_step(input, target): forward + loss + backward, then the optimizer step (trainer.h:163-190);
+        # split only so that HIP events can bracket the optimizer kernel on the launch stream.
+        ctx = tr.training_step(x, t, run_optimizer=False)
+        ev[i][0].record()
+        tr.optimizer_step()
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        el = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    loss1 = tr.loss(ctx)
+
+    adam_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    adam_bytes = ADAM_BYTES_PER_PARAM * n_params
+    achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms > 0 else 0.0
+
+    if rank == 0:
+        result = {
+            "metric": "training_step throughput (samples/s) HashGrid+64-wide FFMLP, batch=256k",
+            "value": world * batch * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['encoding']['otype']} + {cfg['network']['n_neurons']}x{cfg['network']['n_hidden_layers']} FullyFusedMLP, "
+                                   f"RelativeL2 + Adam, n_params={n_params}",
+                       "batch_per_gpu": batch, "global_batch": world * batch, "parallelism": f"replicas x{world}",
+                       "loss_first_last": [loss0, loss1]},
+            "roofline": {"bound": "hbm", "kernel": "k_adam", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": adam_bytes, "avg_launch_ms": adam_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -176,6 +176,10 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 			}
 			const uint32_t index = level_index<D>(lv, primes, hash_type, local);
 			const vecF v = *(const vecF*)&lgrid[(size_t)index * F];
+			// The reference rounds the fp32 weight product to fp32 FIRST and to T afterwards.  Without this barrier hipcc
+			// folds "fp32 multiply + convert" into v_fma_mixlo_f16 (one rounding from the exact product), which differs
+			// from the reference in ~1e-5 of the weights.
+			asm volatile("" : "+v"(weight));
 			const T w = (T)weight;
 #pragma unroll
 			for (int f = 0; f < F; ++f) {
@@ -284,6 +288,7 @@ __global__ void __launch_bounds__(256) k_grid_bwd(
 		const uint32_t index = level_index<D>(lv, primes, hash_type, local);
 		GT* p = lgrad + (size_t)index * F;
 		if constexpr (sizeof(GT) == 2) {
+			asm volatile("" : "+v"(weight)); // keep the fp32 rounding of the weight product (see k_grid_fwd)
 			const GT w = (GT)weight;
 #pragma unroll
 			for (int f = 0; f < F; f += 2) atomic_add_pair<GT>(p + f, (GT)(w * (GT)g[f]), (GT)(w * (GT)g[f + 1]));

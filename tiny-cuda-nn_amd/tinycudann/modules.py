@@ -49,7 +49,7 @@ class NativeModule:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _C is not None and getattr(_C, 'lib', None) is not None:  # modules may already be torn down at exit
             _C.lib.tcnn_module_destroy(h)
 
     # --- bindings.cpp:242-260
@@ -128,7 +128,7 @@ class NativeContext:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _C is not None and getattr(_C, 'lib', None) is not None:  # modules may already be torn down at exit
             _C.lib.tcnn_context_destroy(h)
 
 

@@ -35,7 +35,7 @@ class ForwardContext:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _C is not None and getattr(_C, 'lib', None) is not None:  # modules may already be torn down at exit
             _C.lib.tcnn_train_ctx_destroy(h)
 
     def _view(self, ptr, dtype, itemsize):
@@ -73,7 +73,7 @@ class Trainer:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _C is not None and getattr(_C, 'lib', None) is not None:  # modules may already be torn down at exit
             _C.lib.tcnn_trainer_destroy(h)
 
     # -- trainer.h:163-190
