@@ -88,6 +88,7 @@ def lib():
             "orc_grid_forward": (None, [vp, u32, vp, vp, vp, u32, vp, vp]),
             "orc_grid_backward": (None, [vp, u32, vp, vp, u32, vp, vp]),
             "orc_grid_backward_input": (None, [vp, u32, vp, u32, vp, vp]),
+            "orc_grid_backward_exact": (None, [vp, u32, vp, vp, u32, vp, C.c_int]),
             "orc_oneblob_forward": (None, [u32, u32, u32, vp, vp, u32]), "orc_oneblob_backward_input": (None, [u32, u32, u32, vp, vp, u32, vp]),
             "orc_identity_forward": (None, [u32, u32, f32, f32, vp, vp, u32]), "orc_identity_backward_input": (None, [u32, u32, f32, vp, u32, vp]),
             "orc_mlp_n_params": (sz, [vp]), "orc_mlp_init_params": (None, [vp, vp, vp, f32]),
@@ -274,6 +275,13 @@ class GridEncoding:
             lib().orc_grid_backward_input(C.byref(self.g), n, _p(dL_dy), dL_dy.shape[1], _p(ctx["dy_dx"]), _p(dL_dx))
             return dL_dx
         return None
+
+    def backward_exact(self, x, dL_dy, grad_half, accumulate=False):
+        """Order-independent limit of the reference's fp16 atomic scatter: exact sum of the fp16 products, rounded once."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dL_dy = np.ascontiguousarray(dL_dy)
+        lib().orc_grid_backward_exact(C.byref(self.g), x.shape[0], _p(x), _p(dL_dy), dL_dy.shape[1], _p(grad_half), int(accumulate))
+        return grad_half
 
     def hyperparams(self):
         r = {"otype": "Grid", "type": ["Hash", "Dense", "Tiled"][self.g.grid_type], "n_levels": int(self.g.n_levels),

@@ -558,6 +558,55 @@ void orc_grid_backward(const orc_grid_t* g, uint32_t n, const float* x, const ui
 	}
 }
 
+// Exact mode: every contribution is the reference's fp16 product (half)weight * dL_dy (grid.h:254); the contributions of an
+// entry are summed EXACTLY (integers in units of 2^-24, the fp16 subnormal LSB) and rounded to fp16 once.  This is the
+// order-independent limit of the reference's fp16 atomic accumulation and what the MI355X scatter kernel computes.
+void orc_grid_backward_exact(const orc_grid_t* g, uint32_t n, const float* x, const uint16_t* dL_dy, uint32_t dy_stride, uint16_t* grad, int accumulate) {
+	const uint32_t D = g->n_pos_dims, F = g->n_features_per_level, L = g->n_levels;
+	const uint32_t n_corners = 1u << D;
+	auto to_fixed = [](uint16_t h) -> int64_t { return (int64_t)std::llround(std::ldexp((double)h2f(h), 24)); }; // exact: fp16 * 2^24 is an integer
+#pragma omp parallel for schedule(dynamic, 1)
+	for (uint32_t level = 0; level < L; ++level) {
+		const uint32_t hashmap_size = g->offsets[level + 1] - g->offsets[level];
+		std::vector<int64_t> sum((size_t)hashmap_size * F, 0);
+		uint16_t* lgrad = grad + (size_t)g->offsets[level] * F;
+		if (accumulate) for (size_t k = 0; k < sum.size(); ++k) sum[k] = to_fixed(lgrad[k]);
+		const float scale = g->scales[level];
+		const uint32_t resolution = g->resolutions[level];
+		for (uint32_t i = 0; i < n; ++i) {
+			float pos[8];
+			uint32_t pos_grid[8];
+			for (uint32_t dim = 0; dim < D; ++dim) pos_grid[dim] = pos_fract(x[(size_t)i * D + dim], scale, g->interpolation, &pos[dim], nullptr);
+			const uint16_t* gy = dL_dy + (size_t)i * dy_stride + level * F;
+			auto add = [&](const uint32_t* local, float weight) {
+				const uint32_t index = grid_index(D, g->hash_type, g->grid_type, hashmap_size, resolution, local);
+				const uint16_t wh = f2h(weight);
+				for (uint32_t f = 0; f < F; ++f) sum[(size_t)index * F + f] += to_fixed(hmul(wh, gy[f]));
+			};
+			if (g->interpolation == ORC_INTERP_NEAREST) {
+				add(pos_grid, 1.0f);
+				continue;
+			}
+			for (uint32_t idx = 0; idx < n_corners; ++idx) {
+				float weight = 1;
+				uint32_t local[8];
+				for (uint32_t dim = 0; dim < D; ++dim) {
+					if ((idx & (1u << dim)) == 0) {
+						weight *= 1 - pos[dim];
+						local[dim] = pos_grid[dim];
+					} else {
+						weight *= pos[dim];
+						local[dim] = pos_grid[dim] + 1;
+					}
+				}
+				add(local, weight);
+			}
+		}
+		// |sum| < 2^53 for any realistic batch: the conversion to double is exact, d2h rounds once
+		for (size_t k = 0; k < sum.size(); ++k) lgrad[k] = d2h(std::ldexp((double)sum[k], -24));
+	}
+}
+
 void orc_grid_backward_input(const orc_grid_t* g, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, const float* dy_dx, float* dL_dx) {
 	const uint32_t D = g->n_pos_dims, NF = g->n_levels * g->n_features_per_level;
 #pragma omp parallel for schedule(static)

@@ -89,6 +89,9 @@ void orc_grid_forward(const orc_grid_t* g, uint32_t n, const float* x, const uin
  * grad_f32 (optional): fp32 accumulation of the same products, for tolerance checks. */
 void orc_grid_backward(const orc_grid_t* g, uint32_t n, const float* x, const uint16_t* dL_dy, uint32_t dy_stride,
                        uint16_t* grad, float* grad_f32);
+/* grid.h:215-320 with the order-independent limit of the fp16 atomic accumulation: contributions are the reference's fp16
+ * products, summed exactly and rounded to fp16 once.  grad is overwritten (or, accumulate != 0, the old value joins the exact sum). */
+void orc_grid_backward_exact(const orc_grid_t* g, uint32_t n, const float* x, const uint16_t* dL_dy, uint32_t dy_stride, uint16_t* grad, int accumulate);
 /* grid.h:323-349 */
 void orc_grid_backward_input(const orc_grid_t* g, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, const float* dy_dx, float* dL_dx);
 

@@ -14,89 +14,10 @@
 //     the uint32 wrap-around quirk of grid_index's stride loop, so device and host can never disagree.
 //
 // Compiled with -ffp-contract=off: every fused multiply-add is explicit.
-#include "tcnn_common.h"
-
-#include <hip/hip_fp16.h>
+#include "grid_device.h"
 
 namespace tcnn_amd {
 namespace {
-
-typedef _Float16 half_t;
-
-template <typename T, int N> struct VecOf { typedef T type __attribute__((ext_vector_type(N))); };
-template <typename T> struct VecOf<T, 1> { typedef T type; };
-
-__device__ inline float smoothstep(float v) { return v * v * (3.0f - 2.0f * v); }
-__device__ inline float smoothstep_derivative(float v) { return 6 * v * (1.0f - v); }
-
-// common_device.h:856-868
-__device__ inline uint32_t pos_fract(float input, float scale, uint32_t interpolation, float* pos, float* pos_derivative) {
-	float p = fmaf(scale, input, 0.5f);
-	const float tmp = floorf(p);
-	const uint32_t cell = (uint32_t)(int)tmp;
-	p -= tmp;
-	if (interpolation == (uint32_t)InterpolationType::Smoothstep) {
-		*pos_derivative = smoothstep_derivative(p);
-		*pos = smoothstep(p);
-	} else {
-		*pos_derivative = 1.0f;
-		*pos = p;
-	}
-	return cell;
-}
-
-// pcg32 pieces needed by HashType::Rng (common_device.h:663-676)
-__device__ inline uint32_t rng_hash_device(const uint32_t* pos, int n_dims) {
-	const uint64_t MULT = 0x5851f42d4c957f2dULL;
-	const uint32_t bits_per_dim = 64 / n_dims;
-	uint64_t step = 0;
-	for (int i = 0; i < n_dims; ++i) step ^= (uint64_t)pos[i] << (i * bits_per_dim);
-	// pcg32{1337}: seed()
-	uint64_t inc = (1ull << 1u) | 1u;
-	uint64_t state = 0;
-	state = state * MULT + inc;
-	state += 1337ull;
-	state = state * MULT + inc;
-	// advance(step)
-	uint64_t cur_mult = MULT, cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
-	uint64_t delta = step;
-	while (delta > 0) {
-		if (delta & 1) {
-			acc_mult *= cur_mult;
-			acc_plus = acc_plus * cur_mult + cur_plus;
-		}
-		cur_plus = (cur_mult + 1) * cur_plus;
-		cur_mult *= cur_mult;
-		delta /= 2;
-	}
-	state = acc_mult * state + acc_plus;
-	// next_uint()
-	const uint64_t old = state;
-	const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
-	const uint32_t rot = (uint32_t)(old >> 59u);
-	return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
-}
-
-// grid_index (common_device.h:690-707) with the stride loop folded into GridLevel::stride / ::hashed on the host
-template <int D>
-__device__ inline uint32_t level_index(const GridLevel& lv, const uint32_t* primes, uint32_t hash_type, const uint32_t* cell) {
-	uint32_t index;
-	if (lv.hashed) {
-		if (hash_type == (uint32_t)HashType::Rng) {
-			index = rng_hash_device(cell, D);
-		} else {
-			index = 0;
-#pragma unroll
-			for (int d = 0; d < D; ++d) index ^= cell[d] * primes[d];
-		}
-	} else {
-		index = 0;
-#pragma unroll
-		for (int d = 0; d < D; ++d) index += cell[d] * lv.stride[d];
-	}
-	if (lv.size_mask) return index & lv.size_mask;
-	return index >= lv.size ? index % lv.size : index;
-}
 
 template <typename T> __device__ inline T fma_t(T a, T b, T c);
 template <> __device__ inline float fma_t<float>(float a, float b, float c) { return fmaf(a, b, c); }
@@ -105,7 +26,7 @@ template <> __device__ inline half_t fma_t<half_t>(half_t a, half_t b, half_t c)
 template <typename T, int D, int F>
 __global__ void __launch_bounds__(256) k_grid_fwd(
 	const GridMeta* __restrict__ meta, const uint32_t n, const MatView x, const T* __restrict__ grid,
-	T* __restrict__ out, const uint32_t out_stride, const uint32_t n_chunks, float* __restrict__ dy_dx
+	T* __restrict__ out, const uint32_t out_stride, const uint32_t n_chunks, float* __restrict__ dy_dx, unsigned long long* __restrict__ chunk_mask
 ) {
 	constexpr int LPT = 8 / F; // levels per thread: 8 output features
 	typedef typename VecOf<T, F>::type vecF;
@@ -123,8 +44,7 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 	for (int d = 0; d < D; ++d) primes[d] = meta->primes[d];
 
 	float xin[D];
-#pragma unroll
-	for (int d = 0; d < D; ++d) xin[d] = x.data[(size_t)i * x.stride_sample + (size_t)d * x.stride_dim];
+	load_coords<D>(x, i, xin);
 
 	T res[8];
 #pragma unroll
@@ -145,6 +65,7 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 		if (interpolation == (uint32_t)InterpolationType::Nearest) { // grid.h:121-140
 			const uint32_t index = level_index<D>(lv, primes, hash_type, cell);
 			const vecF v = *(const vecF*)&lgrid[(size_t)index * F];
+			if (chunk_mask) chunk_mask[(size_t)level * n + i] = 1ull << scatter_chunk(lv, index);
 #pragma unroll
 			for (int f = 0; f < F; ++f) { if constexpr (F == 1) res[ll * F + f] = v; else res[ll * F + f] = v[f]; }
 			if (dy_dx) {
@@ -158,6 +79,7 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 
 		// N-linear interpolation (grid.h:142-169): weight product in fp32 (dim order), cast to T, fma chain in corner order
 		T acc[F];
+		unsigned long long touched = 0; // scatter chunks of this level the sample's corners fall into
 #pragma unroll
 		for (int f = 0; f < F; ++f) acc[f] = (T)0.0f;
 #pragma unroll
@@ -176,6 +98,7 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 			}
 			const uint32_t index = level_index<D>(lv, primes, hash_type, local);
 			const vecF v = *(const vecF*)&lgrid[(size_t)index * F];
+			touched |= 1ull << scatter_chunk(lv, index);
 			// The reference rounds the fp32 weight product to fp32 FIRST and to T afterwards.  Without this barrier hipcc
 			// folds "fp32 multiply + convert" into v_fma_mixlo_f16 (one rounding from the exact product), which differs
 			// from the reference in ~1e-5 of the weights.
@@ -190,6 +113,7 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 		}
 #pragma unroll
 		for (int f = 0; f < F; ++f) res[ll * F + f] = acc[f];
+		if (chunk_mask) chunk_mask[(size_t)level * n + i] = touched;
 
 		if (dy_dx) { // grid.h:172-211
 			float grads[F][D];
@@ -339,13 +263,13 @@ __global__ void __launch_bounds__(128) k_grid_bwd_input(
 }
 
 template <typename T, int D, int F>
-void launch_fwd(hipStream_t stream, const GridMeta* dev_meta, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx) {
+void launch_fwd(hipStream_t stream, const GridMeta* dev_meta, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx, uint64_t* chunk_mask) {
 	const uint32_t n_chunks = div_round_up(out_stride, 8);
 	const uint64_t total = (uint64_t)n * n_chunks;
 	CHECK_THROW(total < (1ull << 32));
 	const uint32_t blocks = (uint32_t)((total + 255) / 256);
 	if (blocks == 0) return;
-	hipLaunchKernelGGL((k_grid_fwd<T, D, F>), dim3(blocks), dim3(256), 0, stream, dev_meta, n, x, (const T*)grid, (T*)out, out_stride, n_chunks, dy_dx);
+	hipLaunchKernelGGL((k_grid_fwd<T, D, F>), dim3(blocks), dim3(256), 0, stream, dev_meta, n, x, (const T*)grid, (T*)out, out_stride, n_chunks, dy_dx, (unsigned long long*)chunk_mask);
 }
 
 template <typename T, typename GT, int D, int F>
@@ -358,12 +282,12 @@ void launch_bwd(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_me
 }
 
 template <typename T, int D>
-void dispatch_fwd_F(hipStream_t s, uint32_t F, const GridMeta* dm, uint32_t n, MatView x, const void* grid, void* out, uint32_t os, float* dy_dx) {
+void dispatch_fwd_F(hipStream_t s, uint32_t F, const GridMeta* dm, uint32_t n, MatView x, const void* grid, void* out, uint32_t os, float* dy_dx, uint64_t* cm) {
 	switch (F) {
-		case 1: return launch_fwd<T, D, 1>(s, dm, n, x, grid, out, os, dy_dx);
-		case 2: return launch_fwd<T, D, 2>(s, dm, n, x, grid, out, os, dy_dx);
-		case 4: return launch_fwd<T, D, 4>(s, dm, n, x, grid, out, os, dy_dx);
-		case 8: return launch_fwd<T, D, 8>(s, dm, n, x, grid, out, os, dy_dx);
+		case 1: return launch_fwd<T, D, 1>(s, dm, n, x, grid, out, os, dy_dx, cm);
+		case 2: return launch_fwd<T, D, 2>(s, dm, n, x, grid, out, os, dy_dx, cm);
+		case 4: return launch_fwd<T, D, 4>(s, dm, n, x, grid, out, os, dy_dx, cm);
+		case 8: return launch_fwd<T, D, 8>(s, dm, n, x, grid, out, os, dy_dx, cm);
 		default: throw std::runtime_error{"GridEncoding: n_features_per_level must be 1, 2, 4, or 8."};
 	}
 }
@@ -383,13 +307,14 @@ void dispatch_bwd_F(hipStream_t s, const GridMeta& m, const GridMeta* dm, uint32
 
 } // namespace
 
-void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx) {
+void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx,
+                  uint64_t* chunk_mask) {
 	const uint32_t F = meta.n_features_per_level;
 #define TCNN_GRID_FWD(T) \
 	switch (meta.n_pos_dims) { \
-		case 2: return dispatch_fwd_F<T, 2>(stream, F, dev_meta, n, x, grid, out, out_stride, dy_dx); \
-		case 3: return dispatch_fwd_F<T, 3>(stream, F, dev_meta, n, x, grid, out, out_stride, dy_dx); \
-		case 4: return dispatch_fwd_F<T, 4>(stream, F, dev_meta, n, x, grid, out, out_stride, dy_dx); \
+		case 2: return dispatch_fwd_F<T, 2>(stream, F, dev_meta, n, x, grid, out, out_stride, dy_dx, chunk_mask); \
+		case 3: return dispatch_fwd_F<T, 3>(stream, F, dev_meta, n, x, grid, out, out_stride, dy_dx, chunk_mask); \
+		case 4: return dispatch_fwd_F<T, 4>(stream, F, dev_meta, n, x, grid, out, out_stride, dy_dx, chunk_mask); \
 		default: throw std::runtime_error{"GridEncoding: number of input dims must be 2 or 3."}; \
 	}
 	if (fp32) { TCNN_GRID_FWD(float) } else { TCNN_GRID_FWD(half_t) }

@@ -1,0 +1,443 @@
+// k_grid_scatter.hip -- dL/dgrid for the hash / dense / tiled grid, MI355X form: "owner computes", exact, deterministic.
+//
+// Replaces (reference, /root/reference): include/tiny-cuda-nn/encodings/grid.h:215-320 (kernel_grid_backward) together
+// with the memset of the gradient table (grid.h:858) for half-precision grids with F >= 2.
+//
+// Why not the reference's shape.  The reference scatters 2^D * L packed-fp16 atomics per sample into global memory
+// (grid.h:252-255).  Measured on MI355X (profiles/round1_*): random float atomics execute at the memory side at ~21 G/s
+// chip-wide whatever their scope or footprint, so the 16.8 M atomics of one 256k-sample step cost 0.8-2.2 ms -- up to
+// 78 % of the training step.  LDS *float* atomics are no way out either: ds_pk_add_f16 / ds_add_f32 retire ~0.32 lanes
+// per clock per CU (measured), while LDS *integer* atomics retire 3.7-4.6.
+//
+// What this file does instead.
+//   * Every workgroup OWNS a contiguous chunk of one level's table, held in LDS as 64-bit fixed-point accumulators
+//     (LSB = 2^-24, the finest fp16 subnormal: every fp16 product converts EXACTLY, and 2^39 such products fit).
+//   * The forward pass recorded, per (level, chunk), one bit per sample: "this sample touches the chunk" (k_grid_fwd ->
+//     grid_mask_to_bits).  A workgroup reads only its own bit plane, compacts the hits and recomputes indices / weights
+//     for those samples alone (cheap integer + fp32 math, bit-identical to the forward pass).
+//   * Each contribution is formed exactly as the reference forms it -- (half)weight * dL_dy in fp16 (grid.h:254) -- then
+//     added with ds_add_u64.  Integer addition is associative: the result is the EXACT sum of the fp16 products, rounded
+//     to fp16 once (round-to-nearest-even) -- deterministic, independent of scheduling, and at least as accurate as any
+//     order of the reference's fp16 atomics.  The oracle reproduces it bit for bit (orc_grid_backward, exact mode).
+//   * The owner writes its chunk with plain coalesced stores, which also replaces the memset of the whole table.
+//     Coarse levels, where every sample hits the same few entries, are split over several workgroups by sample range;
+//     their exact partial sums are merged with 64-bit integer atomics in a small scratch table and rounded by
+//     k_grid_scatter_finalize.
+#include "grid_device.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace tcnn_amd {
+namespace {
+
+constexpr uint32_t SCATTER_ACC_BYTES = 128 * 1024; // accumulator chunk per workgroup
+constexpr uint32_t SCATTER_THREADS = 1024;
+constexpr uint32_t SCATTER_WAVES = SCATTER_THREADS / 64;
+constexpr uint32_t SCATTER_QUEUE_IDS = 128;        // wave-private compaction queue (sample ids)
+constexpr uint32_t SCATTER_LDS_BYTES = SCATTER_ACC_BYTES + SCATTER_WAVES * SCATTER_QUEUE_IDS * 4;
+constexpr uint32_t SCATTER_MAX_CHUNKS = 64;        // bit planes per level (the forward mask is a uint64)
+
+// h * 2^24 as an integer: exact for every finite fp16 value
+__device__ inline long long half_to_fixed(half_t h) {
+	const uint16_t b = __builtin_bit_cast(uint16_t, h);
+	const uint32_t e = (b >> 10) & 31u, f = b & 1023u;
+	const unsigned long long m = e ? ((unsigned long long)(1024u | f) << (e - 1)) : (unsigned long long)f;
+	return (b & 0x8000u) ? -(long long)m : (long long)m;
+}
+
+// s * 2^-24 rounded to fp16, round-to-nearest-even, one rounding
+__device__ inline half_t fixed_to_half(long long s) {
+	const bool neg = s < 0;
+	unsigned long long m = neg ? (unsigned long long)(-s) : (unsigned long long)s;
+	if (m == 0) return (half_t)0.0f;
+	const int p = 63 - __builtin_clzll(m);
+	float v;
+	if (p <= 10) {
+		v = (float)(uint32_t)m * 5.9604644775390625e-08f; // 2^-24, exact
+	} else {
+		const int shift = p - 10;
+		unsigned long long q = m >> shift;
+		const unsigned long long rem = m & ((1ull << shift) - 1), half = 1ull << (shift - 1);
+		if (rem > half || (rem == half && (q & 1ull))) ++q;
+		v = ldexpf((float)(uint32_t)q, shift - 24); // <= 12 significant bits: exact; >= 65520 becomes inf in the cast below
+	}
+	const half_t r = (half_t)v;
+	return neg ? -r : r;
+}
+
+template <int D, int F>
+__global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
+	const GridMeta* __restrict__ meta, const GridScatterTask* __restrict__ tasks, const uint32_t n, const MatView x,
+	const half_t* __restrict__ dL_dy, const uint32_t dy_stride_sample, const uint32_t dy_stride_level, half_t* __restrict__ grad,
+	const unsigned long long* __restrict__ chunk_bits, unsigned long long* __restrict__ scratch, const int accumulate_mode,
+	unsigned long long* __restrict__ dbg_times
+) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	long long* acc = (long long*)smem; // [n_entries][F]
+	typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+	lds_u64* acc_lds = (lds_u64*)smem;
+	const GridScatterTask task = tasks[blockIdx.x];
+	if (task.n_entries == 0) return;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63, wave = tid >> 6;
+	uint32_t* queue = (uint32_t*)(smem + SCATTER_ACC_BYTES) + wave * SCATTER_QUEUE_IDS; // wave-private
+	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+
+	const GridLevel lv = meta->levels[task.level];
+	half_t* __restrict__ g = grad + ((size_t)lv.offset + task.entry_begin) * F;
+	const uint32_t n_vals = task.n_entries * F;
+
+	// initialise the owned chunk: zero, or the existing gradient for GradientMode::Accumulate when we are the only owner
+	if (accumulate_mode && !task.flush_atomic) {
+		for (uint32_t i = tid; i < n_vals; i += SCATTER_THREADS) acc[i] = half_to_fixed(g[i]);
+	} else {
+		typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+		u4* a4 = (u4*)smem;
+		const uint32_t n16 = n_vals / 2;
+		for (uint32_t i = tid; i < n16; i += SCATTER_THREADS) a4[i] = u4{0, 0, 0, 0};
+		if ((n_vals & 1u) && tid == 0) acc[n_vals - 1] = 0;
+	}
+	__syncthreads();
+	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+
+	const uint32_t interpolation = meta->interpolation;
+	const uint32_t hash_type = meta->hash_type;
+	uint32_t primes[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) primes[d] = meta->primes[d];
+	const half_t* __restrict__ dy = dL_dy + (size_t)task.level * dy_stride_level;
+	typedef typename VecOf<half_t, F>::type vecF;
+
+	// issue the loads of one sample (coordinates + its dL/dy of this level)
+	auto fetch = [&](const uint32_t i, float (&xin)[D], vecF& gv) {
+		load_coords<D>(x, i, xin);
+		gv = *(const vecF*)&dy[(size_t)i * dy_stride_sample];
+	};
+	// full treatment of one sample: recompute its corners, add those that fall into the owned chunk (grid.h:215-320)
+	auto accumulate = [&](const float (&xin)[D], const vecF& gv) {
+		float pos[D], unused;
+		uint32_t cell[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) cell[d] = pos_fract(xin[d], lv.scale, interpolation, &pos[d], &unused);
+
+		auto add = [&](const uint32_t* local, float weight) {
+			const uint32_t index = level_index<D>(lv, primes, hash_type, local) - task.entry_begin;
+			if (index < task.n_entries) {
+				asm volatile("" : "+v"(weight)); // keep the fp32 rounding of the weight product (see k_grid_fwd)
+				const half_t w = (half_t)weight;
+#pragma unroll
+				for (int f = 0; f < F; ++f) {
+					const half_t c = w * gv[f]; // (GRAD_T)weight * grad in fp16, grid.h:254
+					// explicit LDS address space: guarantees ds_add_u64 (a generic pointer may degrade to flat_atomic_add_x2)
+					__hip_atomic_fetch_add(acc_lds + index * F + f, (unsigned long long)half_to_fixed(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+		};
+
+		if (interpolation == (uint32_t)InterpolationType::Nearest) {
+			add(cell, 1.0f);
+			return;
+		}
+#pragma unroll
+		for (int idx = 0; idx < (1 << D); ++idx) {
+			float weight = 1;
+			uint32_t local[D];
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+				if ((idx & (1 << d)) == 0) {
+					weight *= 1 - pos[d];
+					local[d] = cell[d];
+				} else {
+					weight *= pos[d];
+					local[d] = cell[d] + 1;
+				}
+			}
+			add(local, weight);
+		}
+	};
+
+	// Every wave owns a contiguous block of the task's samples and walks it 64 samples at a time.  Loads of batch k+1 are
+	// issued before batch k is accumulated (two register sets, A and B), so a wave always has a batch in flight.
+	const uint32_t n_task = task.sample_end - task.sample_begin;
+	const uint32_t per_wave = ((n_task + SCATTER_WAVES - 1) / SCATTER_WAVES + 63) / 64 * 64;
+	const uint32_t w_begin = min(task.sample_begin + wave * per_wave, task.sample_end);
+	const uint32_t w_end = min(task.sample_end, w_begin + per_wave);
+	const uint32_t n_blocks = (w_end - w_begin + 63) / 64; // wave-uniform
+
+	float ax[D], bx[D];
+	vecF ag, bg;
+	bool a_valid = false, b_valid = false; // per lane
+	uint32_t phase = 0;                    // wave-uniform: which register set receives the next batch
+	auto submit = [&](const uint32_t i, const bool valid) { // i is in range for every lane (clamped by the caller)
+		if (phase == 0) {
+			fetch(i, ax, ag);
+			if (b_valid) accumulate(bx, bg);
+			a_valid = valid;
+			b_valid = false;
+			phase = 1;
+		} else {
+			fetch(i, bx, bg);
+			if (a_valid) accumulate(ax, ag);
+			b_valid = valid;
+			a_valid = false;
+			phase = 0;
+		}
+	};
+
+	if (n_blocks > 0) {
+		if (chunk_bits == nullptr || lv.scatter_n_chunks == 1) {
+			// no filter available (or nothing to filter): every sample gets the full treatment
+			for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+				const uint32_t i = w_begin + blk * 64 + lane;
+				submit(min(i, w_end - 1), i < w_end);
+			}
+		} else {
+			// One bit per sample says whether it touches this chunk.  A wave reads 64 words at once (one word = the ballot of
+			// one 64-sample block), compacts the hits into its LDS queue and runs the expensive part on full batches of 64.
+			const unsigned long long* __restrict__ words =
+				chunk_bits + ((size_t)task.level * SCATTER_MAX_CHUNKS + scatter_chunk(lv, task.entry_begin)) * (n / 64) + w_begin / 64;
+			uint32_t queued = 0; // wave-uniform
+			for (uint32_t blk0 = 0; blk0 < n_blocks; blk0 += 64) {
+				// one word (= 64 samples) per lane; every round each lane with bits left peels off its lowest one
+				unsigned long long w = blk0 + lane < n_blocks ? words[blk0 + lane] : 0ull;
+				const uint32_t base_id = w_begin + (blk0 + lane) * 64;
+				while (true) {
+					const bool has = w != 0;
+					const unsigned long long ballot = __ballot(has);
+					if (ballot == 0) break;
+					const uint32_t blo = (uint32_t)ballot, bhi = (uint32_t)(ballot >> 32);
+					if (has) {
+						queue[queued + __builtin_amdgcn_mbcnt_hi(bhi, __builtin_amdgcn_mbcnt_lo(blo, 0))] = base_id + (uint32_t)__builtin_ctzll(w);
+						w &= w - 1;
+					}
+					queued += __builtin_popcount(blo) + __builtin_popcount(bhi);
+					if (queued >= 64) {
+						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+						__builtin_amdgcn_wave_barrier();
+						const uint32_t id = queue[lane];
+						const uint32_t rest = queue[64 + lane];
+						__builtin_amdgcn_wave_barrier();
+						queued -= 64;
+						if (lane < queued) queue[lane] = rest;
+						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+						submit(id, true);
+					}
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			if (queued > 0) submit(lane < queued ? queue[lane] : w_begin, lane < queued);
+		}
+		if (a_valid) accumulate(ax, ag);
+		if (b_valid) accumulate(bx, bg);
+	}
+	__syncthreads();
+	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+
+	if (task.flush_atomic) {
+		// several workgroups share this chunk: merge the exact partial sums with 64-bit integer atomics; rounded later
+		unsigned long long* sc = scratch + (size_t)task.scratch_begin;
+		for (uint32_t i = tid; i < n_vals; i += SCATTER_THREADS) {
+			const long long v = acc[i];
+			if (v != 0) atomicAdd(sc + i, (unsigned long long)v);
+		}
+	} else {
+		// sole owner: round once and store (two values per 4-byte store; n_vals is even because F >= 2)
+		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+		for (uint32_t i = tid; i < n_vals / 2; i += SCATTER_THREADS) {
+			((h2*)g)[i] = h2{fixed_to_half(acc[2 * i]), fixed_to_half(acc[2 * i + 1])};
+		}
+	}
+	if (dbg_times) {
+		__syncthreads();
+		if (tid == 0) dbg_times[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+	}
+}
+
+// shared (split) chunks: scratch holds the exact integer sums; round, store, and leave the scratch zeroed for the next step
+__global__ void __launch_bounds__(256) k_grid_scatter_finalize(const GridScatterRange* __restrict__ ranges, unsigned long long* __restrict__ scratch, half_t* __restrict__ grad, const int accumulate_mode) {
+	const GridScatterRange r = ranges[blockIdx.y];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < r.n_elems; i += gridDim.x * blockDim.x) {
+		long long s = (long long)scratch[r.scratch_begin + i];
+		scratch[r.scratch_begin + i] = 0;
+		if (accumulate_mode) s += half_to_fixed(grad[r.grad_begin + i]);
+		grad[r.grad_begin + i] = fixed_to_half(s);
+	}
+}
+
+// [n_levels][n] uint64 masks (written by k_grid_fwd) -> bit planes [n_levels][64][n / 64] uint64: word w of plane (l, c)
+// is the ballot "sample 64 w + lane touches chunk c of level l".  One wave per 64 samples of one level.
+__global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __restrict__ meta, const uint32_t n, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ bits) {
+	const uint32_t level = blockIdx.y;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return; // n is a multiple of 64: whole waves leave together
+	const uint32_t n_chunks = meta->levels[level].scatter_n_chunks;
+	if (n_chunks <= 1) return;
+	const unsigned long long m = mask[(size_t)level * n + i];
+	const uint32_t lane = threadIdx.x & 63;
+	unsigned long long mine = 0;
+	for (uint32_t c = 0; c < n_chunks; ++c) {
+		const unsigned long long b = __ballot((m >> c) & 1ull);
+		if (lane == c) mine = b;
+	}
+	if (lane < n_chunks) bits[((size_t)level * SCATTER_MAX_CHUNKS + lane) * (n / 64) + i / 64] = mine;
+}
+
+template <int D, int F>
+void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x, const void* dy, uint32_t dss, uint32_t dsl,
+                    void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate) {
+	static bool configured = false;
+	if (!configured) { // more than 64 KiB of dynamic LDS has to be opted into once per kernel
+		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_grid_scatter<D, F>, hipFuncAttributeMaxDynamicSharedMemorySize, SCATTER_LDS_BYTES));
+		configured = true;
+	}
+	// development aid: TCNN_AMD_SCATTER_TIMING=1 prints per-task phase times (100 MHz constant clock) for the 3rd launch
+	static const bool timing = getenv("TCNN_AMD_SCATTER_TIMING") != nullptr;
+	static int timing_left = 3;
+	unsigned long long* dbg = nullptr;
+	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&dbg, (size_t)n_tasks * 4 * 8));
+	hipLaunchKernelGGL((k_grid_scatter<D, F>), dim3(n_tasks), dim3(SCATTER_THREADS), SCATTER_LDS_BYTES, s, dm, tasks, n, x, (const half_t*)dy, dss, dsl, (half_t*)grad, chunk_bits,
+	                   scratch, accumulate ? 1 : 0, dbg);
+	HIP_CHECK_THROW(hipGetLastError());
+	if (dbg) {
+		std::vector<unsigned long long> h((size_t)n_tasks * 4);
+		std::vector<GridScatterTask> ht(n_tasks);
+		HIP_CHECK_THROW(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+		HIP_CHECK_THROW(hipMemcpy(ht.data(), tasks, n_tasks * sizeof(GridScatterTask), hipMemcpyDeviceToHost));
+		unsigned long long t0 = ~0ull;
+		for (uint32_t i = 0; i < n_tasks; ++i) if (ht[i].n_entries) t0 = std::min(t0, h[i * 4]);
+		if (--timing_left == 0) {
+			for (uint32_t i = 0; i < n_tasks; ++i) {
+				if (!ht[i].n_entries) continue;
+				fprintf(stderr, "task %3u level %2u entries %6u samples %6u atomic %u: start %7.1f zero %6.1f accumulate %6.1f flush %6.1f us\n", i, ht[i].level, ht[i].n_entries,
+				        ht[i].sample_end - ht[i].sample_begin, ht[i].flush_atomic, (h[i * 4] - t0) * 0.01, (h[i * 4 + 1] - h[i * 4]) * 0.01, (h[i * 4 + 2] - h[i * 4 + 1]) * 0.01,
+				        (h[i * 4 + 3] - h[i * 4 + 2]) * 0.01);
+			}
+		}
+		(void)hipFree(dbg);
+	}
+}
+
+template <int D>
+void dispatch_scatter(hipStream_t s, uint32_t F, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x,
+                      const void* dy, uint32_t dss, uint32_t dsl, void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate) {
+	switch (F) {
+		case 2: return launch_scatter<D, 2>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
+		case 4: return launch_scatter<D, 4>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
+		case 8: return launch_scatter<D, 8>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
+		default: throw std::runtime_error{"grid_backward_lds: needs n_features_per_level in {2, 4, 8}"};
+	}
+}
+
+} // namespace
+
+uint32_t grid_scatter_max_chunks() { return SCATTER_MAX_CHUNKS; }
+
+void grid_scatter_setup_levels(GridMeta& meta) {
+	const uint32_t capacity = SCATTER_ACC_BYTES / (meta.n_features_per_level * 8); // entries one workgroup can own (64-bit accumulators)
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		GridLevel& lv = meta.levels[l];
+		lv.scatter_n_chunks = div_round_up(lv.size, capacity);
+		lv.scatter_per_chunk = next_multiple(div_round_up(lv.size, lv.scatter_n_chunks), 8u);
+		lv.scatter_shift = 0xffffffffu;
+		if ((lv.scatter_per_chunk & (lv.scatter_per_chunk - 1)) == 0) {
+			lv.scatter_shift = 0;
+			while ((1u << lv.scatter_shift) < lv.scatter_per_chunk) ++lv.scatter_shift;
+		}
+	}
+}
+
+void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, const uint64_t* mask, uint64_t* bits) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_grid_mask_to_bits, dim3(div_round_up(n, 256), meta.n_levels), dim3(256), 0, stream, dev_meta, n, (const unsigned long long*)mask, (unsigned long long*)bits);
+}
+
+void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems) {
+	const uint32_t F = meta.n_features_per_level;
+	const uint32_t corners = meta.interpolation == (uint32_t)InterpolationType::Nearest ? 1u : (1u << meta.n_pos_dims);
+	tasks.clear();
+	shared_ranges.clear();
+	scratch_elems = 0;
+
+	// profiling aid: TCNN_AMD_SCATTER_LEVELS="lo,hi" restricts the plan to levels lo..hi (results are then incomplete!)
+	uint32_t dbg_lo = 0, dbg_hi = meta.n_levels;
+	if (const char* e = getenv("TCNN_AMD_SCATTER_LEVELS")) sscanf(e, "%u,%u", &dbg_lo, &dbg_hi);
+
+	std::vector<std::vector<GridScatterTask>> per_level(meta.n_levels);
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		if (l < dbg_lo || l > dbg_hi) continue;
+		const GridLevel& lv = meta.levels[l];
+		const uint32_t n_chunks = lv.scatter_n_chunks;
+		const uint32_t per_chunk = lv.scatter_per_chunk;
+		// corner events landing in one chunk; beyond ~64k the adds dominate: split the samples over several workgroups
+		const uint64_t events = (uint64_t)n * corners / n_chunks;
+		uint32_t splits = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(events / 65536, 1), 32);
+		splits = std::min(splits, std::max(n / 1024u, 1u));
+		const uint32_t samples_per_split = next_multiple(div_round_up(n, splits), 64u);
+		for (uint32_t c = 0; c < n_chunks; ++c) {
+			const uint32_t begin = c * per_chunk;
+			if (begin >= lv.size) break;
+			const uint32_t cnt = std::min(per_chunk, lv.size - begin);
+			const bool shared = splits > 1;
+			uint32_t scratch_begin = 0;
+			if (shared) {
+				scratch_begin = (uint32_t)scratch_elems;
+				const size_t grad_begin = ((size_t)lv.offset + begin) * F;
+				if (!shared_ranges.empty() && shared_ranges.back().grad_begin + shared_ranges.back().n_elems == grad_begin &&
+				    shared_ranges.back().scratch_begin + shared_ranges.back().n_elems == scratch_begin) {
+					shared_ranges.back().n_elems += cnt * F;
+				} else {
+					shared_ranges.push_back(GridScatterRange{grad_begin, cnt * F, scratch_begin, 0});
+				}
+				scratch_elems += (size_t)cnt * F;
+			}
+			for (uint32_t s = 0; s < splits; ++s) {
+				const uint32_t sb = s * samples_per_split;
+				if (sb >= n) break;
+				per_level[l].push_back(GridScatterTask{l, begin, cnt, sb, std::min(n, sb + samples_per_split), shared ? 1u : 0u, scratch_begin, 0});
+			}
+		}
+	}
+
+	// Speed-only placement: blocks b and b + 8 usually share an XCD (MI355X_MICROARCH.md "Workgroup dispatch"), so give all
+	// tasks of a level the same residue mod 8 -- its coordinates, bit planes and gradient plane then stay in that XCD's L2.
+	std::vector<uint32_t> order(meta.n_levels);
+	for (uint32_t l = 0; l < meta.n_levels; ++l) order[l] = l;
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return per_level[a].size() > per_level[b].size(); });
+	std::vector<std::vector<GridScatterTask>> bins(8);
+	for (uint32_t l : order) {
+		size_t best = 0;
+		for (size_t b = 1; b < 8; ++b) if (bins[b].size() < bins[best].size()) best = b;
+		bins[best].insert(bins[best].end(), per_level[l].begin(), per_level[l].end());
+	}
+	size_t longest = 0;
+	for (const auto& b : bins) longest = std::max(longest, b.size());
+	for (size_t j = 0; j < longest; ++j) {
+		for (size_t b = 0; b < 8; ++b) {
+			if (j < bins[b].size()) tasks.push_back(bins[b][j]);
+			else tasks.push_back(GridScatterTask{0, 0, 0, 0, 0, 0, 0, 0});
+		}
+	}
+	while (!tasks.empty() && tasks.back().n_entries == 0) tasks.pop_back();
+}
+
+void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
+                       const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
+                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate) {
+	if (n_tasks == 0) return;
+	const unsigned long long* bits = (const unsigned long long*)chunk_bits;
+	unsigned long long* sc = (unsigned long long*)scratch;
+	switch (meta.n_pos_dims) {
+		case 2: dispatch_scatter<2>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate); break;
+		case 3: dispatch_scatter<3>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate); break;
+		case 4: dispatch_scatter<4>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate); break;
+		default: throw std::runtime_error{"GridEncoding: number of input dims must be 2 or 3."};
+	}
+	if (n_ranges > 0) {
+		hipLaunchKernelGGL(k_grid_scatter_finalize, dim3(32, n_ranges), dim3(256), 0, stream, dev_ranges, sc, (half_t*)grad, accumulate ? 1 : 0);
+	}
+}
+
+} // namespace tcnn_amd

@@ -265,10 +265,28 @@ struct BwdArgs {
 	const half_t* out;     // [n][out_width]   (only read when output_activation != None)
 	const half_t* hidden;  // [n_hidden][n][width]
 	half_t* dhidden;       // [n_hidden][n][width]
-	half_t* dL_dx;         // optional [n][in_width]
+	half_t* dL_dx;         // optional [n][in_width], or level planes [in_width / F][n][F] when dx_plane_f = F > 0
 	const h8* image;       // backward fragments
 	uint32_t n;
+	uint32_t dx_plane_f;
 };
+
+// Store 4 consecutive input-gradient features k0..k0+3 of sample s.  AoS: one 8-byte store.  Level planes (what the grid
+// scatter reads with unit stride): feature k lives at ((k / F) * n + s) * F + k % F.
+__device__ inline void store_dx(half_t* base, uint32_t plane_f, uint32_t n, uint32_t in_w, uint32_t s, uint32_t k0, h4 v) {
+	typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+	if (plane_f == 0) {
+		*(h4*)(base + (size_t)s * in_w + k0) = v;
+	} else if (plane_f == 2) {
+		*(h2*)(base + ((size_t)(k0 / 2) * n + s) * 2) = h2{v[0], v[1]};
+		*(h2*)(base + ((size_t)(k0 / 2 + 1) * n + s) * 2) = h2{v[2], v[3]};
+	} else if (plane_f >= 4) {
+		*(h4*)(base + ((size_t)(k0 / plane_f) * n + s) * plane_f + (k0 % plane_f)) = v;
+	} else {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) base[(size_t)(k0 + r) * n + s] = v[r];
+	}
+}
 
 template <int W, int NB, int ACT>
 __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs a) {
@@ -385,7 +403,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					const h4 v = h4{(half_t)o[b][0], (half_t)o[b][1], (half_t)o[b][2], (half_t)o[b][3]};
-					*(h4*)(a.dL_dx + (size_t)(s0 + 16 * b + c) * in_w + 16 * ti + 4 * q) = v;
+					store_dx(a.dL_dx, a.dx_plane_f, a.n, in_w, s0 + 16 * b + c, 16 * ti + 4 * q, v);
 				}
 			}
 		}
@@ -485,8 +503,15 @@ __global__ void __launch_bounds__(256) k_wgrad(
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const uint32_t n_elems, const uint32_t cols, const uint32_t ldg, const uint32_t n_slabs, const float* __restrict__ slabs, half_t* __restrict__ grad, const int accumulate) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_elems) return;
-	float s = 0.0f;
-	for (uint32_t k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * n_elems + i];
+	// 8 independent partial sums keep 8 loads in flight (fixed association -> still bitwise reproducible)
+	float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t k = 0;
+	for (; k + 8 <= n_slabs; k += 8) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) p[u] += slabs[(size_t)(k + u) * n_elems + i];
+	}
+	for (; k < n_slabs; ++k) p[0] += slabs[(size_t)k * n_elems + i];
+	float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
 	const uint32_t row = i / cols, col = i - row * cols;
 	half_t* g = grad + (size_t)row * ldg + col;
 	if (accumulate) s += (float)*g;
@@ -553,12 +578,13 @@ void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32
 	}
 }
 
-void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* dL_dout, const void* out, const void* hidden, void* dhidden, void* dL_dx) {
+void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* dL_dout, const void* out, const void* hidden, void* dhidden, void* dL_dx,
+                  uint32_t dx_plane_features) {
 	CHECK_THROW(n % BATCH_SIZE_GRANULARITY == 0);
 	CHECK_THROW(d.n_hidden >= 1);
 	if (n == 0) return;
 	BwdArgs a{(const half_t*)dL_dout, (const half_t*)out, (const half_t*)hidden, (half_t*)dhidden, (half_t*)dL_dx,
-	          (const h8*)((const char*)image + (size_t)d.n_frags_fwd * 1024), n};
+	          (const h8*)((const char*)image + (size_t)d.n_frags_fwd * 1024), n, dx_plane_features};
 	switch (d.width) {
 		case 16: return launch_bwd_act<16, nb_for_width(16)>(stream, d, a, mlp_grid(n, nb_for_width(16)));
 		case 32: return launch_bwd_act<32, nb_for_width(32)>(stream, d, a, mlp_grid(n, nb_for_width(32)));

@@ -202,7 +202,9 @@ struct Pcg32 {
 // Encodings
 // ------------------------------------------------------------------------------------------------------------------
 struct EncodingContext {
-	ArenaBuf dy_dx; // grid only: float [n][L*F][D]
+	ArenaBuf dy_dx;       // grid only: float [n][L*F][D]
+	ArenaBuf chunk_mask;  // grid only: uint64 [L][32][n/64] bit planes, which samples touch which scatter chunk (filter for the LDS scatter)
+	uint32_t n = 0;
 };
 
 class Encoding {
@@ -219,9 +221,13 @@ public:
 	virtual size_t n_params() const { return 0; }
 	virtual void initialize_params(Pcg32& rng, float* params_full_precision, float scale) {}
 	// out: [n][padded_output_width] T (T = float if fp32 else half)
-	virtual EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients) = 0;
+	// prepare_param_gradients: a backward pass with parameter gradients will follow (lets the grid record its scatter filter)
+	virtual EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) = 0;
 	// dL_dy [n][padded] T; grads: T[n_params] or nullptr (Ignore)
-	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) = 0;
+	// dy_planes: dL_dy is laid out as level planes [padded / F][n][F] (only if level_plane_features() allowed it), else AoS
+	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) = 0;
+	// > 0: this encoding's backward prefers dL_dy in level planes with that many features per plane (see k_grid_bwd_lds)
+	virtual uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const { return 0; }
 	virtual Json hyperparams() const = 0;
 	bool fp32() const { return m_fp32; }
 protected:
@@ -323,6 +329,10 @@ public:
 		}
 		m_n_entries = offset;
 		m_n_params = (size_t)offset * F;
+		if (F >= 2) {
+			grid_scatter_setup_levels(m_meta);
+			for (uint32_t i = 0; i < n_levels; ++i) m_scatter_mask_ok &= m_meta.levels[i].scatter_n_chunks <= grid_scatter_max_chunks(); // the filter is a uint64 per (level, sample)
+		}
 	}
 
 	// device copy of the level table, uploaded on first use (construction itself never touches the GPU)
@@ -351,15 +361,23 @@ public:
 		generate_random_uniform(nullptr, rng.st, n_params(), params_full_precision, -1e-4f * scale, 1e-4f * scale);
 	}
 
-	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients) override {
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
 		EncodingContext ctx;
 		if ((!out && !prepare_input_gradients) || padded_output_width() == 0 || n == 0) return ctx;
 		if (prepare_input_gradients) ctx.dy_dx = ArenaBuf{stream, (size_t)n * m_n_features * m_meta.n_pos_dims * sizeof(float)};
-		grid_forward(stream, m_meta, dev_meta(), m_fp32, n, x, params, out, padded_output_width(), ctx.dy_dx.as<float>());
+		const bool want_filter = prepare_param_gradients && lds_scatter_usable() && n % 64 == 0;
+		ArenaBuf mask;
+		if (want_filter) mask = ArenaBuf{stream, (size_t)m_meta.n_levels * n * sizeof(uint64_t)};
+		grid_forward(stream, m_meta, dev_meta(), m_fp32, n, x, params, out, padded_output_width(), ctx.dy_dx.as<float>(), mask.as<uint64_t>());
+		if (want_filter) {
+			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_scatter_max_chunks() * (n / 64) * sizeof(uint64_t)};
+			ctx.n = n;
+			grid_mask_to_bits(stream, m_meta, dev_meta(), n, mask.as<uint64_t>(), ctx.chunk_mask.as<uint64_t>());
+		}
 		return ctx;
 	}
 
-	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) override {
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
 		if ((!dL_dx && mode == GradientMode::Ignore) || n == 0) return;
 		const size_t elem = m_fp32 ? 4 : 2;
 		if (mode != GradientMode::Ignore) {
@@ -371,15 +389,65 @@ public:
 				else cast_half_to_float(stream, n_params(), grads, tmp.as<float>());
 				grid_backward(stream, m_meta, dev_meta(), true, n, x, dL_dy, false, padded_output_width(), tmp.data());
 				cast_float_to_half(stream, n_params(), tmp.as<float>(), grads);
+			} else if (lds_scatter_usable() && n % 64 == 0) {
+				// MI355X path: LDS owner-computes scatter with exact integer accumulation; writes every element (k_grid_scatter.hip)
+				ScatterPlan& plan = scatter_plan(n);
+				const uint32_t F = m_meta.n_features_per_level;
+				const uint64_t* mask = (ctx.chunk_mask && ctx.n == n) ? ctx.chunk_mask.as<uint64_t>() : nullptr;
+				grid_backward_lds(stream, m_meta, dev_meta(), plan.dev_tasks.as<GridScatterTask>(), plan.n_tasks, plan.dev_ranges.as<GridScatterRange>(), plan.n_ranges,
+				                  plan.scratch.as<uint64_t>(), n, x, dL_dy, dy_planes ? F : padded_output_width(), dy_planes ? n * F : F, grads, mask,
+				                  mode == GradientMode::Accumulate);
 			} else {
+				CHECK_THROW(!dy_planes);
 				if (mode == GradientMode::Overwrite) HIP_CHECK_THROW(hipMemsetAsync(grads, 0, n_params() * elem, stream)); // grid.h:858
 				grid_backward(stream, m_meta, dev_meta(), m_fp32, n, x, dL_dy, m_fp32, padded_output_width(), grads);
 			}
 		}
 		if (dL_dx) {
 			CHECK_THROW(ctx.dy_dx);
+			CHECK_THROW(!dy_planes);
 			grid_backward_input(stream, m_meta, m_fp32, n, dL_dy, padded_output_width(), ctx.dy_dx.as<float>(), *dL_dx);
 		}
+	}
+
+	uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const override {
+		const uint32_t F = m_meta.n_features_per_level;
+		return (lds_scatter_usable() && !need_dL_dx && mode != GradientMode::Ignore) ? F : 0;
+	}
+
+	// half precision, F >= 2, and every level's table cut into at most 64 chunks (the sample filter is a uint64)
+	bool lds_scatter_usable() const { return !m_fp32 && m_meta.n_features_per_level >= 2 && use_lds_scatter() && m_scatter_mask_ok; }
+
+	// TCNN_AMD_GRID_SCATTER=atomic selects the reference-shaped global-atomic kernel (kept for A/B runs and as the fp32 / F==1 path)
+	static bool use_lds_scatter() {
+		static const bool v = [] {
+			const char* e = getenv("TCNN_AMD_GRID_SCATTER");
+			return !(e && std::string{e} == "atomic");
+		}();
+		return v;
+	}
+
+	struct ScatterPlan {
+		DeviceBuf dev_tasks, dev_ranges, scratch;
+		uint32_t n_tasks = 0, n_ranges = 0;
+	};
+	ScatterPlan& scatter_plan(uint32_t n) {
+		auto it = m_scatter_plans.find(n);
+		if (it != m_scatter_plans.end()) return *it->second;
+		auto plan = std::make_unique<ScatterPlan>();
+		std::vector<GridScatterTask> tasks;
+		std::vector<GridScatterRange> ranges;
+		size_t scratch_elems = 0;
+		grid_scatter_plan(m_meta, n, tasks, ranges, scratch_elems);
+		plan->n_tasks = (uint32_t)tasks.size();
+		plan->n_ranges = (uint32_t)ranges.size();
+		plan->dev_tasks.resize(tasks.size() * sizeof(GridScatterTask));
+		if (!tasks.empty()) HIP_CHECK_THROW(hipMemcpy(plan->dev_tasks.data(), tasks.data(), tasks.size() * sizeof(GridScatterTask), hipMemcpyHostToDevice));
+		plan->dev_ranges.resize(ranges.size() * sizeof(GridScatterRange));
+		if (!ranges.empty()) HIP_CHECK_THROW(hipMemcpy(plan->dev_ranges.data(), ranges.data(), ranges.size() * sizeof(GridScatterRange), hipMemcpyHostToDevice));
+		plan->scratch.resize(scratch_elems * sizeof(uint64_t));
+		plan->scratch.memset(0); // the finalize pass leaves it zeroed again after every step
+		return *(m_scatter_plans[n] = std::move(plan));
 	}
 
 	Json hyperparams() const override { // grid.h:1098-1115
@@ -402,6 +470,8 @@ public:
 private:
 	GridMeta m_meta;
 	DeviceBuf m_dev_meta;
+	std::map<uint32_t, std::unique_ptr<ScatterPlan>> m_scatter_plans;
+	bool m_scatter_mask_ok = true;
 	std::vector<uint32_t> m_resolutions;
 	uint32_t m_n_features, m_log2_hashmap_size, m_base_resolution, m_n_entries;
 	float m_per_level_scale;
@@ -416,11 +486,11 @@ public:
 	}
 	uint32_t input_width() const override { return m_n_dims; }
 	uint32_t output_width() const override { return m_n_dims * m_n_bins; }
-	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients) override {
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
 		if (out && padded_output_width() > 0) oneblob_forward(stream, m_fp32, n, m_n_dims, m_n_bins, x, out, padded_output_width());
 		return {};
 	}
-	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) override {
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
 		if (!dL_dx) return;
 		oneblob_backward_input(stream, m_fp32, n, m_n_dims, m_n_bins, x, dL_dy, padded_output_width(), *dL_dx);
 	}
@@ -439,11 +509,11 @@ public:
 	IdentityEncoding(uint32_t n_dims_to_encode, float scale, float offset, bool fp32) : Encoding{fp32}, m_n_dims{n_dims_to_encode}, m_scale{scale}, m_offset{offset} {}
 	uint32_t input_width() const override { return m_n_dims; }
 	uint32_t output_width() const override { return m_n_dims; }
-	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients) override {
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
 		if (out && padded_output_width() > 0) identity_forward(stream, m_fp32, n, m_n_dims, m_scale, m_offset, x, out, padded_output_width());
 		return {};
 	}
-	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) override {
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
 		if (!dL_dx) return;
 		identity_backward_input(stream, m_fp32, n, m_n_dims, m_scale, dL_dy, padded_output_width(), *dL_dx);
 	}
@@ -597,7 +667,7 @@ public:
 
 	// dL_dinput: optional half [n][in_width]; gradients: half[n_params] or nullptr
 	void backward(hipStream_t stream, const NetworkContext& ctx, uint32_t n, const void* input, const void* output, const void* dL_doutput,
-	              void* dL_dinput, const void* params, void* gradients, GradientMode mode) const {
+	              void* dL_dinput, const void* params, void* gradients, GradientMode mode, uint32_t dx_plane_features = 0) const {
 		ArenaBuf image = prepare(stream, params, true);
 		ArenaBuf dhidden{stream, (size_t)m_n_hidden * n * m_width * 2};
 		// output-activation transfer, computed once up front like the reference (fully_fused_mlp.cu:757-762)
@@ -610,7 +680,7 @@ public:
 			dY = dY_tmp.data();
 			desc.output_activation = (uint32_t)Activation::None;
 		}
-		mlp_backward(stream, desc, image.data(), n, dY, output, ctx.hidden.data(), dhidden.data(), dL_dinput);
+		mlp_backward(stream, desc, image.data(), n, dY, output, ctx.hidden.data(), dhidden.data(), dL_dinput, dx_plane_features);
 		if (mode == GradientMode::Ignore) return;
 		CHECK_THROW(gradients != nullptr);
 
@@ -713,7 +783,7 @@ public:
 		if (n == 0) return;
 		const _Float16* p = (const _Float16*)params;
 		ArenaBuf network_input{stream, (size_t)n * m_encoding->padded_output_width() * 2};
-		m_encoding->forward(stream, n, input, p + m_network->n_params(), network_input.data(), false);
+		m_encoding->forward(stream, n, input, p + m_network->n_params(), network_input.data(), false, false);
 		m_network->inference(stream, n, network_input.data(), output, p);
 	}
 
@@ -729,7 +799,7 @@ public:
 		if (n == 0) return ctx;
 		const _Float16* p = (const _Float16*)params;
 		ctx->network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
-		ctx->encoding_ctx = m_encoding->forward(stream, n, input, p + m_network->n_params(), ctx->network_input.data(), prepare_input_gradients);
+		ctx->encoding_ctx = m_encoding->forward(stream, n, input, p + m_network->n_params(), ctx->network_input.data(), prepare_input_gradients, true);
 		ctx->network_ctx = m_network->forward(stream, n, ctx->network_input.data(), output, p);
 		return ctx;
 	}
@@ -745,10 +815,12 @@ public:
 		if (m_encoding->n_params() > 0 || dL_dinput) { // :93-96
 			dL_dnetwork_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
 		}
-		m_network->backward(stream, ctx.network_ctx, n, ctx.network_input.data(), output, dL_doutput, dL_dnetwork_input.data(), p, g, mode);
+		// the grid scatter reads dL/d(encoding) with unit stride when the MLP writes it as level planes
+		const uint32_t plane_f = dL_dnetwork_input ? m_encoding->level_plane_features(dL_dinput != nullptr, mode) : 0;
+		m_network->backward(stream, ctx.network_ctx, n, ctx.network_input.data(), output, dL_doutput, dL_dnetwork_input.data(), p, g, mode, plane_f);
 		if (dL_dnetwork_input) {
 			m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + m_network->n_params(),
-			                     g ? g + m_network->n_params() : nullptr, mode);
+			                     g ? g + m_network->n_params() : nullptr, mode, plane_f > 0);
 		}
 	}
 
@@ -784,19 +856,19 @@ public:
 	};
 	void inference(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params) override {
 		check_batch(n);
-		m_encoding->forward(stream, n, input, params, output, false);
+		m_encoding->forward(stream, n, input, params, output, false, false);
 	}
 	std::unique_ptr<ModelContext> forward(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params, bool prepare_input_gradients) override {
 		check_batch(n);
 		auto ctx = std::make_unique<Ctx>();
-		ctx->encoding_ctx = m_encoding->forward(stream, n, input, params, output, prepare_input_gradients);
+		ctx->encoding_ctx = m_encoding->forward(stream, n, input, params, output, prepare_input_gradients, true);
 		return ctx;
 	}
 	void backward(hipStream_t stream, const ModelContext& mctx, uint32_t n, MatView input, const void* output, const void* dL_doutput,
 	              MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) override {
 		check_batch(n);
 		const Ctx& ctx = dynamic_cast<const Ctx&>(mctx);
-		m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_doutput, dL_dinput, params, gradients, mode);
+		m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_doutput, dL_dinput, params, gradients, mode, false);
 	}
 	Json hyperparams() const override { return m_encoding->hyperparams(); }
 private:

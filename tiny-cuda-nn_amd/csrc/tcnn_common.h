@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace tcnn_amd {
 
@@ -47,7 +48,10 @@ struct GridLevel {
 	uint32_t hashed;      // 1: index = hash(cell) ; 0: index = sum cell_d * stride[d]   (common_device.h:690-707)
 	uint32_t stride[4];   // per-dim stride of the dense index INCLUDING the uint32 wrap-around / early-exit behaviour
 	uint32_t size_mask;   // size-1 if size is a power of two, else 0 (then a real modulo is used)
-	uint32_t pad[3];
+	// LDS owner-computes scatter (k_grid_bwd_lds): the level's table is cut into scatter_n_chunks chunks of scatter_per_chunk entries
+	uint32_t scatter_per_chunk;
+	uint32_t scatter_shift;    // log2(scatter_per_chunk) if it is a power of two, else 0xffffffff
+	uint32_t scatter_n_chunks;
 };
 
 struct GridMeta {
@@ -74,9 +78,36 @@ struct MatViewMut {
 };
 
 // half data travels as void* on the host side
-void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx);
-// grad: T[n_params] accumulated in place (caller zeroes it).  For F == 1 && !fp32 the caller passes an fp32 scratch as `grad` with grad_is_fp32_scratch = true.
+// chunk_mask (optional, uint64 [n_levels][n]): bit c set <=> the sample touches scatter chunk c of that level (filter for k_grid_scatter)
+void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx,
+                  uint64_t* chunk_mask);
+// reference-shaped gradient scatter with global float atomics (fp32 grids, F == 1, tables too large for the LDS scheme).
+// grad: T[n_params] accumulated in place (caller zeroes it).  For F == 1 && !fp32 the caller passes an fp32 scratch as `grad`.
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32_grad, uint32_t n, MatView x, const void* dL_dy, bool dy_fp32, uint32_t dy_stride, void* grad);
+
+// ---- LDS owner-computes scatter (k_grid_scatter.hip): exact 64-bit fixed-point accumulation, one task per workgroup
+struct GridScatterTask {
+	uint32_t level;
+	uint32_t entry_begin, n_entries;      // owned chunk of the level's table (n_entries == 0: padding task)
+	uint32_t sample_begin, sample_end;    // samples examined by this task
+	uint32_t flush_atomic;                // 1: several tasks share the chunk -> merge into the scratch table, finalize rounds
+	uint32_t scratch_begin;               // first element of the chunk inside the scratch table (shared chunks only)
+	uint32_t pad;
+};
+struct GridScatterRange { size_t grad_begin; uint32_t n_elems; uint32_t scratch_begin; uint32_t pad; }; // shared chunks, for the finalize pass
+uint32_t grid_scatter_max_chunks();                 // chunks per level the sample filter can describe (64)
+void grid_scatter_setup_levels(GridMeta& meta);     // fills GridLevel::scatter_* (how each level's table is cut into chunks)
+// Plans the task list for a batch of n samples (half gradients, F >= 2).
+void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems);
+// chunk_mask [n_levels][n] uint64 -> chunk_bits [n_levels][64][n / 64] uint64 (one ballot word per 64 samples per (level, chunk))
+void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, const uint64_t* chunk_mask, uint64_t* chunk_bits);
+// dL_dy element (sample i, level l, feature f) at dL_dy[i * dy_stride_sample + l * dy_stride_level + f].
+// chunk_bits: optional filter derived from grid_forward's masks for the SAME batch (n samples); nullptr -> every sample is examined in full.
+// scratch: uint64[scratch_elems], zero on entry, zero again on return.  Writes EVERY gradient element (no memset needed);
+// accumulate = GradientMode::Accumulate.
+void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
+                       const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
+                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate);
 void grid_backward_input(hipStream_t stream, const GridMeta& meta, bool fp32, uint32_t n, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
 
 // OneBlob / Identity (AoS output, T = half or float)
@@ -112,7 +143,9 @@ void mlp_prepare_weights(hipStream_t stream, const MlpDesc& d, const void* param
 // x: [n][in_width] half AoS; out: [n][out_width] half; hidden (optional): [n_hidden][n][width] half post-activation
 void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, void* out, void* hidden);
 // Reference-shaped backward: dL_dout [n][out_width]; hidden from mlp_forward; writes dhidden [n_hidden][n][width] and (optional) dL_dx [n][in_width]
-void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* dL_dout, const void* out, const void* hidden, void* dhidden, void* dL_dx);
+// dx_plane_features = 0: dL_dx is AoS [n][in_width]; = F > 0: "level planes" [in_width / F][n][F] (what the grid scatter reads)
+void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* dL_dout, const void* out, const void* hidden, void* dhidden, void* dL_dx,
+                  uint32_t dx_plane_features);
 // fully_fused_mlp.cu:757-762: result = dL_dout * act'(out), elementwise over n_elems halfs
 void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32_t activation, const void* dL_dout, const void* out, void* result);
 // dW[rows x cols] = sum_i dO[i][rows]^T In[i][cols]; result written as half into grad (overwrite or accumulate). workspace: float[wgrad_workspace_floats()]
