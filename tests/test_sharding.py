@@ -1,0 +1,95 @@
+"""CPU tests of the multi-GPU inference path (BASELINE config 4): contiguous row shards, one all-gather.
+world_size 2 over gloo; the per-rank "network" is a deterministic row-wise function standing in for network->inference()
+so that the test checks exactly what this layer owns -- the partition and the exchange."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
+
+
+def _parallel():
+    # tinycudann/__init__ needs the built library; parallel.py itself is pure torch
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("tcnn_parallel", os.path.join(ROOT, "tiny-cuda-nn_amd", "tinycudann", "parallel.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("n,world", [(0, 1), (256, 1), (1000, 2), (256, 2), (4096, 8), (1 << 21, 8), (300, 8), (257, 3)])
+def test_shard_rows_tiles_the_batch(n, world):
+    par = _parallel()
+    prev = 0
+    sizes = []
+    for r in range(world):
+        b, e = par.shard_rows(n, world, r)
+        assert b == prev and e >= b
+        if e < n:
+            assert (e - b) % 256 == 0          # every shard but the last non-empty one keeps the batch granularity
+        sizes.append(e - b)
+        prev = e
+    assert prev == n
+    full = [s for s in sizes if s]
+    assert max(sizes) - min(full or [0]) <= 256 or n < 256 * world
+    with pytest.raises(ValueError):
+        par.shard_rows(n, world, world)
+
+
+def _row_fn(x):
+    # rows are independent, like inference: out[i] depends on x[i] only
+    return torch.stack([x.sum(1), (x * x).sum(1), x[:, 0] - x[:, -1]], dim=1)
+
+
+def _worker(rank, world, port, n, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = _parallel()
+        g = torch.Generator().manual_seed(1234)
+        x = torch.rand((n, 4), generator=g)
+        calls = []
+
+        def infer(rows):
+            calls.append(rows.shape[0])
+            return _row_fn(rows)
+
+        out = par.sharded_inference(infer, x, 3)
+        want = _row_fn(x)
+        b, e = par.shard_rows(n, world, rank)
+        ok = bool(torch.equal(out, want)) and calls == ([e - b] if e > b else [])
+        results[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n", [1000, 256, 5 * 256 + 17])
+def test_sharded_inference_gloo_world2(n):
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, results), nprocs=world, join=True)
+    assert dict(results) == {0: True, 1: True}
+
+
+def test_single_process_is_plain_inference():
+    par = _parallel()
+    x = torch.rand((512, 4))
+    assert torch.equal(par.sharded_inference(_row_fn, x, 3), _row_fn(x))

@@ -20,69 +20,10 @@
 //       k(s, q, j) = 32 s + 16 (j >> 2) + 4 q + (j & 3)
 //   (elements 0..3 come from accumulator tile 2s, elements 4..7 from tile 2s+1.)
 //   Layer 0 reads its B operand from memory ([n][in] half, 16 bytes per lane) in natural order k = 32 s + 8 q + j.
-#include "tcnn_common.h"
-
-#include <hip/hip_fp16.h>
+#include "mlp_device.h"
 
 namespace tcnn_amd {
 namespace {
-
-typedef _Float16 half_t;
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-constexpr float K_ACT = 10.0f;
-
-__device__ inline float logistic(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// common_device.h:102-160, applied to the fp16-rounded accumulator like the reference's warp_activation
-__device__ inline half_t activation_fwd(uint32_t act, half_t pre) {
-	const float x = (float)pre;
-	switch (act) {
-		case (uint32_t)Activation::ReLU: return x > 0.0f ? pre : (half_t)0.0f;
-		case (uint32_t)Activation::LeakyReLU: return pre * (half_t)(x > 0.0f ? 1.0f : 0.01f);
-		case (uint32_t)Activation::Exponential: return (half_t)expf(x);
-		case (uint32_t)Activation::Sine: return (half_t)sinf(x);
-		case (uint32_t)Activation::Sigmoid: return (half_t)logistic(x);
-		case (uint32_t)Activation::Squareplus: { const float y = x * K_ACT; return (half_t)(0.5f * (y + sqrtf(y * y + 4)) / K_ACT); }
-		case (uint32_t)Activation::Softplus: return (half_t)(logf(expf(x * K_ACT) + 1.0f) / K_ACT);
-		case (uint32_t)Activation::Tanh: return (half_t)tanhf(x);
-		default: return pre;
-	}
-}
-
-// common_device.h:241-297: derivative from the forward OUTPUT
-__device__ inline half_t activation_bwd(uint32_t act, half_t grad, half_t fwd) {
-	const float y = (float)fwd;
-	switch (act) {
-		case (uint32_t)Activation::ReLU: return y > 0.0f ? grad : grad * (half_t)0.0f;
-		case (uint32_t)Activation::LeakyReLU: return grad * (half_t)(y > 0.0f ? 1.0f : 0.01f);
-		case (uint32_t)Activation::Exponential: return grad * fwd;
-		case (uint32_t)Activation::Sigmoid: return grad * (half_t)(fwd * (half_t)(1.0f - y));
-		case (uint32_t)Activation::Squareplus: { const float t = y * K_ACT; return grad * (half_t)(t * t / (t * t + 1)); }
-		case (uint32_t)Activation::Softplus: return grad * (half_t)(1.0f - expf(-y * K_ACT));
-		case (uint32_t)Activation::Tanh: return grad * (half_t)(1.0f - (y * y));
-		default: return grad; // None; Sine is unsupported from outputs (common_device.h:261-265)
-	}
-}
-
-template <int ACT> __device__ inline half_t act_fwd_t(uint32_t act, half_t v) {
-	if constexpr (ACT == (int)Activation::ReLU) return v > (half_t)0.0f ? v : (half_t)0.0f;
-	else if constexpr (ACT == (int)Activation::None) return v;
-	else return activation_fwd(act, v);
-}
-template <int ACT> __device__ inline half_t act_bwd_t(uint32_t act, half_t g, half_t fwd) {
-	if constexpr (ACT == (int)Activation::ReLU) return fwd > (half_t)0.0f ? g : g * (half_t)0.0f;
-	else if constexpr (ACT == (int)Activation::None) return g;
-	else return activation_bwd(act, g, fwd);
-}
-
-__device__ inline f4 mfma(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-
-// k index of element j of a chained-layer fragment
-__host__ __device__ inline uint32_t k_chain(uint32_t s, uint32_t q, uint32_t j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
-__host__ __device__ inline uint32_t k_natural(uint32_t s, uint32_t q, uint32_t j) { return 32 * s + 8 * q + j; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // weights (row-major half) -> fragment images.  One thread per image element.
@@ -271,23 +212,6 @@ struct BwdArgs {
 	uint32_t dx_plane_f;
 };
 
-// Store 4 consecutive input-gradient features k0..k0+3 of sample s.  AoS: one 8-byte store.  Level planes (what the grid
-// scatter reads with unit stride): feature k lives at ((k / F) * n + s) * F + k % F.
-__device__ inline void store_dx(half_t* base, uint32_t plane_f, uint32_t n, uint32_t in_w, uint32_t s, uint32_t k0, h4 v) {
-	typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-	if (plane_f == 0) {
-		*(h4*)(base + (size_t)s * in_w + k0) = v;
-	} else if (plane_f == 2) {
-		*(h2*)(base + ((size_t)(k0 / 2) * n + s) * 2) = h2{v[0], v[1]};
-		*(h2*)(base + ((size_t)(k0 / 2 + 1) * n + s) * 2) = h2{v[2], v[3]};
-	} else if (plane_f >= 4) {
-		*(h4*)(base + ((size_t)(k0 / plane_f) * n + s) * plane_f + (k0 % plane_f)) = v;
-	} else {
-#pragma unroll
-		for (int r = 0; r < 4; ++r) base[(size_t)(k0 + r) * n + s] = v[r];
-	}
-}
-
 template <int W, int NB, int ACT>
 __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs a) {
 	constexpr int T = W / 16;
@@ -420,13 +344,6 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 constexpr int WG_CHUNK = 64;       // samples per staged chunk (2 k-steps)
 constexpr int WG_MAX_TILES = 16;   // accumulator tiles per wave: R*C <= 128*128 with 4 waves
 constexpr int WG_PAD = 8;          // halfs of row padding in LDS (keeps rows 16-byte aligned, breaks the power-of-2 stride)
-
-typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-
-__device__ inline h4 lds_read_tr(const half_t* p) {
-	fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((fp16x4 __attribute__((address_space(3)))*)p);
-	return __builtin_bit_cast(h4, v);
-}
 
 __global__ void __launch_bounds__(256) k_wgrad(
 	const uint32_t n, const half_t* __restrict__ dO, const uint32_t ldo, const uint32_t R,
@@ -597,6 +514,11 @@ void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint3
 void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32_t activation, const void* dL_dout, const void* out, void* result) {
 	if (n_elems == 0) return;
 	hipLaunchKernelGGL(k_act_bwd_output, dim3(div_round_up(n_elems, 256)), dim3(256), 0, stream, n_elems, activation, (const half_t*)dL_dout, (const half_t*)out, (half_t*)result);
+}
+
+void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate) {
+	if (n_params == 0) return;
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_params, 256)), dim3(256), 0, stream, n_params, n_params, n_params, n_slabs, slabs, (half_t*)grad_half, accumulate ? 1 : 0);
 }
 
 size_t wgrad_workspace_floats(uint32_t rows, uint32_t cols, uint32_t n) { return (size_t)wgrad_grid(n) * rows * cols; }

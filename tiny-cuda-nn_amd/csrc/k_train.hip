@@ -1,0 +1,468 @@
+// k_train.hip -- the Trainer's hot path as ONE kernel: MLP forward -> loss -> backward -> weight gradients.
+//
+// Replaces, for trainer->training_step() (reference, /root/reference):
+//   src/fully_fused_mlp.cu:500-557   kernel_mlp_fused (forward, stores every hidden activation to HBM)
+//   include/tiny-cuda-nn/losses/{l2,relative_l2}.h:40-75   loss kernels (read prediction, write values + gradients)
+//   src/fully_fused_mlp.cu:151-259   kernel_mlp_fused_backward (re-reads the activations, stores dL/dhidden to HBM)
+//   src/fully_fused_mlp.cu:785,819,828 + cutlass_matmul.h:438-479   three split-K CUTLASS GEMMs that re-read all of it
+// The reference's decomposition moves ~2 KB of HBM traffic per sample; here activations never leave the CU.
+//
+// Structure (one workgroup = NW waves, S = NW * NB * 16 samples per trip, persistent over the batch):
+//   phase A, per wave, no synchronisation: the register-chained MFMA forward of k_mlp.hip (activations transposed, the
+//     accumulator tile of one layer IS the B operand of the next), the loss on the accumulator tile of the output layer,
+//     and the backward chain with the transposed weight images.  Every activation / gradient tile is also dropped into
+//     LDS as [sample][feature] rows -- the only copy that ever exists.
+//   barrier
+//   phase B, cooperative: dW_l += dOut_l^T In_l over the S samples of the trip.  The MFMA operands need the SAMPLE index
+//     on the k axis, i.e. the transposed view of those LDS rows: gfx950's ds_read_b64_tr_b16 delivers exactly that.
+//     Output tiles are distributed over the waves; their accumulators stay in registers for the whole kernel.
+//   barrier
+//   At the end every workgroup writes one fp32 slab of partial weight gradients; k_wgrad_reduce sums the slabs in a fixed
+//   order (bitwise reproducible, no atomics) and rounds to fp16.
+#include "mlp_device.h"
+
+namespace tcnn_amd {
+namespace {
+
+constexpr int TR_PAD = 8; // halves of row padding of the LDS images (rows stay 16-byte aligned)
+
+struct TrainArgs {
+	const half_t* x;        // [n][in_width] encoded input
+	const float* target;    // [n][dims] (unused with ext_dy)
+	const float* data_pdf;  // optional [n][dims]
+	const half_t* ext_dy;   // optional external dL/doutput [n][out_width] (already loss-scaled)
+	half_t* out;            // [n][out_width]
+	half_t* dL_dout;        // [n][out_width] (written unless ext_dy)
+	float* L;               // [n][out_width] (written unless ext_dy)
+	half_t* dL_dx;          // optional, AoS or level planes
+	float* slabs;           // [gridDim.x][n_params] partial weight gradients (nullptr: no weight gradients)
+	const h8* image;        // forward fragments followed by backward fragments
+	uint32_t n, dims, loss_type;
+	float loss_scale;
+	uint32_t dx_plane_f, n_params;
+	uint32_t image_in_lds;
+};
+
+template <int W, int NB, int NW, int MAXT, int ACT>
+__global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const TrainArgs a) {
+	constexpr int T = W / 16;
+	constexpr int KS = (T + 1) / 2;
+	constexpr int S = NW * NB * 16;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	half_t* lds = (half_t*)smem;
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: everything derived from it stays in SGPRs
+	const uint32_t c = lane & 15, q = lane >> 4;
+	const uint32_t in_w = d.in_width, out_w = d.out_width, nh = d.n_hidden;
+	const uint32_t m_out = out_w / 16; // 1 or 2 output tiles (host guarantees out_width <= 32)
+
+	// LDS images, [S rows][features + pad] halves each
+	const uint32_t xs_stride = in_w + TR_PAD, hs_stride = W + TR_PAD, dys_stride = out_w + TR_PAD;
+	const uint32_t xs_off = 0;
+	const uint32_t hs_off = xs_off + S * xs_stride;           // + l * S * hs_stride
+	const uint32_t dhs_off = hs_off + nh * S * hs_stride;     // + l * S * hs_stride
+	const uint32_t dys_off = dhs_off + nh * S * hs_stride;
+
+	// ---- static assignment of weight-gradient tiles to waves (phase B): wave w owns tiles [first, first + my_tiles) of the
+	// enumeration "layer by layer, row-major".  The tile -> (layer, row tile, col tile) arithmetic is scalar (SALU) work.
+	uint32_t my_tiles = 0, first_tile = 0;
+	if (a.slabs) {
+		uint32_t total = 0;
+		for (uint32_t l = 0; l < d.n_layers; ++l) total += (d.layers[l].rows / 16) * (d.layers[l].cols / 16);
+		const uint32_t per = (total + NW - 1) / NW;
+		first_tile = wave * per;
+		my_tiles = first_tile < total ? min(per, total - first_tile) : 0;
+	}
+	struct TileDesc { uint32_t a, as, b, bs, out, ld; };
+	auto tile_desc = [&](uint32_t id) {
+		uint32_t l = 0;
+		while (l + 1 < d.n_layers && id >= (d.layers[l].rows / 16) * (d.layers[l].cols / 16)) {
+			id -= (d.layers[l].rows / 16) * (d.layers[l].cols / 16);
+			++l;
+		}
+		const uint32_t tc_n = d.layers[l].cols / 16;
+		const uint32_t tr = id / tc_n, tc = id - tr * tc_n;
+		const bool last = l == d.n_layers - 1;
+		TileDesc t;
+		t.a = (last ? dys_off : dhs_off + l * S * hs_stride) + 16 * tr;       // dOut image
+		t.as = last ? dys_stride : hs_stride;
+		t.b = (l == 0 ? xs_off : hs_off + (l - 1) * S * hs_stride) + 16 * tc;  // In image
+		t.bs = l == 0 ? xs_stride : hs_stride;
+		t.out = d.layers[l].w_off + 16 * tr * d.layers[l].cols + 16 * tc;
+		t.ld = d.layers[l].cols;
+		return t;
+	};
+	f4 wacc[MAXT];
+#pragma unroll
+	for (int i = 0; i < MAXT; ++i) wacc[i] = f4{0, 0, 0, 0};
+
+	// weight fragment images: copied into LDS once per workgroup when they fit next to the activation images (a.image_in_lds),
+	// else read from global memory (L2) on every use
+	const h8* image = a.image;
+	if (a.image_in_lds) {
+		h8* dst = (h8*)(lds + dys_off + S * dys_stride);
+		const uint32_t n16 = (d.n_frags_fwd + d.n_frags_bwd) * 64;
+		for (uint32_t i = tid; i < n16; i += NW * 64) dst[i] = a.image[i];
+		image = dst;
+		__syncthreads();
+	}
+	const h8* img_f = image + lane;
+	const h8* img_b = image + (size_t)d.n_frags_fwd * 64 + lane;
+	const uint32_t n_total = a.n * a.dims; // loss normalisation (relative_l2.h:58)
+	const uint32_t n_trips = a.n / S;
+	const uint32_t row0 = wave * NB * 16; // this wave's first row inside the LDS images
+
+	for (uint32_t trip = blockIdx.x; trip < n_trips; trip += gridDim.x) {
+		const uint32_t s0 = trip * S + row0; // first sample of this wave
+
+		// =================================================================== phase A: forward
+		f4 acc[T][NB];
+#pragma unroll
+		for (int t = 0; t < T; ++t)
+#pragma unroll
+			for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+		{
+			const uint32_t ks0 = d.layers[0].ks_fwd;
+			const h8* img = img_f + (size_t)d.layers[0].fwd_off * 64;
+			for (uint32_t s = 0; s < ks0; ++s) {
+				h8 bf[NB];
+				const uint32_t k0 = 32 * s + 8 * q;
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					if (k0 < in_w) {
+						bf[b] = *(const h8*)(a.x + (size_t)(s0 + 16 * b + c) * in_w + k0);
+						*(h8*)(lds + xs_off + (row0 + 16 * b + c) * xs_stride + k0) = bf[b];
+					} else {
+						bf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+					}
+				}
+#pragma unroll
+				for (int t = 0; t < T; ++t) {
+					const h8 af = img[(size_t)(t * ks0 + s) * 64];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, bf[b], acc[t][b]);
+				}
+			}
+		}
+		h8 hf[KS][NB];
+		// activation, pack into the next layer's B fragments, and drop the [sample][feature] rows into LDS
+		auto finish_layer = [&](uint32_t l) {
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					h4 v;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) v[r] = act_fwd_t<ACT>(d.activation, (half_t)acc[t][b][r]);
+					*(h4*)(lds + hs_off + l * S * hs_stride + (row0 + 16 * b + c) * hs_stride + 16 * t + 4 * q) = v;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) hf[t / 2][b][(t & 1) * 4 + r] = v[r];
+				}
+			if constexpr (T & 1) {
+#pragma unroll
+				for (int b = 0; b < NB; ++b)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) hf[KS - 1][b][4 + r] = (half_t)0.0f;
+			}
+		};
+		finish_layer(0);
+		for (uint32_t l = 1; l < nh; ++l) {
+			const h8* img = img_f + (size_t)d.layers[l].fwd_off * 64;
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+#pragma unroll
+				for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+#pragma unroll
+			for (int s = 0; s < KS; ++s) {
+#pragma unroll
+				for (int t = 0; t < T; ++t) {
+					const h8 af = img[(size_t)(t * KS + s) * 64];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
+				}
+			}
+			finish_layer(l);
+		}
+
+		// =================================================================== output layer + loss (on the accumulator tile)
+		h8 dyf[NB]; // dL/d(pre-activation output) as the B fragment of the first backward product (k = output index)
+#pragma unroll
+		for (int b = 0; b < NB; ++b) dyf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+		{
+			const MlpLayer Lo = d.layers[d.n_layers - 1];
+			const h8* img = img_f + (size_t)Lo.fwd_off * 64;
+#pragma unroll
+			for (int to = 0; to < 2; ++to) {
+				if (to < (int)m_out) {
+					f4 o[NB];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) o[b] = f4{0, 0, 0, 0};
+#pragma unroll
+					for (int s = 0; s < KS; ++s) {
+						const h8 af = img[(size_t)(to * KS + s) * 64];
+#pragma unroll
+						for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], o[b]);
+					}
+#pragma unroll
+					for (int b = 0; b < NB; ++b) {
+						const uint32_t sample = s0 + 16 * b + c;
+						const uint32_t j0 = 16 * to + 4 * q; // this lane's 4 output indices
+						h4 ov, gv;
+						float lv[4];
+#pragma unroll
+						for (int r = 0; r < 4; ++r) ov[r] = activation_fwd(d.output_activation, (half_t)o[b][r]);
+						if (a.ext_dy) {
+							gv = *(const h4*)(a.ext_dy + (size_t)sample * out_w + j0);
+						} else {
+#pragma unroll
+							for (int r = 0; r < 4; ++r) { // l2.h:40-74 / relative_l2.h:40-75
+								const uint32_t j = j0 + r;
+								float value = 0.0f;
+								half_t grad = (half_t)0.0f;
+								if (j < a.dims) {
+									const uint32_t target_idx = sample * a.dims + j;
+									const float prediction = (float)ov[r];
+									const float pdf = a.data_pdf ? a.data_pdf[target_idx] : 1;
+									const float difference = prediction - a.target[target_idx];
+									float gradient;
+									if (a.loss_type == (uint32_t)LossType::RelativeL2) {
+										const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
+										value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
+										gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+									} else {
+										value = difference * difference / pdf / n_total;
+										gradient = 2 * difference / pdf;
+									}
+									grad = (half_t)(a.loss_scale * gradient / n_total);
+								}
+								lv[r] = value;
+								gv[r] = grad;
+							}
+							if (a.L) *(f4*)(a.L + (size_t)sample * out_w + j0) = f4{lv[0], lv[1], lv[2], lv[3]};
+							if (a.dL_dout) *(h4*)(a.dL_dout + (size_t)sample * out_w + j0) = gv;
+						}
+						if (a.out) *(h4*)(a.out + (size_t)sample * out_w + j0) = ov;
+						// output-activation transfer (fully_fused_mlp.cu:757-762)
+						if (d.output_activation != (uint32_t)Activation::None) {
+#pragma unroll
+							for (int r = 0; r < 4; ++r) gv[r] = activation_bwd(d.output_activation, gv[r], ov[r]);
+						}
+						*(h4*)(lds + dys_off + (row0 + 16 * b + c) * dys_stride + j0) = gv;
+#pragma unroll
+						for (int r = 0; r < 4; ++r) dyf[b][to * 4 + r] = gv[r];
+					}
+				}
+			}
+		}
+
+		// =================================================================== backward chain
+#pragma unroll
+		for (int t = 0; t < T; ++t)
+#pragma unroll
+			for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+		{
+			const h8* img = img_b + (size_t)d.layers[d.n_layers - 1].bwd_off * 64; // Wout^T: T row tiles, one k-step (out_width <= 32)
+#pragma unroll
+			for (int t = 0; t < T; ++t) {
+				const h8 af = img[(size_t)t * 64];
+#pragma unroll
+				for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, dyf[b], acc[t][b]);
+			}
+		}
+		for (int l = (int)nh - 1; l >= 0; --l) {
+			// acc = W_{l+1}^T dH_{l+1}: multiply by act'(H_l) from the forward output (own rows of the LDS image), keep, pack
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					const uint32_t off = (row0 + 16 * b + c) * hs_stride + 16 * t + 4 * q;
+					const h4 hv = *(const h4*)(lds + hs_off + l * S * hs_stride + off);
+					h4 g;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) g[r] = act_bwd_t<ACT>(d.activation, (half_t)acc[t][b][r], hv[r]);
+					*(h4*)(lds + dhs_off + l * S * hs_stride + off) = g;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) hf[t / 2][b][(t & 1) * 4 + r] = g[r];
+				}
+			if constexpr (T & 1) {
+#pragma unroll
+				for (int b = 0; b < NB; ++b)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) hf[KS - 1][b][4 + r] = (half_t)0.0f;
+			}
+			if (l > 0) {
+				const h8* img = img_b + (size_t)d.layers[l].bwd_off * 64;
+#pragma unroll
+				for (int t = 0; t < T; ++t)
+#pragma unroll
+					for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+#pragma unroll
+				for (int s = 0; s < KS; ++s) {
+#pragma unroll
+					for (int t = 0; t < T; ++t) {
+						const h8 af = img[(size_t)(t * KS + s) * 64];
+#pragma unroll
+						for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
+					}
+				}
+			}
+		}
+		if (a.dL_dx) { // dX = W0^T dH_0
+			const h8* img = img_b + (size_t)d.layers[0].bwd_off * 64;
+			for (uint32_t ti = 0; ti < in_w / 16; ++ti) {
+				f4 o[NB];
+#pragma unroll
+				for (int b = 0; b < NB; ++b) o[b] = f4{0, 0, 0, 0};
+#pragma unroll
+				for (int s = 0; s < KS; ++s) {
+					const h8 af = img[(size_t)(ti * KS + s) * 64];
+#pragma unroll
+					for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], o[b]);
+				}
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					const h4 v = h4{(half_t)o[b][0], (half_t)o[b][1], (half_t)o[b][2], (half_t)o[b][3]};
+					store_dx(a.dL_dx, a.dx_plane_f, a.n, in_w, s0 + 16 * b + c, 16 * ti + 4 * q, v);
+				}
+			}
+		}
+
+		// =================================================================== phase B: weight gradients from the LDS images
+		__syncthreads();
+		if (a.slabs) {
+			const uint32_t grp = lane >> 4, li = lane & 15;
+			const uint32_t row_in_step = 8 * grp + (li >> 2), colo = 4 * (li & 3);
+#pragma unroll
+			for (int i = 0; i < MAXT; ++i) {
+				if (i < (int)my_tiles) { // wave-uniform
+					const TileDesc td = tile_desc(first_tile + i);
+					const half_t* pa = lds + td.a + colo;
+					const half_t* pb = lds + td.b + colo;
+#pragma unroll
+					for (int ks = 0; ks < S / 32; ++ks) {
+						const uint32_t row = 32 * ks + row_in_step;
+						const h4 a_lo = lds_read_tr(pa + row * td.as);
+						const h4 a_hi = lds_read_tr(pa + (row + 4) * td.as);
+						const h4 b_lo = lds_read_tr(pb + row * td.bs);
+						const h4 b_hi = lds_read_tr(pb + (row + 4) * td.bs);
+						const h8 af = h8{a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+						const h8 bf = h8{b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+						wacc[i] = mfma(af, bf, wacc[i]);
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	if (a.slabs) {
+		float* slab = a.slabs + (size_t)blockIdx.x * a.n_params;
+		const uint32_t grp = lane >> 4, li = lane & 15;
+#pragma unroll
+		for (int i = 0; i < MAXT; ++i) {
+			if (i < (int)my_tiles) {
+				const TileDesc td = tile_desc(first_tile + i);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) slab[td.out + (size_t)(4 * grp + r) * td.ld + li] = wacc[i][r];
+			}
+		}
+	}
+}
+
+struct TrainConfig {
+	int nb, nw, maxt;
+	uint32_t lds_bytes, s;
+	bool ok, image_in_lds;
+};
+
+// (NB, NW, MAXT) triples that are instantiated; pick_config only ever returns one of them
+struct TrainVariant { int width_class, nb, nw, maxt; }; // width_class: 64 or 128
+constexpr TrainVariant TRAIN_VARIANTS[] = {
+	{64, 1, 8, 8}, {64, 2, 4, 8}, {64, 2, 4, 16}, {64, 1, 4, 16}, {64, 1, 4, 32},
+	{128, 1, 8, 16}, {128, 1, 8, 32}, {128, 1, 4, 32},
+};
+
+inline TrainConfig pick_config(const MlpDesc& d) {
+	TrainConfig cfg{};
+	cfg.ok = false;
+	if (d.out_width > 32 || d.n_hidden < 1 || (d.width != 64 && d.width != 128)) return cfg;
+	uint32_t total_tiles = 0;
+	for (uint32_t l = 0; l < d.n_layers; ++l) total_tiles += (d.layers[l].rows / 16) * (d.layers[l].cols / 16);
+	const uint32_t image_bytes = (d.n_frags_fwd + d.n_frags_bwd) * 1024;
+	const uint32_t budget = 160 * 1024 - 512;
+	// first choice: a variant whose activation images AND the weight images fit in LDS together; else weights stay in L2
+	for (int pass = 0; pass < 2; ++pass) {
+		for (const TrainVariant& v : TRAIN_VARIANTS) {
+			if (v.width_class != (int)d.width) continue;
+			const uint32_t s = v.nw * v.nb * 16;
+			const uint32_t bytes = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + TR_PAD) + (d.out_width + TR_PAD)) + (pass == 0 ? image_bytes : 0);
+			const uint32_t per = (total_tiles + v.nw - 1) / v.nw;
+			if (bytes > budget || (int)per > v.maxt) continue;
+			cfg.nb = v.nb;
+			cfg.nw = v.nw;
+			cfg.maxt = v.maxt;
+			cfg.s = s;
+			cfg.lds_bytes = bytes;
+			cfg.image_in_lds = pass == 0;
+			cfg.ok = true;
+			return cfg;
+		}
+	}
+	return cfg;
+}
+
+template <int W, int NB, int NW, int MAXT>
+void launch_train(hipStream_t stream, const MlpDesc& d, const TrainArgs& a, uint32_t grid, uint32_t lds_bytes) {
+	auto go = [&](auto kernel) {
+		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(NW * 64), lds_bytes, stream, d, a);
+		HIP_CHECK_THROW(hipGetLastError());
+	};
+	if (d.activation == (uint32_t)Activation::ReLU) go(k_mlp_train<W, NB, NW, MAXT, (int)Activation::ReLU>);
+	else go(k_mlp_train<W, NB, NW, MAXT, -1>);
+}
+
+void dispatch_train(hipStream_t stream, const MlpDesc& d, const TrainArgs& a, const TrainConfig& cfg, uint32_t grid) {
+#define TCNN_TRAIN_CASE(W_, NB_, NW_, MAXT_) \
+	if ((int)d.width == W_ && cfg.nb == NB_ && cfg.nw == NW_ && cfg.maxt == MAXT_) return launch_train<W_, NB_, NW_, MAXT_>(stream, d, a, grid, cfg.lds_bytes);
+	TCNN_TRAIN_CASE(64, 1, 8, 8)
+	TCNN_TRAIN_CASE(64, 2, 4, 8)
+	TCNN_TRAIN_CASE(64, 2, 4, 16)
+	TCNN_TRAIN_CASE(64, 1, 4, 16)
+	TCNN_TRAIN_CASE(64, 1, 4, 32)
+	TCNN_TRAIN_CASE(128, 1, 8, 16)
+	TCNN_TRAIN_CASE(128, 1, 8, 32)
+	TCNN_TRAIN_CASE(128, 1, 4, 32)
+#undef TCNN_TRAIN_CASE
+	throw std::runtime_error{"mlp_train_fused: no kernel instance for this configuration"};
+}
+
+} // namespace
+
+bool mlp_train_fused_supported(const MlpDesc& d, uint32_t n) {
+	const TrainConfig cfg = pick_config(d);
+	return cfg.ok && n % cfg.s == 0 && n > 0;
+}
+
+uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n) {
+	const TrainConfig cfg = pick_config(d);
+	if (!cfg.ok) return 0;
+	const uint32_t trips = n / cfg.s;
+	const uint32_t per_cu = std::max(1u, (160u * 1024u) / std::max(cfg.lds_bytes, 1u));
+	const uint32_t cap = 256 * std::min(per_cu, 2u);
+	return std::max(1u, std::min(trips, cap));
+}
+
+void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, const float* data_pdf,
+                     const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
+                     uint32_t dx_plane_features, float* slabs, uint32_t n_params) {
+	const TrainConfig cfg = pick_config(d);
+	CHECK_THROW(cfg.ok && n % cfg.s == 0);
+	TrainArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)dL_dout, L, (half_t*)dL_dx, slabs, (const h8*)image,
+	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u};
+	dispatch_train(stream, d, a, cfg, mlp_train_fused_grid(d, n));
+}
+
+} // namespace tcnn_amd

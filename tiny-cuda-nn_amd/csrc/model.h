@@ -824,6 +824,52 @@ public:
 		}
 	}
 
+	// TCNN_AMD_FUSED_STEP=0 selects the reference-shaped kernel sequence (forward / loss / backward / wgrad) for A/B runs
+	static bool use_fused_step() {
+		static const bool v = [] {
+			const char* e = getenv("TCNN_AMD_FUSED_STEP");
+			return !(e && std::string{e} == "0");
+		}();
+		return v;
+	}
+	bool fused_step_supported(uint32_t n) const { return use_fused_step() && mlp_train_fused_supported(m_network->desc(), n); }
+
+	// forward + loss + backward of a training step with the MLP part as ONE kernel (k_train.hip): same results as
+	// forward() -> loss_evaluate() -> backward(), activations never leave the CU.  out / dL_dout / L: [n][padded_out].
+	std::unique_ptr<ModelContext> fused_step(hipStream_t stream, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
+	                                         LossType loss, float loss_scale, void* out, void* dL_dout, float* L, MatViewMut* dL_dinput, const void* params,
+	                                         void* gradients, GradientMode mode) {
+		check_batch(n);
+		auto ctx = std::make_unique<Ctx>();
+		const _Float16* p = (const _Float16*)params;
+		_Float16* g = (_Float16*)gradients;
+		const uint32_t n_net = (uint32_t)m_network->n_params();
+		ctx->network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
+		ctx->encoding_ctx = m_encoding->forward(stream, n, input, p + n_net, ctx->network_input.data(), dL_dinput != nullptr, mode != GradientMode::Ignore);
+
+		const bool need_dx = m_encoding->n_params() > 0 || dL_dinput;
+		ArenaBuf dL_dnetwork_input;
+		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
+		const uint32_t plane_f = need_dx ? m_encoding->level_plane_features(dL_dinput != nullptr, mode) : 0;
+
+		ArenaBuf image = m_network->prepare(stream, params, true);
+		const MlpDesc& d = m_network->desc();
+		ArenaBuf slabs;
+		uint32_t n_slabs = 0;
+		if (mode != GradientMode::Ignore) {
+			CHECK_THROW(gradients != nullptr);
+			n_slabs = mlp_train_fused_grid(d, n);
+			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
+		}
+		mlp_train_fused(stream, d, image.data(), n, ctx->network_input.data(), target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L,
+		                dL_dnetwork_input.data(), plane_f, slabs.as<float>(), n_net);
+		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
+		if (need_dx) {
+			m_encoding->backward(stream, ctx->encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + n_net, g ? g + n_net : nullptr, mode, plane_f > 0);
+		}
+		return ctx;
+	}
+
 	Json hyperparams() const override {
 		Json j = Json::object();
 		j["otype"] = "NetworkWithInputEncoding";
@@ -1048,8 +1094,28 @@ public:
 	std::unique_ptr<TrainContext> training_step(hipStream_t stream, uint32_t n, MatView input, const float* target, const float* data_pdf, bool run_optimizer,
 	                                            MatViewMut* dL_dinput, bool use_inference_params, GradientMode mode, const void* external_dL_dy) { // trainer.h:163-190
 		const float loss_scale = LOSS_SCALE_FP16;
-		auto ctx = forward(stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy);
-		backward(stream, *ctx, n, input, dL_dinput, use_inference_params, mode);
+		std::unique_ptr<TrainContext> ctx;
+		if (m_model->fused_step_supported(n)) {
+			// MI355X path: encoding -> ONE fused MLP kernel (forward + loss + backward + weight gradients) -> grid scatter
+			ctx = std::make_unique<TrainContext>();
+			ctx->n = n;
+			const uint32_t pw = m_model->padded_output_width();
+			ctx->output = ArenaBuf{stream, (size_t)n * pw * 2};
+			ctx->L = ArenaBuf{stream, (size_t)n * pw * sizeof(float)};
+			if (external_dL_dy) {
+				ctx->dL_doutput_ptr = external_dL_dy;
+				HIP_CHECK_THROW(hipMemsetAsync(ctx->L.data(), 0, ctx->L.bytes(), stream));
+			} else {
+				CHECK_THROW(target != nullptr);
+				ctx->dL_doutput = ArenaBuf{stream, (size_t)n * pw * 2};
+				ctx->dL_doutput_ptr = ctx->dL_doutput.data();
+			}
+			ctx->model_ctx = m_model->fused_step(stream, n, input, target, data_pdf, external_dL_dy, m_loss, loss_scale, ctx->output.data(), ctx->dL_doutput.data(),
+			                                     ctx->L.as<float>(), dL_dinput, m_params.data(), m_grads.data(), mode);
+		} else {
+			ctx = forward(stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy);
+			backward(stream, *ctx, n, input, dL_dinput, use_inference_params, mode);
+		}
 		if (run_optimizer) optimizer_step(stream, loss_scale);
 		return ctx;
 	}

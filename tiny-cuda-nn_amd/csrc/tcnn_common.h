@@ -146,6 +146,18 @@ void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32
 // dx_plane_features = 0: dL_dx is AoS [n][in_width]; = F > 0: "level planes" [in_width / F][n][F] (what the grid scatter reads)
 void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* dL_dout, const void* out, const void* hidden, void* dhidden, void* dL_dx,
                   uint32_t dx_plane_features);
+// ---- the Trainer's fused step (k_train.hip): forward + loss + backward + weight gradients in one kernel.
+// Supported when out_width <= 32, width in {64, 128} and the activations of one trip fit in LDS; else use the pieces above.
+bool mlp_train_fused_supported(const MlpDesc& d, uint32_t n);
+uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n); // workgroups = number of weight-gradient slabs
+// x [n][in_width] half.  target / data_pdf [n][dims] float or external_dL_dy [n][out_width] half (loss-scaled).
+// Writes out, dL_dout, L ([n][out_width]; dL_dout and L only without external_dL_dy), dL_dx (optional; AoS or level planes),
+// and -- if slabs != nullptr -- one fp32 slab of partial weight gradients per workgroup: slabs[grid][n_params].
+void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, const float* data_pdf,
+                     const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
+                     uint32_t dx_plane_features, float* slabs, uint32_t n_params);
+// grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once
+void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate);
 // fully_fused_mlp.cu:757-762: result = dL_dout * act'(out), elementwise over n_elems halfs
 void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32_t activation, const void* dL_dout, const void* out, void* result);
 // dW[rows x cols] = sum_i dO[i][rows]^T In[i][cols]; result written as half into grad (overwrite or accumulate). workspace: float[wgrad_workspace_floats()]
