@@ -56,6 +56,9 @@ ADAM_BYTES_PER_PARAM = 36  # half grad r 2 + fp32 w/m/v r+w 24 + u3
 
 def cpu_baseline(name, budget_s=15.0):
     """The CPU oracle (port of the reference algorithm) timed on a bounded sample of the same workload."""
+    # the GPU box gives one GPU's share of the host (16 cores); an OpenMP pool over every visible core oversubscribes it
+    threads = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(len(os.sched_getaffinity(0)), 16)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     import oracle as orc
 
     n_in, n_out, batch, cfg = WORKLOADS[name]
@@ -73,10 +76,24 @@ def cpu_baseline(name, budget_s=15.0):
     return {
         "value": steps * sample_batch / dt,
         "unit": "samples/s",
-        "cores": os.cpu_count() if os.environ.get("OMP_NUM_THREADS") is None else int(os.environ["OMP_NUM_THREADS"]),
+        "cores": threads,
         "kind": "port",
         "sample": f"{steps} training_step(s) of the CPU oracle at batch {sample_batch} (full Adam over all {tr.model.n_params} parameters each step)",
     }
+
+
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (tools/profile_summary.py; FETCH_SIZE / WRITE_SIZE
+    collected in separate rocprofv3 --pmc passes of this very script, corrected as MI355X_MICROARCH.md prescribes).
+    The counters cannot be read from inside the process, so the latest committed measurement is reported; None if absent
+    or if it was taken on another workload."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    if not files or workload != "c3a":
+        return None, None
+    d = json.load(open(files[-1])).get("kernels", {}).get(kernel, {})
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
 def main():
@@ -152,6 +169,7 @@ def main():
     achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms > 0 else 0.0
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic("k_adam", args.workload if not args.batch else "")
         result = {
             "metric": "training_step throughput (samples/s) HashGrid+64-wide FFMLP, batch=256k",
             "value": world * batch * args.steps / elapsed,
@@ -170,7 +188,7 @@ def main():
                        "batch_per_gpu": batch, "global_batch": world * batch, "parallelism": f"replicas x{world}",
                        "loss_first_last": [loss0, loss1]},
             "roofline": {"bound": "hbm", "kernel": "k_adam", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": adam_bytes, "avg_launch_ms": adam_ms},
+                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": adam_bytes, "avg_launch_ms": adam_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload)
