@@ -1,0 +1,244 @@
+// k_grid_planes.hip -- the training-step form of the grid encoding forward pass (kernel_grid, grid.h:49-212) for gfx950.
+//
+// Same arithmetic as k_grid_fwd (fp32 corner weights, fp16 fma chain in corner order -- bit-identical results), different
+// SHAPE, chosen for where the time goes on MI355X: the gathers of one level hit a 2^log2_hashmap_size * F * 2 byte table
+// (2 MB for T = 2^19, F = 2) that fits in ONE XCD's 4 MB L2 but not next to the other 15 levels.
+//   * level-major work list, cut into per-XCD runs on the host (grid_planes_plan): workgroup b runs on XCD b % 8 and walks
+//     that XCD's run in order, so an XCD gathers from one or two tables at a time and they stay in its L2;
+//   * a thread owns ONE level of SPT samples (8 x 4 gathers in flight), and the output is written as level planes
+//     half [L][n][F] (dense 256-B stores per wave) which the fused MLP kernel reads directly;
+//   * the sample filter of the owner-computes scatter (bit planes over samples per (level, table chunk)) is produced
+//     here, in LDS with integer ORs (or ballots for levels with few chunks), instead of a uint64 mask per (sample, level)
+//     in HBM plus a transposition kernel.
+#include "grid_device.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace tcnn_amd {
+namespace {
+
+constexpr int FP_THREADS = 128;                       // 2 waves per workgroup
+constexpr int FP_SPT = 8;                             // samples per thread = consecutive 64-sample groups per wave
+constexpr int FP_WAVE_SAMPLES = 64 * FP_SPT;          // 512
+constexpr int FP_ITEM_SAMPLES = FP_THREADS * FP_SPT;  // 1024 samples of one level per work item
+constexpr int FP_MAX_CHUNKS = 64;
+
+template <int D, int F>
+__global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
+	const GridMeta* __restrict__ meta, const uint32_t* __restrict__ work, const uint32_t max_items, const uint32_t blocks_per_xcd, const uint32_t n, const MatView x,
+	const half_t* __restrict__ grid, half_t* __restrict__ out, unsigned long long* __restrict__ bits
+) {
+	typedef typename VecOf<half_t, F>::type vecF;
+	__shared__ unsigned long long planes[FP_THREADS / 64][FP_SPT][FP_MAX_CHUNKS];
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+	const uint32_t n_items = work[xcd];
+	const uint32_t* __restrict__ items = work + 8 + (size_t)xcd * max_items;
+
+	const uint32_t interpolation = meta->interpolation;
+	const uint32_t hash_type = meta->hash_type;
+	uint32_t primes[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) primes[d] = meta->primes[d];
+	const uint32_t n_words = n / 64;
+	constexpr int C = 1 << D;
+
+	for (uint32_t it = slot; it < n_items; it += blocks_per_xcd) {
+		const uint32_t w = items[it];
+		const uint32_t level = w >> 24;
+		const uint32_t base = (w & 0xffffffu) * FP_ITEM_SAMPLES + wave * FP_WAVE_SAMPLES; // first sample of this wave
+		if (base >= n) continue;
+		const GridLevel lv = meta->levels[level];
+		const half_t* __restrict__ lgrid = grid + (size_t)lv.offset * F;
+		half_t* __restrict__ lout = out + (size_t)level * n * F;
+		const uint32_t n_chunks = lv.scatter_n_chunks;
+		const bool want_bits = bits != nullptr && n_chunks > 1;
+		const bool lds_or = want_bits && n_chunks > 8;
+		const bool nearest = interpolation == (uint32_t)InterpolationType::Nearest;
+
+		if (lds_or) {
+#pragma unroll
+			for (int k = 0; k < FP_SPT; ++k) planes[wave][k][lane] = 0ull;
+		}
+
+		// ---- phase 1: positions, indices, all gathers in flight
+		vecF v[FP_SPT][C];
+		float pos[FP_SPT][D];
+		unsigned long long touched[FP_SPT];
+#pragma unroll
+		for (int k = 0; k < FP_SPT; ++k) {
+			const uint32_t i = min(base + k * 64 + lane, n - 1); // groups past the end recompute the last sample and store nothing
+			float xin[D];
+			load_coords<D>(x, i, xin);
+			uint32_t cell[D];
+			float pd;
+#pragma unroll
+			for (int d = 0; d < D; ++d) cell[d] = pos_fract(xin[d], lv.scale, interpolation, &pos[k][d], &pd);
+			touched[k] = 0;
+#pragma unroll
+			for (int idx = 0; idx < C; ++idx) {
+				if (idx > 0 && nearest) { v[k][idx] = v[k][0]; continue; }
+				uint32_t local[D];
+#pragma unroll
+				for (int d = 0; d < D; ++d) local[d] = cell[d] + ((idx >> d) & 1);
+				const uint32_t index = level_index<D>(lv, primes, hash_type, local);
+				v[k][idx] = *(const vecF*)&lgrid[(size_t)index * F];
+				if (want_bits) {
+					const uint32_t ch = scatter_chunk(lv, index);
+					if (lds_or) {
+						// bit `lane` of word [k][ch]; integer LDS atomics run at ~4 lane-ops/clk/CU
+						__hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)&planes[wave][k][ch] + (lane >> 5), 1u << (lane & 31), __ATOMIC_RELAXED,
+						                      __HIP_MEMORY_SCOPE_WAVEFRONT);
+					} else {
+						touched[k] |= 1ull << ch;
+					}
+				}
+			}
+		}
+
+		// ---- phase 2: interpolation (grid.h:142-169) and the plane stores
+#pragma unroll
+		for (int k = 0; k < FP_SPT; ++k) {
+			const uint32_t i = base + k * 64 + lane;
+			half_t acc[F];
+			if (nearest) { // grid.h:121-140
+#pragma unroll
+				for (int f = 0; f < F; ++f) { if constexpr (F == 1) acc[f] = v[k][0]; else acc[f] = v[k][0][f]; }
+			} else {
+#pragma unroll
+				for (int f = 0; f < F; ++f) acc[f] = (half_t)0.0f;
+#pragma unroll
+				for (int idx = 0; idx < C; ++idx) {
+					float weight = 1;
+#pragma unroll
+					for (int d = 0; d < D; ++d) weight *= (idx & (1 << d)) == 0 ? 1 - pos[k][d] : pos[k][d];
+					asm volatile("" : "+v"(weight)); // round to fp32 first, then to fp16 (see k_grid.hip)
+					const half_t wh = (half_t)weight;
+#pragma unroll
+					for (int f = 0; f < F; ++f) {
+						half_t val;
+						if constexpr (F == 1) val = v[k][idx]; else val = v[k][idx][f];
+						acc[f] = __builtin_fmaf16(wh, val, acc[f]);
+					}
+				}
+			}
+			if (base + k * 64 < n) {
+				vecF o;
+#pragma unroll
+				for (int f = 0; f < F; ++f) { if constexpr (F == 1) o = acc[f]; else o[f] = acc[f]; }
+				*(vecF*)&lout[(size_t)i * F] = o;
+			}
+		}
+
+		// ---- phase 3: bit planes.  Lane c ends up with the FP_SPT consecutive words of chunk c: one 64-byte run per lane.
+		if (want_bits) {
+			unsigned long long mine[FP_SPT];
+			if (lds_or) {
+				__builtin_amdgcn_wave_barrier(); // LDS serves one wave's instructions in order; keep the compiler from moving the reads up
+#pragma unroll
+				for (int k = 0; k < FP_SPT; ++k) mine[k] = planes[wave][k][lane];
+			} else {
+#pragma unroll
+				for (int k = 0; k < FP_SPT; ++k) {
+					mine[k] = 0;
+					for (uint32_t c = 0; c < n_chunks; ++c) {
+						const unsigned long long b = __ballot((touched[k] >> c) & 1ull);
+						if (lane == c) mine[k] = b;
+					}
+				}
+			}
+			if (lane < n_chunks) {
+				unsigned long long* dst = bits + ((size_t)level * FP_MAX_CHUNKS + lane) * n_words + base / 64;
+				if (base + FP_WAVE_SAMPLES <= n) {
+					typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+					for (int k = 0; k < FP_SPT; k += 2) *(u64x2*)&dst[k] = u64x2{mine[k], mine[k + 1]};
+				} else {
+#pragma unroll
+					for (int k = 0; k < FP_SPT; ++k) if (base + k * 64 < n) dst[k] = mine[k];
+				}
+			}
+		}
+	}
+}
+
+template <int D, int F>
+void launch_planes(hipStream_t s, const GridMeta* dm, const uint32_t* work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n, MatView x, const void* grid, void* out, uint64_t* bits) {
+	hipLaunchKernelGGL((k_grid_fwd_planes<D, F>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
+	                   (unsigned long long*)bits);
+	HIP_CHECK_THROW(hipGetLastError());
+}
+
+} // namespace
+
+bool grid_planes_supported(const GridMeta& meta, uint32_t n) {
+	const uint32_t F = meta.n_features_per_level;
+	return (F == 2 || F == 4 || F == 8) && (meta.n_pos_dims == 2 || meta.n_pos_dims == 3) && meta.n_levels < 256 && n % 64 == 0 && n > 0 &&
+	       div_round_up(n, (uint32_t)FP_ITEM_SAMPLES) < (1u << 24);
+}
+
+// Work list: [0..7] = number of items of XCD x, then 8 runs of max_items entries (level << 24 | item index inside the level).
+// Levels are laid end to end in order and the sequence is cut into 8 runs of equal estimated cost, so every XCD gathers
+// from at most a few consecutive levels (usually two) and each table is pulled into at most two L2s.
+void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd) {
+	const uint32_t items_per_level = div_round_up(n, (uint32_t)FP_ITEM_SAMPLES);
+	// relative cost of one item: tables beyond a few hundred KB miss the per-CU cache on nearly every corner pair
+	float coarse_cost = 0.6f;
+	if (const char* e = getenv("TCNN_AMD_FWD_COARSE_COST")) coarse_cost = (float)atof(e);
+	std::vector<float> cost(meta.n_levels);
+	double total = 0;
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		const size_t bytes = (size_t)meta.levels[l].size * meta.n_features_per_level * 2;
+		cost[l] = bytes > (256u << 10) ? 1.0f : coarse_cost;
+		total += (double)cost[l] * items_per_level;
+	}
+	// profiling aid: TCNN_AMD_FWD_LEVELS="lo,hi" restricts the work list to levels lo..hi (results are then incomplete!)
+	uint32_t dbg_lo = 0, dbg_hi = meta.n_levels;
+	if (const char* e = getenv("TCNN_AMD_FWD_LEVELS")) {
+		sscanf(e, "%u,%u", &dbg_lo, &dbg_hi);
+		total = 0;
+		for (uint32_t l = dbg_lo; l <= dbg_hi && l < meta.n_levels; ++l) total += (double)cost[l] * items_per_level;
+	}
+	std::vector<std::vector<uint32_t>> runs(8);
+	double acc = 0;
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		if (l < dbg_lo || l > dbg_hi) continue;
+		for (uint32_t i = 0; i < items_per_level; ++i) {
+			const uint32_t bin = std::min<uint32_t>((uint32_t)((acc + 0.5 * cost[l]) * 8.0 / total), 7u);
+			runs[bin].push_back(l << 24 | i);
+			acc += cost[l];
+		}
+	}
+	max_items = 0;
+	for (auto& r : runs) max_items = std::max<uint32_t>(max_items, (uint32_t)r.size());
+	work.assign(8 + (size_t)8 * max_items, 0xffffffffu);
+	for (uint32_t b = 0; b < 8; ++b) {
+		work[b] = (uint32_t)runs[b].size();
+		std::copy(runs[b].begin(), runs[b].end(), work.begin() + 8 + (size_t)b * max_items);
+	}
+	// 8 workgroups (16 waves) per CU on each XCD's 32 CUs, fewer when there is less work
+	blocks_per_xcd = std::max(1u, std::min(256u, max_items));
+	if (const char* e = getenv("TCNN_AMD_FWD_BLOCKS_PER_XCD")) blocks_per_xcd = std::max(1, atoi(e));
+}
+
+void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
+                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits) {
+	CHECK_THROW(grid_planes_supported(meta, n));
+	const uint32_t F = meta.n_features_per_level;
+#define TCNN_PLANES(D) \
+	switch (F) { \
+		case 2: return launch_planes<D, 2>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
+		case 4: return launch_planes<D, 4>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
+		default: return launch_planes<D, 8>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
+	}
+	if (meta.n_pos_dims == 2) { TCNN_PLANES(2) } else { TCNN_PLANES(3) }
+#undef TCNN_PLANES
+}
+
+} // namespace tcnn_amd

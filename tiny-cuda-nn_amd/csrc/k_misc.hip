@@ -13,6 +13,7 @@
 
 #include <hip/hip_fp16.h>
 
+#include <cmath>
 #include <limits>
 
 namespace tcnn_amd {
@@ -173,61 +174,123 @@ struct AdamArgs {
 	float relative_weight_decay, absolute_weight_decay, weight_clipping_magnitude, loss_scale, learning_rate, non_matrix_learning_rate_factor;
 	float beta1, beta2, epsilon, lower_lr_bound, upper_lr_bound, l2_reg;
 	uint32_t optimize_matrix_params, optimize_non_matrix_params;
+	float inv_loss_scale;
+	uint32_t inv_loss_scale_exact;
+	uint32_t common_step; // the optimizer's own step count: the per-parameter count of every parameter that was updated in every step
 };
 
-__device__ inline void adam_one(const AdamArgs& a, const bool is_matrix, const half_t g_h, float& w_fp, half_t& w_h, float& m1, float& m2, uint32_t& step) {
-	float gradient = (float)g_h / a.loss_scale;
-	if (!is_matrix) {
-		if (!a.optimize_non_matrix_params || gradient == 0) return;
-	} else {
-		if (!a.optimize_matrix_params) return;
-	}
+// debiasing factor of adam.h:97-98
+__device__ inline float adam_debias(const float beta1, const float beta2, uint32_t step) { return sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step)); }
+// out of line: only parameters whose own step count differs from the optimizer's take this path
+__device__ __noinline__ float adam_debias_slow(const float beta1, const float beta2, uint32_t step) { return adam_debias(beta1, beta2, step); }
+
+// One parameter, branch-free on the common path (selects instead of early returns, so that a wave whose lanes disagree about
+// "skipped" does not execute the body twice).  common_debias = adam_debias(common_step) is evaluated once per thread: nearly all
+// parameters share the optimizer's step count, and two powf per parameter would make the kernel ALU-bound.
+// `updated` reports whether adam.h:76-84 lets this parameter through.
+__device__ inline void adam_one(const AdamArgs& a, const float common_debias, const bool is_matrix, const half_t g_h, float& w_fp, half_t& w_h, float& m1, float& m2, uint32_t& step,
+                                bool& updated) {
+	// loss_scale is a power of two in practice (128): the reciprocal multiply is then exact, i.e. identical to the division
+	float gradient = a.inv_loss_scale_exact ? (float)g_h * a.inv_loss_scale : (float)g_h / a.loss_scale;
+	updated = is_matrix ? a.optimize_matrix_params != 0 : (a.optimize_non_matrix_params != 0 && gradient != 0);
 	const float weight_fp = w_fp;
 	if (is_matrix) gradient += a.l2_reg * weight_fp;
 	const float gradient_sq = gradient * gradient;
-	const float first_moment = m1 = a.beta1 * m1 + (1 - a.beta1) * gradient;
-	const float second_moment = m2 = a.beta2 * m2 + (1 - a.beta2) * gradient_sq;
+	const float first_moment = a.beta1 * m1 + (1 - a.beta1) * gradient;
+	const float second_moment = a.beta2 * m2 + (1 - a.beta2) * gradient_sq;
 	float learning_rate = a.learning_rate;
 	if (!is_matrix) learning_rate *= a.non_matrix_learning_rate_factor;
-	const uint32_t current_step = ++step;
-	learning_rate *= sqrtf(1 - powf(a.beta2, (float)current_step)) / (1 - powf(a.beta1, (float)current_step));
+	const uint32_t current_step = step + 1;
+	float debias = common_debias;
+	if (__builtin_expect(updated && current_step != a.common_step, 0)) debias = adam_debias_slow(a.beta1, a.beta2, current_step);
+	learning_rate *= debias;
 	const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), a.lower_lr_bound), a.upper_lr_bound);
 	// weight_decay(rel * lr, abs * lr, w), common_device.h:870-873
 	const float decayed_weight = (1 - a.relative_weight_decay * learning_rate) * weight_fp - copysignf(a.absolute_weight_decay * learning_rate, weight_fp);
 	float new_weight = decayed_weight - effective_learning_rate * first_moment;
 	if (a.weight_clipping_magnitude != 0.0f) new_weight = fminf(fmaxf(new_weight, -a.weight_clipping_magnitude), a.weight_clipping_magnitude);
-	w_fp = new_weight;
-	w_h = (half_t)new_weight;
+	w_fp = updated ? new_weight : weight_fp;
+	w_h = (half_t)new_weight; // stored only if updated
+	m1 = updated ? first_moment : m1;
+	m2 = updated ? second_moment : m2;
+	step = updated ? current_step : step;
 }
 
+constexpr int ADAM_Q = 1; // quads (of 4 parameters) per thread, one block-width apart (measured: 1 -> 82 us, 2 -> 84 us, 4 -> 91 us on C3a; occupancy wins)
+
+// QUAD_UNIFORM: n_matrix is a multiple of 4, so the 4 parameters of a quad are all matrix weights or all not
+template <bool QUAD_UNIFORM>
 __global__ void __launch_bounds__(256) k_adam(
 	const AdamArgs a, const size_t n, const size_t n_matrix,
 	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps
 ) {
-	const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-	if (i4 >= n) return;
-	if (i4 + 4 <= n) {
-		const h4 gv = *(const h4*)(g + i4);
-		// grid (non-matrix) entries whose 4 gradients are all zero are skipped without touching the other 32 B/param
-		const bool all_non_matrix = i4 >= n_matrix;
-		if (all_non_matrix && gv[0] == (half_t)0.0f && gv[1] == (half_t)0.0f && gv[2] == (half_t)0.0f && gv[3] == (half_t)0.0f) return;
-		float4 wf = *(const float4*)(w_fp + i4);
-		float4 a1 = *(const float4*)(m1 + i4);
-		float4 a2 = *(const float4*)(m2 + i4);
-		uint4 st = *(const uint4*)(steps + i4);
-		const h4 wh = *(const h4*)(w + i4);
-		half_t w0 = wh[0], w1 = wh[1], w2 = wh[2], w3 = wh[3];
-		adam_one(a, i4 + 0 < n_matrix, gv[0], wf.x, w0, a1.x, a2.x, st.x);
-		adam_one(a, i4 + 1 < n_matrix, gv[1], wf.y, w1, a1.y, a2.y, st.y);
-		adam_one(a, i4 + 2 < n_matrix, gv[2], wf.z, w2, a1.z, a2.z, st.z);
-		adam_one(a, i4 + 3 < n_matrix, gv[3], wf.w, w3, a1.w, a2.w, st.w);
-		*(float4*)(w_fp + i4) = wf;
-		*(float4*)(m1 + i4) = a1;
-		*(float4*)(m2 + i4) = a2;
-		*(uint4*)(steps + i4) = st;
-		*(h4*)(w + i4) = h4{w0, w1, w2, w3};
-	} else {
-		for (size_t i = i4; i < n; ++i) adam_one(a, i < n_matrix, g[i], w_fp[i], w[i], m1[i], m2[i], steps[i]);
+	const size_t base = (size_t)blockIdx.x * (256 * 4 * ADAM_Q) + threadIdx.x * 4;
+	__shared__ float s_debias;
+	// phase 1: the gradients of all quads (8 B each).  Grid (non-matrix) quads whose 4 gradients are all zero are skipped
+	// without touching the other 32 B/param (adam.h:76-79 returns before reading anything else).
+	h4 gv[ADAM_Q];
+	bool live[ADAM_Q];
+#pragma unroll
+	for (int q = 0; q < ADAM_Q; ++q) {
+		const size_t i4 = base + (size_t)q * 1024;
+		live[q] = i4 + 4 <= n;
+		gv[q] = live[q] ? *(const h4*)(g + i4) : h4{0, 0, 0, 0};
+	}
+#pragma unroll
+	for (int q = 0; q < ADAM_Q; ++q) {
+		const size_t i4 = base + (size_t)q * 1024;
+		const bool zero = gv[q][0] == (half_t)0.0f && gv[q][1] == (half_t)0.0f && gv[q][2] == (half_t)0.0f && gv[q][3] == (half_t)0.0f;
+		if (live[q] && i4 >= n_matrix && zero) live[q] = false;
+	}
+	// the common debiasing factor (two powf, ~300 instructions) is evaluated by one wave per workgroup while the loads fly
+	if (threadIdx.x < 64) {
+		const float d = adam_debias(a.beta1, a.beta2, a.common_step);
+		if (threadIdx.x == 0) s_debias = d;
+	}
+	// phase 2: all remaining loads in flight together
+	float4 wf[ADAM_Q], a1[ADAM_Q], a2[ADAM_Q];
+	uint4 st[ADAM_Q];
+#pragma unroll
+	for (int q = 0; q < ADAM_Q; ++q) {
+		const size_t i4 = base + (size_t)q * 1024;
+		if (live[q]) {
+			wf[q] = *(const float4*)(w_fp + i4);
+			a1[q] = *(const float4*)(m1 + i4);
+			a2[q] = *(const float4*)(m2 + i4);
+			st[q] = *(const uint4*)(steps + i4);
+		}
+	}
+	__syncthreads();
+	const float debias = s_debias;
+#pragma unroll
+	for (int q = 0; q < ADAM_Q; ++q) {
+		const size_t i4 = base + (size_t)q * 1024;
+		if (live[q]) {
+			half_t wh[4];
+			bool up[4];
+			const bool quad_matrix = i4 < n_matrix;
+			adam_one(a, debias, QUAD_UNIFORM ? quad_matrix : i4 + 0 < n_matrix, gv[q][0], wf[q].x, wh[0], a1[q].x, a2[q].x, st[q].x, up[0]);
+			adam_one(a, debias, QUAD_UNIFORM ? quad_matrix : i4 + 1 < n_matrix, gv[q][1], wf[q].y, wh[1], a1[q].y, a2[q].y, st[q].y, up[1]);
+			adam_one(a, debias, QUAD_UNIFORM ? quad_matrix : i4 + 2 < n_matrix, gv[q][2], wf[q].z, wh[2], a1[q].z, a2[q].z, st[q].z, up[2]);
+			adam_one(a, debias, QUAD_UNIFORM ? quad_matrix : i4 + 3 < n_matrix, gv[q][3], wf[q].w, wh[3], a1[q].w, a2[q].w, st[q].w, up[3]);
+			*(float4*)(w_fp + i4) = wf[q];
+			*(float4*)(m1 + i4) = a1[q];
+			*(float4*)(m2 + i4) = a2[q];
+			*(uint4*)(steps + i4) = st[q];
+			if (up[0] && up[1] && up[2] && up[3]) {
+				*(h4*)(w + i4) = h4{wh[0], wh[1], wh[2], wh[3]};
+			} else { // skipped parameters keep their half value, whatever it is: only the updated ones are stored
+#pragma unroll
+				for (int e = 0; e < 4; ++e) if (up[e]) w[i4 + e] = wh[e];
+			}
+		} else if (i4 < n && i4 + 4 > n) { // ragged tail
+			for (size_t i = i4; i < n; ++i) {
+				bool up;
+				half_t wh;
+				adam_one(a, debias, i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
+				if (up) w[i] = wh;
+			}
+		}
 	}
 }
 
@@ -381,7 +444,13 @@ void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix
 	a.l2_reg = h.l2_reg;
 	a.optimize_matrix_params = h.optimize_matrix_params;
 	a.optimize_non_matrix_params = h.optimize_non_matrix_params;
-	hipLaunchKernelGGL(k_adam, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps);
+	a.common_step = current_step;
+	int exponent = 0;
+	a.inv_loss_scale_exact = (std::frexp(loss_scale, &exponent) == 0.5f && loss_scale >= 1.0f / 65536 && loss_scale <= 65536.0f) ? 1 : 0;
+	a.inv_loss_scale = 1.0f / loss_scale;
+	const dim3 grid(blocks_for((n + 3) / 4, 256 * ADAM_Q));
+	if (n_matrix % 4 == 0) hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps);
+	else hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps);
 }
 
 namespace {

@@ -41,6 +41,7 @@ struct TrainArgs {
 	float loss_scale;
 	uint32_t dx_plane_f, n_params;
 	uint32_t image_in_lds;
+	uint32_t x_plane_f;     // 0: x is AoS [n][in_width]; F: x is level planes [in_width / F][n][F] (k_grid_planes.hip)
 };
 
 template <int W, int NB, int NW, int MAXT, int ACT>
@@ -132,7 +133,23 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					if (k0 < in_w) {
-						bf[b] = *(const h8*)(a.x + (size_t)(s0 + 16 * b + c) * in_w + k0);
+						const uint32_t sample = s0 + 16 * b + c;
+						if (a.x_plane_f == 2) { // four 4-byte loads, each a dense 64-byte run per 16 lanes
+							typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+							u4 v;
+#pragma unroll
+							for (int p = 0; p < 4; ++p) v[p] = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + p) * a.n + sample) * 2);
+							bf[b] = __builtin_bit_cast(h8, v);
+						} else if (a.x_plane_f == 4) {
+							const uint2 lo = *(const uint2*)(a.x + ((size_t)(k0 / 4) * a.n + sample) * 4);
+							const uint2 hi = *(const uint2*)(a.x + ((size_t)(k0 / 4 + 1) * a.n + sample) * 4);
+							typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+							bf[b] = __builtin_bit_cast(h8, (u4{lo.x, lo.y, hi.x, hi.y}));
+						} else if (a.x_plane_f == 8) {
+							bf[b] = *(const h8*)(a.x + ((size_t)(k0 / 8) * a.n + sample) * 8);
+						} else {
+							bf[b] = *(const h8*)(a.x + (size_t)sample * in_w + k0);
+						}
 						*(h8*)(lds + xs_off + (row0 + 16 * b + c) * xs_stride + k0) = bf[b];
 					} else {
 						bf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -455,13 +472,13 @@ uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n) {
 	return std::max(1u, std::min(trips, cap));
 }
 
-void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, const float* data_pdf,
+void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
                      uint32_t dx_plane_features, float* slabs, uint32_t n_params) {
 	const TrainConfig cfg = pick_config(d);
 	CHECK_THROW(cfg.ok && n % cfg.s == 0);
 	TrainArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)dL_dout, L, (half_t*)dL_dx, slabs, (const h8*)image,
-	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u};
+	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u, x_plane_features};
 	dispatch_train(stream, d, a, cfg, mlp_train_fused_grid(d, n));
 }
 

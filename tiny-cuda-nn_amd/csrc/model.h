@@ -228,6 +228,11 @@ public:
 	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) = 0;
 	// > 0: this encoding's backward prefers dL_dy in level planes with that many features per plane (see k_grid_bwd_lds)
 	virtual uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const { return 0; }
+	// > 0: forward_planes() can write the encoded batch as level planes [padded / F][n][F] (no input gradients in that form)
+	virtual uint32_t forward_plane_features(uint32_t n) { return 0; }
+	virtual EncodingContext forward_planes(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out_planes, bool prepare_param_gradients) {
+		throw std::runtime_error{"Encoding: level-plane output is not available"};
+	}
 	virtual Json hyperparams() const = 0;
 	bool fp32() const { return m_fp32; }
 protected:
@@ -377,6 +382,46 @@ public:
 		return ctx;
 	}
 
+	// TCNN_AMD_GRID_PLANES=0 keeps the AoS forward kernel inside the fused training step (A/B runs)
+	static bool use_planes() {
+		static const bool v = [] {
+			const char* e = getenv("TCNN_AMD_GRID_PLANES");
+			return !(e && std::string{e} == "0");
+		}();
+		return v;
+	}
+	uint32_t forward_plane_features(uint32_t n) override {
+		return (!m_fp32 && use_planes() && m_n_to_pad == 0 && grid_planes_supported(m_meta, n)) ? m_meta.n_features_per_level : 0;
+	}
+
+	struct PlanesPlan {
+		DeviceBuf dev_work;
+		uint32_t max_items = 0, blocks_per_xcd = 0;
+	};
+	PlanesPlan& planes_plan(uint32_t n) {
+		auto it = m_planes_plans.find(n);
+		if (it != m_planes_plans.end()) return *it->second;
+		auto plan = std::make_unique<PlanesPlan>();
+		std::vector<uint32_t> work;
+		grid_planes_plan(m_meta, n, work, plan->max_items, plan->blocks_per_xcd);
+		plan->dev_work.resize(work.size() * sizeof(uint32_t));
+		HIP_CHECK_THROW(hipMemcpy(plan->dev_work.data(), work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		return *(m_planes_plans[n] = std::move(plan));
+	}
+
+	EncodingContext forward_planes(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out_planes, bool prepare_param_gradients) override {
+		EncodingContext ctx;
+		CHECK_THROW(forward_plane_features(n) > 0);
+		const bool want_filter = prepare_param_gradients && lds_scatter_usable();
+		if (want_filter) {
+			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_scatter_max_chunks() * (n / 64) * sizeof(uint64_t)};
+			ctx.n = n;
+		}
+		PlanesPlan& plan = planes_plan(n);
+		grid_forward_planes(stream, m_meta, dev_meta(), plan.dev_work.as<uint32_t>(), plan.max_items, plan.blocks_per_xcd, n, x, params, out_planes, ctx.chunk_mask.as<uint64_t>());
+		return ctx;
+	}
+
 	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
 		if ((!dL_dx && mode == GradientMode::Ignore) || n == 0) return;
 		const size_t elem = m_fp32 ? 4 : 2;
@@ -471,6 +516,7 @@ private:
 	GridMeta m_meta;
 	DeviceBuf m_dev_meta;
 	std::map<uint32_t, std::unique_ptr<ScatterPlan>> m_scatter_plans;
+	std::map<uint32_t, std::unique_ptr<PlanesPlan>> m_planes_plans;
 	bool m_scatter_mask_ok = true;
 	std::vector<uint32_t> m_resolutions;
 	uint32_t m_n_features, m_log2_hashmap_size, m_base_resolution, m_n_entries;
@@ -845,7 +891,10 @@ public:
 		_Float16* g = (_Float16*)gradients;
 		const uint32_t n_net = (uint32_t)m_network->n_params();
 		ctx->network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
-		ctx->encoding_ctx = m_encoding->forward(stream, n, input, p + n_net, ctx->network_input.data(), dL_dinput != nullptr, mode != GradientMode::Ignore);
+		// grids hand the encoded batch over as level planes (XCD-aware forward kernel, scatter filter produced on the way)
+		const uint32_t x_plane_f = dL_dinput ? 0 : m_encoding->forward_plane_features(n);
+		if (x_plane_f) ctx->encoding_ctx = m_encoding->forward_planes(stream, n, input, p + n_net, ctx->network_input.data(), mode != GradientMode::Ignore);
+		else ctx->encoding_ctx = m_encoding->forward(stream, n, input, p + n_net, ctx->network_input.data(), dL_dinput != nullptr, mode != GradientMode::Ignore);
 
 		const bool need_dx = m_encoding->n_params() > 0 || dL_dinput;
 		ArenaBuf dL_dnetwork_input;
@@ -861,7 +910,7 @@ public:
 			n_slabs = mlp_train_fused_grid(d, n);
 			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
 		}
-		mlp_train_fused(stream, d, image.data(), n, ctx->network_input.data(), target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L,
+		mlp_train_fused(stream, d, image.data(), n, ctx->network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L,
 		                dL_dnetwork_input.data(), plane_f, slabs.as<float>(), n_net);
 		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
 		if (need_dx) {

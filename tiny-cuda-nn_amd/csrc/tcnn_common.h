@@ -81,6 +81,12 @@ struct MatViewMut {
 // chunk_mask (optional, uint64 [n_levels][n]): bit c set <=> the sample touches scatter chunk c of that level (filter for k_grid_scatter)
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx,
                   uint64_t* chunk_mask);
+// ---- training-step forward (k_grid_planes.hip): half, F >= 2, D in {2, 3}; level-major and XCD-aware.
+// out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][64][n / 64], written for levels with > 1 scatter chunk.
+bool grid_planes_supported(const GridMeta& meta, uint32_t n);
+void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd);
+void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
+                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits);
 // reference-shaped gradient scatter with global float atomics (fp32 grids, F == 1, tables too large for the LDS scheme).
 // grad: T[n_params] accumulated in place (caller zeroes it).  For F == 1 && !fp32 the caller passes an fp32 scratch as `grad`.
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32_grad, uint32_t n, MatView x, const void* dL_dy, bool dy_fp32, uint32_t dy_stride, void* grad);
@@ -150,10 +156,11 @@ void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint3
 // Supported when out_width <= 32, width in {64, 128} and the activations of one trip fit in LDS; else use the pieces above.
 bool mlp_train_fused_supported(const MlpDesc& d, uint32_t n);
 uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n); // workgroups = number of weight-gradient slabs
-// x [n][in_width] half.  target / data_pdf [n][dims] float or external_dL_dy [n][out_width] half (loss-scaled).
+// x [n][in_width] half (x_plane_features = 0) or level planes [in_width / F][n][F] (x_plane_features = F in {2, 4, 8}).
+// target / data_pdf [n][dims] float or external_dL_dy [n][out_width] half (loss-scaled).
 // Writes out, dL_dout, L ([n][out_width]; dL_dout and L only without external_dL_dy), dL_dx (optional; AoS or level planes),
 // and -- if slabs != nullptr -- one fp32 slab of partial weight gradients per workgroup: slabs[grid][n_params].
-void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, const float* data_pdf,
+void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
                      uint32_t dx_plane_features, float* slabs, uint32_t n_params);
 // grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once

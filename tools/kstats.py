@@ -1,5 +1,5 @@
 import csv, sys, re, glob
-f = glob.glob(sys.argv[1] + '/*/*_kernel_stats.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*_kernel_stats.csv') + glob.glob(sys.argv[1] + '/*_kernel_stats.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 tot = 0
 for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 14]:

@@ -1,5 +1,5 @@
 import csv, glob, collections, sys
-f = glob.glob(sys.argv[1] + '/*/*counter_collection.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*counter_collection.csv') + glob.glob(sys.argv[1] + '/*counter_collection.csv'))[0]
 keys = sys.argv[2].split(',')
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(f)):
