@@ -35,7 +35,8 @@ namespace {
 constexpr uint32_t SCATTER_ACC_BYTES = 128 * 1024; // accumulator chunk per workgroup
 constexpr uint32_t SCATTER_THREADS = 1024;
 constexpr uint32_t SCATTER_WAVES = SCATTER_THREADS / 64;
-constexpr uint32_t SCATTER_QUEUE_IDS = 128;        // wave-private compaction queue (sample ids)
+constexpr int SCATTER_SUB_BATCHES = 2;             // 64-sample batches whose gathers are in flight together per wave
+constexpr uint32_t SCATTER_QUEUE_IDS = 64 * SCATTER_SUB_BATCHES + 64; // wave-private compaction queue (sample ids)
 constexpr uint32_t SCATTER_LDS_BYTES = SCATTER_ACC_BYTES + SCATTER_WAVES * SCATTER_QUEUE_IDS * 4;
 constexpr uint32_t SCATTER_MAX_CHUNKS = 64;        // bit planes per level (the forward mask is a uint64)
 
@@ -45,6 +46,14 @@ __device__ inline long long half_to_fixed(half_t h) {
 	const uint32_t e = (b >> 10) & 31u, f = b & 1023u;
 	const unsigned long long m = e ? ((unsigned long long)(1024u | f) << (e - 1)) : (unsigned long long)f;
 	return (b & 0x8000u) ? -(long long)m : (long long)m;
+}
+
+// the same for the common case |h| < 64: h * 2^24 fits an int32 and the float detour is exact (3 instructions instead of ~12)
+__device__ inline long long half_to_fixed_fast(half_t h) {
+	const float f = (float)h;
+	long long v = (long long)(int)(f * 16777216.0f);
+	if (__builtin_expect(!(__builtin_fabsf(f) < 64.0f), 0)) v = half_to_fixed(h);
+	return v;
 }
 
 // s * 2^-24 rounded to fp16, round-to-nearest-even, one rounding
@@ -67,7 +76,15 @@ __device__ inline half_t fixed_to_half(long long s) {
 	return neg ? -r : r;
 }
 
-template <int D, int F>
+// |s| < 2^24 (|value| < 1): s is exact as a float, the scaling is exact, and the hardware float -> half conversion is the one RNE rounding
+__device__ inline half_t fixed_to_half_fast(long long s) {
+	if (__builtin_expect((unsigned long long)(s + (1ll << 24)) < (1ull << 25), 1)) return (half_t)((float)(int)s * 5.9604644775390625e-08f);
+	return fixed_to_half(s);
+}
+
+// REC: dL_dy holds 16-byte records float4 [level][n] = {D coordinates, F gradient halves} written by the fused MLP kernel
+// (mlp_device.h store_dx_record): one gather per hit instead of two -- gathers cost ~2 clk per lane per CU whatever their width.
+template <int D, int F, bool REC>
 __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	const GridMeta* __restrict__ meta, const GridScatterTask* __restrict__ tasks, const uint32_t n, const MatView x,
 	const half_t* __restrict__ dL_dy, const uint32_t dy_stride_sample, const uint32_t dy_stride_level, half_t* __restrict__ grad,
@@ -83,7 +100,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63, wave = tid >> 6;
 	uint32_t* queue = (uint32_t*)(smem + SCATTER_ACC_BYTES) + wave * SCATTER_QUEUE_IDS; // wave-private
-	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
 
 	const GridLevel lv = meta->levels[task.level];
 	half_t* __restrict__ g = grad + ((size_t)lv.offset + task.entry_begin) * F;
@@ -100,7 +117,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 		if ((n_vals & 1u) && tid == 0) acc[n_vals - 1] = 0;
 	}
 	__syncthreads();
-	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
 	const uint32_t interpolation = meta->interpolation;
 	const uint32_t hash_type = meta->hash_type;
@@ -111,9 +128,23 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	typedef typename VecOf<half_t, F>::type vecF;
 
 	// issue the loads of one sample (coordinates + its dL/dy of this level)
+	const uint4* recs = (const uint4*)dL_dy + (size_t)task.level * n;
 	auto fetch = [&](const uint32_t i, float (&xin)[D], vecF& gv) {
-		load_coords<D>(x, i, xin);
-		gv = *(const vecF*)&dy[(size_t)i * dy_stride_sample];
+		if constexpr (REC) {
+			const uint4 r = recs[i];
+			const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+			for (int d = 0; d < D; ++d) xin[d] = __builtin_bit_cast(float, w[d]);
+			if constexpr (F == 2) {
+				gv = __builtin_bit_cast(vecF, w[D]);
+			} else {
+				typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+				gv = __builtin_bit_cast(vecF, (u2{w[2], w[3]}));
+			}
+		} else {
+			load_coords<D>(x, i, xin);
+			gv = *(const vecF*)&dy[(size_t)i * dy_stride_sample];
+		}
 	};
 	// full treatment of one sample: recompute its corners, add those that fall into the owned chunk (grid.h:215-320)
 	auto accumulate = [&](const float (&xin)[D], const vecF& gv) {
@@ -131,7 +162,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 				for (int f = 0; f < F; ++f) {
 					const half_t c = w * gv[f]; // (GRAD_T)weight * grad in fp16, grid.h:254
 					// explicit LDS address space: guarantees ds_add_u64 (a generic pointer may degrade to flat_atomic_add_x2)
-					__hip_atomic_fetch_add(acc_lds + index * F + f, (unsigned long long)half_to_fixed(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					__hip_atomic_fetch_add(acc_lds + index * F + f, (unsigned long long)half_to_fixed_fast(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 			}
 		};
@@ -140,8 +171,15 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 			add(cell, 1.0f);
 			return;
 		}
+		// All 2^D corners are located first; then the wave adds "the next corner of mine that falls into the chunk" until no
+		// lane has one left.  A sample that reaches this point typically owns 2^(D-1) such corners (one row of the cell), so
+		// this takes half as many -- fully populated -- LDS atomic instructions as walking the corners in lockstep.
+		constexpr int C = 1 << D;
+		uint32_t cidx[C];
+		float cw[C];
+		uint32_t mine = 0;
 #pragma unroll
-		for (int idx = 0; idx < (1 << D); ++idx) {
+		for (int idx = 0; idx < C; ++idx) {
 			float weight = 1;
 			uint32_t local[D];
 #pragma unroll
@@ -154,7 +192,29 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 					local[d] = cell[d] + 1;
 				}
 			}
-			add(local, weight);
+			asm volatile("" : "+v"(weight)); // keep the fp32 rounding of the weight product (see k_grid_fwd)
+			cw[idx] = weight;
+			cidx[idx] = level_index<D>(lv, primes, hash_type, local) - task.entry_begin;
+			if (cidx[idx] < task.n_entries) mine |= 1u << idx;
+		}
+		while (__builtin_amdgcn_ballot_w64(mine != 0) != 0) {
+			if (mine != 0) {
+				const uint32_t k = (uint32_t)__builtin_ctz(mine);
+				mine &= mine - 1;
+				uint32_t index = cidx[0];
+				float weight = cw[0];
+#pragma unroll
+				for (int idx = 1; idx < C; ++idx) {
+					index = k == (uint32_t)idx ? cidx[idx] : index;
+					weight = k == (uint32_t)idx ? cw[idx] : weight;
+				}
+				const half_t w = (half_t)weight;
+#pragma unroll
+				for (int f = 0; f < F; ++f) {
+					const half_t c = w * gv[f]; // (GRAD_T)weight * grad in fp16, grid.h:254
+					__hip_atomic_fetch_add(acc_lds + index * F + f, (unsigned long long)half_to_fixed_fast(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
 		}
 	};
 
@@ -166,32 +226,51 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	const uint32_t w_end = min(task.sample_end, w_begin + per_wave);
 	const uint32_t n_blocks = (w_end - w_begin + 63) / 64; // wave-uniform
 
-	float ax[D], bx[D];
-	vecF ag, bg;
-	bool a_valid = false, b_valid = false; // per lane
-	uint32_t phase = 0;                    // wave-uniform: which register set receives the next batch
-	auto submit = [&](const uint32_t i, const bool valid) { // i is in range for every lane (clamped by the caller)
-		if (phase == 0) {
-			fetch(i, ax, ag);
-			if (b_valid) accumulate(bx, bg);
-			a_valid = valid;
-			b_valid = false;
-			phase = 1;
-		} else {
-			fetch(i, bx, bg);
-			if (a_valid) accumulate(ax, ag);
-			b_valid = valid;
-			a_valid = false;
-			phase = 0;
+	// Software pipeline, two batches in flight: the loads of batch k are issued, then batch k-2 is accumulated.  The register
+	// sets rotate statically (plain moves) so that the compiler can count the younger loads and wait with vmcnt(2), not vmcnt(0).
+	constexpr int SB = SCATTER_SUB_BATCHES;
+	float ax[SB][D], nx[SB][D];
+	vecF ag[SB], ng[SB];
+	bool a_valid[SB]; // per lane
+#pragma unroll
+	for (int s = 0; s < SB; ++s) a_valid[s] = false;
+	unsigned long long t_fetch = 0, t_acc = 0, n_sub = 0; // development aid (TCNN_AMD_SCATTER_TIMING): shader clocks of wave 0
+	auto submit = [&](const uint32_t (&ids)[SB], const bool (&valid)[SB]) { // ids are in range for every lane (clamped by the caller)
+		const unsigned long long c0 = dbg_times ? __builtin_readcyclecounter() : 0;
+#pragma unroll
+		for (int s = 0; s < SB; ++s) fetch(ids[s], nx[s], ng[s]);
+		const unsigned long long c1 = dbg_times ? __builtin_readcyclecounter() : 0;
+#pragma unroll
+		for (int s = 0; s < SB; ++s) if (a_valid[s]) accumulate(ax[s], ag[s]);
+		if (dbg_times) {
+			const unsigned long long c2 = __builtin_readcyclecounter();
+			t_fetch += c1 - c0;
+			t_acc += c2 - c1;
+			++n_sub;
+		}
+#pragma unroll
+		for (int s = 0; s < SB; ++s) {
+#pragma unroll
+			for (int d = 0; d < D; ++d) ax[s][d] = nx[s][d];
+			ag[s] = ng[s];
+			a_valid[s] = valid[s];
 		}
 	};
 
+	const unsigned long long t_loop0 = dbg_times ? __builtin_readcyclecounter() : 0;
 	if (n_blocks > 0) {
 		if (chunk_bits == nullptr || lv.scatter_n_chunks == 1) {
 			// no filter available (or nothing to filter): every sample gets the full treatment
-			for (uint32_t blk = 0; blk < n_blocks; ++blk) {
-				const uint32_t i = w_begin + blk * 64 + lane;
-				submit(min(i, w_end - 1), i < w_end);
+			for (uint32_t blk = 0; blk < n_blocks; blk += SB) {
+				uint32_t ids[SB];
+				bool valid[SB];
+#pragma unroll
+				for (int s = 0; s < SB; ++s) {
+					const uint32_t i = w_begin + (blk + s) * 64 + lane;
+					ids[s] = min(i, w_end - 1);
+					valid[s] = i < w_end;
+				}
+				submit(ids, valid);
 			}
 		} else {
 			// One bit per sample says whether it touches this chunk.  A wave reads 64 words at once (one word = the ballot of
@@ -199,9 +278,11 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 			const unsigned long long* __restrict__ words =
 				chunk_bits + ((size_t)task.level * SCATTER_MAX_CHUNKS + scatter_chunk(lv, task.entry_begin)) * (n / 64) + w_begin / 64;
 			uint32_t queued = 0; // wave-uniform
+			unsigned long long w_next = lane < n_blocks ? words[lane] : 0ull;
 			for (uint32_t blk0 = 0; blk0 < n_blocks; blk0 += 64) {
 				// one word (= 64 samples) per lane; every round each lane with bits left peels off its lowest one
-				unsigned long long w = blk0 + lane < n_blocks ? words[blk0 + lane] : 0ull;
+				unsigned long long w = w_next;
+				w_next = blk0 + 64 + lane < n_blocks ? words[blk0 + 64 + lane] : 0ull; // in flight while this block is processed
 				const uint32_t base_id = w_begin + (blk0 + lane) * 64;
 				while (true) {
 					const bool has = w != 0;
@@ -213,28 +294,51 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 						w &= w - 1;
 					}
 					queued += __builtin_popcount(blo) + __builtin_popcount(bhi);
-					if (queued >= 64) {
-						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+					if (queued >= 64 * SB) {
+						// the queue is wave-private and LDS serves one wave's instructions in order: compiler barriers suffice
+						// (a memory fence here would also drain the gathers in flight)
+						__atomic_signal_fence(__ATOMIC_SEQ_CST);
 						__builtin_amdgcn_wave_barrier();
-						const uint32_t id = queue[lane];
-						const uint32_t rest = queue[64 + lane];
+						uint32_t ids[SB];
+						bool valid[SB];
+#pragma unroll
+						for (int s = 0; s < SB; ++s) {
+							ids[s] = queue[s * 64 + lane];
+							valid[s] = true;
+						}
+						const uint32_t rest = queue[64 * SB + lane];
 						__builtin_amdgcn_wave_barrier();
-						queued -= 64;
+						queued -= 64 * SB;
 						if (lane < queued) queue[lane] = rest;
-						__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-						submit(id, true);
+						__atomic_signal_fence(__ATOMIC_SEQ_CST);
+						submit(ids, valid);
 					}
 				}
 			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__atomic_signal_fence(__ATOMIC_SEQ_CST);
 			__builtin_amdgcn_wave_barrier();
-			if (queued > 0) submit(lane < queued ? queue[lane] : w_begin, lane < queued);
+			if (queued > 0) {
+				uint32_t ids[SB];
+				bool valid[SB];
+#pragma unroll
+				for (int s = 0; s < SB; ++s) {
+					valid[s] = s * 64 + lane < queued;
+					ids[s] = valid[s] ? queue[s * 64 + lane] : w_begin;
+				}
+				submit(ids, valid);
+			}
 		}
-		if (a_valid) accumulate(ax, ag);
-		if (b_valid) accumulate(bx, bg);
+#pragma unroll
+		for (int s = 0; s < SB; ++s) if (a_valid[s]) accumulate(ax[s], ag[s]);
+	}
+	if (dbg_times && tid == 0) {
+		dbg_times[blockIdx.x * 8 + 4] = t_fetch;
+		dbg_times[blockIdx.x * 8 + 5] = t_acc;
+		dbg_times[blockIdx.x * 8 + 6] = __builtin_readcyclecounter() - t_loop0;
+		dbg_times[blockIdx.x * 8 + 7] = n_sub;
 	}
 	__syncthreads();
-	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+	if (dbg_times && tid == 0) dbg_times[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
 
 	if (task.flush_atomic) {
 		// several workgroups share this chunk: merge the exact partial sums with 64-bit integer atomics; rounded later
@@ -247,12 +351,12 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 		// sole owner: round once and store (two values per 4-byte store; n_vals is even because F >= 2)
 		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 		for (uint32_t i = tid; i < n_vals / 2; i += SCATTER_THREADS) {
-			((h2*)g)[i] = h2{fixed_to_half(acc[2 * i]), fixed_to_half(acc[2 * i + 1])};
+			((h2*)g)[i] = h2{fixed_to_half_fast(acc[2 * i]), fixed_to_half_fast(acc[2 * i + 1])};
 		}
 	}
 	if (dbg_times) {
 		__syncthreads();
-		if (tid == 0) dbg_times[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+		if (tid == 0) dbg_times[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 	}
 }
 
@@ -285,35 +389,35 @@ __global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __res
 	if (lane < n_chunks) bits[((size_t)level * SCATTER_MAX_CHUNKS + lane) * (n / 64) + i / 64] = mine;
 }
 
-template <int D, int F>
+template <int D, int F, bool REC = false>
 void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x, const void* dy, uint32_t dss, uint32_t dsl,
                     void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate) {
 	static bool configured = false;
 	if (!configured) { // more than 64 KiB of dynamic LDS has to be opted into once per kernel
-		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_grid_scatter<D, F>, hipFuncAttributeMaxDynamicSharedMemorySize, SCATTER_LDS_BYTES));
+		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_grid_scatter<D, F, REC>, hipFuncAttributeMaxDynamicSharedMemorySize, SCATTER_LDS_BYTES));
 		configured = true;
 	}
 	// development aid: TCNN_AMD_SCATTER_TIMING=1 prints per-task phase times (100 MHz constant clock) for the 3rd launch
 	static const bool timing = getenv("TCNN_AMD_SCATTER_TIMING") != nullptr;
 	static int timing_left = 3;
 	unsigned long long* dbg = nullptr;
-	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&dbg, (size_t)n_tasks * 4 * 8));
-	hipLaunchKernelGGL((k_grid_scatter<D, F>), dim3(n_tasks), dim3(SCATTER_THREADS), SCATTER_LDS_BYTES, s, dm, tasks, n, x, (const half_t*)dy, dss, dsl, (half_t*)grad, chunk_bits,
+	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&dbg, (size_t)n_tasks * 8 * 8));
+	hipLaunchKernelGGL((k_grid_scatter<D, F, REC>), dim3(n_tasks), dim3(SCATTER_THREADS), SCATTER_LDS_BYTES, s, dm, tasks, n, x, (const half_t*)dy, dss, dsl, (half_t*)grad, chunk_bits,
 	                   scratch, accumulate ? 1 : 0, dbg);
 	HIP_CHECK_THROW(hipGetLastError());
 	if (dbg) {
-		std::vector<unsigned long long> h((size_t)n_tasks * 4);
+		std::vector<unsigned long long> h((size_t)n_tasks * 8);
 		std::vector<GridScatterTask> ht(n_tasks);
 		HIP_CHECK_THROW(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
 		HIP_CHECK_THROW(hipMemcpy(ht.data(), tasks, n_tasks * sizeof(GridScatterTask), hipMemcpyDeviceToHost));
 		unsigned long long t0 = ~0ull;
-		for (uint32_t i = 0; i < n_tasks; ++i) if (ht[i].n_entries) t0 = std::min(t0, h[i * 4]);
+		for (uint32_t i = 0; i < n_tasks; ++i) if (ht[i].n_entries) t0 = std::min(t0, h[i * 8]);
 		if (--timing_left == 0) {
 			for (uint32_t i = 0; i < n_tasks; ++i) {
 				if (!ht[i].n_entries) continue;
-				fprintf(stderr, "task %3u level %2u entries %6u samples %6u atomic %u: start %7.1f zero %6.1f accumulate %6.1f flush %6.1f us\n", i, ht[i].level, ht[i].n_entries,
-				        ht[i].sample_end - ht[i].sample_begin, ht[i].flush_atomic, (h[i * 4] - t0) * 0.01, (h[i * 4 + 1] - h[i * 4]) * 0.01, (h[i * 4 + 2] - h[i * 4 + 1]) * 0.01,
-				        (h[i * 4 + 3] - h[i * 4 + 2]) * 0.01);
+				fprintf(stderr, "task %3u level %2u entries %6u samples %6u atomic %u: start %7.1f zero %6.1f accumulate %6.1f flush %6.1f us | wave0 clocks: fetch %llu acc %llu loop %llu submits %llu\n", i, ht[i].level, ht[i].n_entries,
+				        ht[i].sample_end - ht[i].sample_begin, ht[i].flush_atomic, (h[i * 8] - t0) * 0.01, (h[i * 8 + 1] - h[i * 8]) * 0.01, (h[i * 8 + 2] - h[i * 8 + 1]) * 0.01,
+				        (h[i * 8 + 3] - h[i * 8 + 2]) * 0.01, h[i * 8 + 4], h[i * 8 + 5], h[i * 8 + 6], h[i * 8 + 7]);
 			}
 		}
 		(void)hipFree(dbg);
@@ -322,7 +426,16 @@ void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* ta
 
 template <int D>
 void dispatch_scatter(hipStream_t s, uint32_t F, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x,
-                      const void* dy, uint32_t dss, uint32_t dsl, void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate) {
+                      const void* dy, uint32_t dss, uint32_t dsl, void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate, bool records) {
+	if (records) {
+		if constexpr (D == 2) {
+			if (F == 2) return launch_scatter<D, 2, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
+			if (F == 4) return launch_scatter<D, 4, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
+		} else if constexpr (D == 3) {
+			if (F == 2) return launch_scatter<D, 2, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
+		}
+		throw std::runtime_error{"grid_backward_lds: scatter records need 4 D + 2 F <= 16"};
+	}
 	switch (F) {
 		case 2: return launch_scatter<D, 2>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
 		case 4: return launch_scatter<D, 4>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
@@ -334,6 +447,11 @@ void dispatch_scatter(hipStream_t s, uint32_t F, const GridMeta* dm, const GridS
 } // namespace
 
 uint32_t grid_scatter_max_chunks() { return SCATTER_MAX_CHUNKS; }
+
+bool grid_scatter_records_supported(const GridMeta& meta) {
+	const uint32_t D = meta.n_pos_dims, F = meta.n_features_per_level;
+	return (D == 2 && (F == 2 || F == 4)) || (D == 3 && F == 2);
+}
 
 void grid_scatter_setup_levels(GridMeta& meta) {
 	const uint32_t capacity = SCATTER_ACC_BYTES / (meta.n_features_per_level * 8); // entries one workgroup can own (64-bit accumulators)
@@ -425,14 +543,15 @@ void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatter
 
 void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
-                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate) {
+                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records) {
 	if (n_tasks == 0) return;
 	const unsigned long long* bits = (const unsigned long long*)chunk_bits;
 	unsigned long long* sc = (unsigned long long*)scratch;
+	CHECK_THROW(!dy_records || grid_scatter_records_supported(meta));
 	switch (meta.n_pos_dims) {
-		case 2: dispatch_scatter<2>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate); break;
-		case 3: dispatch_scatter<3>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate); break;
-		case 4: dispatch_scatter<4>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate); break;
+		case 2: dispatch_scatter<2>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
+		case 3: dispatch_scatter<3>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
+		case 4: dispatch_scatter<4>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
 		default: throw std::runtime_error{"GridEncoding: number of input dims must be 2 or 3."};
 	}
 	if (n_ranges > 0) {

@@ -41,6 +41,8 @@ struct TrainArgs {
 	float loss_scale;
 	uint32_t dx_plane_f, n_params;
 	uint32_t image_in_lds;
+	const float* rec_x;     // dL_dx as 16-byte scatter records (mlp_device.h store_dx_record): the samples' coordinates, AoS [n][rec_dims]
+	uint32_t rec_dims;
 	uint32_t x_plane_f;     // 0: x is AoS [n][in_width]; F: x is level planes [in_width / F][n][F] (k_grid_planes.hip)
 };
 
@@ -341,7 +343,16 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					const h4 v = h4{(half_t)o[b][0], (half_t)o[b][1], (half_t)o[b][2], (half_t)o[b][3]};
-					store_dx(a.dL_dx, a.dx_plane_f, a.n, in_w, s0 + 16 * b + c, 16 * ti + 4 * q, v);
+					if (a.rec_x) {
+						const uint32_t sample = s0 + 16 * b + c;
+						float xs[3];
+						xs[0] = a.rec_x[(size_t)sample * a.rec_dims];
+						xs[1] = a.rec_x[(size_t)sample * a.rec_dims + 1];
+						xs[2] = a.rec_dims == 3 ? a.rec_x[(size_t)sample * a.rec_dims + 2] : 0.0f;
+						store_dx_record(a.dL_dx, a.dx_plane_f, a.rec_dims, a.n, sample, 16 * ti + 4 * q, v, xs);
+					} else {
+						store_dx(a.dL_dx, a.dx_plane_f, a.n, in_w, s0 + 16 * b + c, 16 * ti + 4 * q, v);
+					}
 				}
 			}
 		}
@@ -474,11 +485,11 @@ uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n) {
 
 void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
-                     uint32_t dx_plane_features, float* slabs, uint32_t n_params) {
+                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params) {
 	const TrainConfig cfg = pick_config(d);
 	CHECK_THROW(cfg.ok && n % cfg.s == 0);
 	TrainArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)dL_dout, L, (half_t*)dL_dx, slabs, (const h8*)image,
-	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u, x_plane_features};
+	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u, dx_record_x, dx_record_dims, x_plane_features};
 	dispatch_train(stream, d, a, cfg, mlp_train_fused_grid(d, n));
 }
 

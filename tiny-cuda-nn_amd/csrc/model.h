@@ -205,6 +205,7 @@ struct EncodingContext {
 	ArenaBuf dy_dx;       // grid only: float [n][L*F][D]
 	ArenaBuf chunk_mask;  // grid only: uint64 [L][32][n/64] bit planes, which samples touch which scatter chunk (filter for the LDS scatter)
 	uint32_t n = 0;
+	bool dy_records = false; // the level planes handed to backward() hold 16-byte scatter records {coordinates, gradients} (mlp_train_fused)
 };
 
 class Encoding {
@@ -228,6 +229,8 @@ public:
 	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) = 0;
 	// > 0: this encoding's backward prefers dL_dy in level planes with that many features per plane (see k_grid_bwd_lds)
 	virtual uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const { return 0; }
+	// true: backward() (with level planes allowed) prefers 16-byte records {coordinates, gradients} per (level, sample)
+	virtual bool scatter_records_usable(MatView x) const { return false; }
 	// > 0: forward_planes() can write the encoded batch as level planes [padded / F][n][F] (no input gradients in that form)
 	virtual uint32_t forward_plane_features(uint32_t n) { return 0; }
 	virtual EncodingContext forward_planes(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out_planes, bool prepare_param_gradients) {
@@ -441,7 +444,7 @@ public:
 				const uint64_t* mask = (ctx.chunk_mask && ctx.n == n) ? ctx.chunk_mask.as<uint64_t>() : nullptr;
 				grid_backward_lds(stream, m_meta, dev_meta(), plan.dev_tasks.as<GridScatterTask>(), plan.n_tasks, plan.dev_ranges.as<GridScatterRange>(), plan.n_ranges,
 				                  plan.scratch.as<uint64_t>(), n, x, dL_dy, dy_planes ? F : padded_output_width(), dy_planes ? n * F : F, grads, mask,
-				                  mode == GradientMode::Accumulate);
+				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records);
 			} else {
 				CHECK_THROW(!dy_planes);
 				if (mode == GradientMode::Overwrite) HIP_CHECK_THROW(hipMemsetAsync(grads, 0, n_params() * elem, stream)); // grid.h:858
@@ -458,6 +461,14 @@ public:
 	uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const override {
 		const uint32_t F = m_meta.n_features_per_level;
 		return (lds_scatter_usable() && !need_dL_dx && mode != GradientMode::Ignore) ? F : 0;
+	}
+
+	// The MLP kernel writes {coordinates, gradient} records and the scatter does one gather per hit instead of two: measured on
+	// C3a the scatter gains 12 us and the MLP kernel loses 6 us (4x the dX bytes).  TCNN_AMD_SCATTER_RECORDS=0 turns it off.
+	bool scatter_records_usable(MatView x) const override {
+		const char* e = getenv("TCNN_AMD_SCATTER_RECORDS"); // read per step so that tests can cover both forms in one process
+		const bool enabled = !(e && e[0] == '0');
+		return enabled && lds_scatter_usable() && grid_scatter_records_supported(m_meta) && x.stride_dim == 1 && x.stride_sample == m_meta.n_pos_dims;
 	}
 
 	// half precision, F >= 2, and every level's table cut into at most 64 chunks (the sample filter is a uint64)
@@ -898,8 +909,11 @@ public:
 
 		const bool need_dx = m_encoding->n_params() > 0 || dL_dinput;
 		ArenaBuf dL_dnetwork_input;
-		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
 		const uint32_t plane_f = need_dx ? m_encoding->level_plane_features(dL_dinput != nullptr, mode) : 0;
+		// scatter records: the MLP kernel interleaves the samples' coordinates with dL/d(encoding) so that the grid scatter needs one gather per hit
+		const bool records = plane_f > 0 && m_encoding->padded_output_width() == m_encoding->output_width() && m_encoding->scatter_records_usable(input);
+		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, records ? (size_t)n * (m_encoding->output_width() / plane_f) * 16 : (size_t)n * m_encoding->padded_output_width() * 2};
+		ctx->encoding_ctx.dy_records = records;
 
 		ArenaBuf image = m_network->prepare(stream, params, true);
 		const MlpDesc& d = m_network->desc();
@@ -911,7 +925,7 @@ public:
 			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
 		}
 		mlp_train_fused(stream, d, image.data(), n, ctx->network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L,
-		                dL_dnetwork_input.data(), plane_f, slabs.as<float>(), n_net);
+		                dL_dnetwork_input.data(), plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u, slabs.as<float>(), n_net);
 		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
 		if (need_dx) {
 			m_encoding->backward(stream, ctx->encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + n_net, g ? g + n_net : nullptr, mode, plane_f > 0);

@@ -113,7 +113,9 @@ void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta*
 // accumulate = GradientMode::Accumulate.
 void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
-                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate);
+                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records = false);
+// dy_records: dL_dy is float4 [n_levels][n] scatter records {coordinates, F halves} (see mlp_train_fused); x is then not read
+bool grid_scatter_records_supported(const GridMeta& meta);
 void grid_backward_input(hipStream_t stream, const GridMeta& meta, bool fp32, uint32_t n, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
 
 // OneBlob / Identity (AoS output, T = half or float)
@@ -160,9 +162,11 @@ uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n); // workgroups = num
 // target / data_pdf [n][dims] float or external_dL_dy [n][out_width] half (loss-scaled).
 // Writes out, dL_dout, L ([n][out_width]; dL_dout and L only without external_dL_dy), dL_dx (optional; AoS or level planes),
 // and -- if slabs != nullptr -- one fp32 slab of partial weight gradients per workgroup: slabs[grid][n_params].
+// dx_record_x != nullptr (with dx_plane_features = F): dL_dx is written as 16-byte scatter records float4 [in_width / F][n] =
+// {coordinates (dx_record_dims floats, read from dx_record_x [n][dims]), F halves}; needs 4 dims + 2 F <= 16.
 void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
-                     uint32_t dx_plane_features, float* slabs, uint32_t n_params);
+                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params);
 // grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once
 void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate);
 // fully_fused_mlp.cu:757-762: result = dL_dout * act'(out), elementwise over n_elems halfs
