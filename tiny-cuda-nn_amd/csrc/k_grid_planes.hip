@@ -67,10 +67,28 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 			for (int k = 0; k < FP_SPT; ++k) planes[wave][k][lane] = 0ull;
 		}
 
-		// ---- phase 1: positions, indices, all gathers in flight
-		vecF v[FP_SPT][C];
+		// ---- phase 1: positions, indices, all gathers in flight.
+		// A gather costs ~2 clocks per lane per CU whatever its width (tools/ubench/gather.hip), so the two corners of a cell
+		// that differ only in x are fetched as ONE 2-entry load wherever they are neighbours in memory: always for dense-style
+		// levels (index(x + 1) = index(x) + 1), and for hashed levels with prime[0] == 1 when x is even (index(x + 1) =
+		// index(x) ^ 1).  A lane whose second corner is not in the pair issues an extra load; masked-off lanes cost nothing.
+		constexpr int R = C / 2; // rows = corner pairs (x, x + 1)
+		typedef typename VecOf<half_t, 2 * F>::type vecP __attribute__((aligned(2 * F)));
+		vecP P[FP_SPT][R];
+		vecF E[FP_SPT][R];
+		uint32_t sel[FP_SPT]; // per row 3 bits: corner 0 is the pair's high entry | corner 1 is the pair's high entry | corner 1 came by its own load
 		float pos[FP_SPT][D];
 		unsigned long long touched[FP_SPT];
+		auto note_chunk = [&](const int k, const uint32_t index) {
+			const uint32_t ch = scatter_chunk(lv, index);
+			if (lds_or) {
+				// bit `lane` of word [k][ch]; integer LDS atomics run at ~4 lane-ops/clk/CU
+				__hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)&planes[wave][k][ch] + (lane >> 5), 1u << (lane & 31), __ATOMIC_RELAXED,
+				                      __HIP_MEMORY_SCOPE_WAVEFRONT);
+			} else {
+				touched[k] |= 1ull << ch;
+			}
+		};
 #pragma unroll
 		for (int k = 0; k < FP_SPT; ++k) {
 			const uint32_t i = min(base + k * 64 + lane, n - 1); // groups past the end recompute the last sample and store nothing
@@ -81,23 +99,30 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 #pragma unroll
 			for (int d = 0; d < D; ++d) cell[d] = pos_fract(xin[d], lv.scale, interpolation, &pos[k][d], &pd);
 			touched[k] = 0;
+			sel[k] = 0;
 #pragma unroll
-			for (int idx = 0; idx < C; ++idx) {
-				if (idx > 0 && nearest) { v[k][idx] = v[k][0]; continue; }
+			for (int r = 0; r < R; ++r) {
+				if (r > 0 && nearest) { P[k][r] = P[k][0]; E[k][r] = E[k][0]; continue; }
 				uint32_t local[D];
+				local[0] = cell[0];
 #pragma unroll
-				for (int d = 0; d < D; ++d) local[d] = cell[d] + ((idx >> d) & 1);
-				const uint32_t index = level_index<D>(lv, primes, hash_type, local);
-				v[k][idx] = *(const vecF*)&lgrid[(size_t)index * F];
+				for (int d = 1; d < D; ++d) local[d] = cell[d] + ((r >> (d - 1)) & 1);
+				const uint32_t idx0 = level_index<D>(lv, primes, hash_type, local);
+				local[0] = cell[0] + 1;
+				const uint32_t idx1 = nearest ? idx0 : level_index<D>(lv, primes, hash_type, local);
+				const uint32_t a0 = lv.hashed ? (idx0 & ~1u) : min(idx0, lv.size - 2u);
+				P[k][r] = *(const vecP*)&lgrid[(size_t)a0 * F];
+				const uint32_t d1 = idx1 - a0;
+				const bool own = d1 > 1u;
+				vecF e;
+#pragma unroll
+				for (int f = 0; f < F; ++f) { if constexpr (F == 1) e = (half_t)0.0f; else e[f] = (half_t)0.0f; }
+				if (own) e = *(const vecF*)&lgrid[(size_t)idx1 * F];
+				E[k][r] = e;
+				sel[k] |= ((idx0 - a0) | ((d1 & 1u) << 1) | (own ? 4u : 0u)) << (3 * r);
 				if (want_bits) {
-					const uint32_t ch = scatter_chunk(lv, index);
-					if (lds_or) {
-						// bit `lane` of word [k][ch]; integer LDS atomics run at ~4 lane-ops/clk/CU
-						__hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)&planes[wave][k][ch] + (lane >> 5), 1u << (lane & 31), __ATOMIC_RELAXED,
-						                      __HIP_MEMORY_SCOPE_WAVEFRONT);
-					} else {
-						touched[k] |= 1ull << ch;
-					}
+					note_chunk(k, idx0);
+					if (!nearest) note_chunk(k, idx1);
 				}
 			}
 		}
@@ -106,10 +131,20 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 #pragma unroll
 		for (int k = 0; k < FP_SPT; ++k) {
 			const uint32_t i = base + k * 64 + lane;
+			vecF v[C];
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				const uint32_t s = sel[k] >> (3 * r);
+				vecF lo, hi;
+#pragma unroll
+				for (int f = 0; f < F; ++f) { lo[f] = P[k][r][f]; hi[f] = P[k][r][F + f]; }
+				v[2 * r] = (s & 1u) ? hi : lo;
+				v[2 * r + 1] = (s & 4u) ? E[k][r] : ((s & 2u) ? hi : lo);
+			}
 			half_t acc[F];
 			if (nearest) { // grid.h:121-140
 #pragma unroll
-				for (int f = 0; f < F; ++f) { if constexpr (F == 1) acc[f] = v[k][0]; else acc[f] = v[k][0][f]; }
+				for (int f = 0; f < F; ++f) acc[f] = v[0][f];
 			} else {
 #pragma unroll
 				for (int f = 0; f < F; ++f) acc[f] = (half_t)0.0f;
@@ -123,7 +158,7 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 #pragma unroll
 					for (int f = 0; f < F; ++f) {
 						half_t val;
-						if constexpr (F == 1) val = v[k][idx]; else val = v[k][idx][f];
+						val = v[idx][f];
 						acc[f] = __builtin_fmaf16(wh, val, acc[f]);
 					}
 				}
