@@ -555,7 +555,8 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
 		default: throw std::runtime_error{"GridEncoding: number of input dims must be 2 or 3."};
 	}
 	if (n_ranges > 0) {
-		hipLaunchKernelGGL(k_grid_scatter_finalize, dim3(32, n_ranges), dim3(256), 0, stream, dev_ranges, sc, (half_t*)grad, accumulate ? 1 : 0);
+		hipLaunchKernelGGL(k_grid_scatter_finalize, dim3(256, n_ranges), dim3(256), 0, stream, dev_ranges, sc, (half_t*)grad,
+		                   accumulate ? 1 : 0);
 	}
 }
 

@@ -417,22 +417,33 @@ __global__ void __launch_bounds__(256) k_wgrad(
 	}
 }
 
-__global__ void __launch_bounds__(256) k_wgrad_reduce(const uint32_t n_elems, const uint32_t cols, const uint32_t ldg, const uint32_t n_slabs, const float* __restrict__ slabs, half_t* __restrict__ grad, const int accumulate) {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_elems) return;
-	// 8 independent partial sums keep 8 loads in flight (fixed association -> still bitwise reproducible)
-	float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	uint32_t k = 0;
-	for (; k + 8 <= n_slabs; k += 8) {
+// Sum of the per-workgroup slabs.  64 elements x 16 slab groups per workgroup: group g adds slabs g, g + 16, ... with four
+// loads in flight, the 16 group sums are combined through LDS in a fixed order (bitwise reproducible, no atomics).
+constexpr int WR_ELEMS = 64, WR_GROUPS = 16;
+__global__ void __launch_bounds__(WR_ELEMS * WR_GROUPS) k_wgrad_reduce(const uint32_t n_elems, const uint32_t cols, const uint32_t ldg, const uint32_t n_slabs, const float* __restrict__ slabs, half_t* __restrict__ grad, const int accumulate) {
+	__shared__ float part[WR_GROUPS][WR_ELEMS];
+	const uint32_t e = threadIdx.x & (WR_ELEMS - 1), grp = threadIdx.x / WR_ELEMS;
+	const uint32_t i = blockIdx.x * WR_ELEMS + e;
+	float p[4] = {0, 0, 0, 0};
+	if (i < n_elems) {
+		uint32_t k = grp;
+		for (; k + 3 * WR_GROUPS < n_slabs; k += 4 * WR_GROUPS) {
 #pragma unroll
-		for (int u = 0; u < 8; ++u) p[u] += slabs[(size_t)(k + u) * n_elems + i];
+			for (int u = 0; u < 4; ++u) p[u] += slabs[(size_t)(k + u * WR_GROUPS) * n_elems + i];
+		}
+		for (; k < n_slabs; k += WR_GROUPS) p[0] += slabs[(size_t)k * n_elems + i];
 	}
-	for (; k < n_slabs; ++k) p[0] += slabs[(size_t)k * n_elems + i];
-	float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-	const uint32_t row = i / cols, col = i - row * cols;
-	half_t* g = grad + (size_t)row * ldg + col;
-	if (accumulate) s += (float)*g;
-	*g = (half_t)s;
+	part[grp][e] = (p[0] + p[1]) + (p[2] + p[3]);
+	__syncthreads();
+	if (grp == 0 && i < n_elems) {
+		float s = 0;
+#pragma unroll
+		for (int g = 0; g < WR_GROUPS; ++g) s += part[g][e];
+		const uint32_t row = i / cols, col = i - row * cols;
+		half_t* g = grad + (size_t)row * ldg + col;
+		if (accumulate) s += (float)*g;
+		*g = (half_t)s;
+	}
 }
 
 // kernel_activation_backward_output (common_device.h:748): dL/d(pre-activation output) from the forward OUTPUT values
@@ -518,7 +529,7 @@ void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32
 
 void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate) {
 	if (n_params == 0) return;
-	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_params, 256)), dim3(256), 0, stream, n_params, n_params, n_params, n_slabs, slabs, (half_t*)grad_half, accumulate ? 1 : 0);
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_params, (uint32_t)WR_ELEMS)), dim3(WR_ELEMS * WR_GROUPS), 0, stream, n_params, n_params, n_params, n_slabs, slabs, (half_t*)grad_half, accumulate ? 1 : 0);
 }
 
 size_t wgrad_workspace_floats(uint32_t rows, uint32_t cols, uint32_t n) { return (size_t)wgrad_grid(n) * rows * cols; }
@@ -532,7 +543,7 @@ void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uin
 	const size_t shmem = (size_t)WG_CHUNK * ((rows + WG_PAD) + (cols + WG_PAD)) * sizeof(half_t);
 	hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, (const half_t*)dO, ldo, rows, (const half_t*)In, ldi, cols, workspace);
 	const uint32_t n_elems = rows * cols;
-	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_elems, 256)), dim3(256), 0, stream, n_elems, cols, ldg, grid, workspace, (half_t*)grad_half, accumulate ? 1 : 0);
+	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_elems, (uint32_t)WR_ELEMS)), dim3(WR_ELEMS * WR_GROUPS), 0, stream, n_elems, cols, ldg, grid, workspace, (half_t*)grad_half, accumulate ? 1 : 0);
 }
 
 } // namespace tcnn_amd
