@@ -181,15 +181,20 @@ struct AdamArgs {
 
 // debiasing factor of adam.h:97-98
 __device__ inline float adam_debias(const float beta1, const float beta2, uint32_t step) { return sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step)); }
-// out of line: only parameters whose own step count differs from the optimizer's take this path
-__device__ __noinline__ float adam_debias_slow(const float beta1, const float beta2, uint32_t step) { return adam_debias(beta1, beta2, step); }
 
-// One parameter, branch-free on the common path (selects instead of early returns, so that a wave whose lanes disagree about
-// "skipped" does not execute the body twice).  common_debias = adam_debias(common_step) is evaluated once per thread: nearly all
-// parameters share the optimizer's step count, and two powf per parameter would make the kernel ALU-bound.
+// table[t] = adam_debias(t) for t in [from, to): the factor depends on (beta1, beta2, t) only.  Evaluating it per parameter
+// (two powf, ~300 instructions) made the kernel ALU-bound, and more so with every step: a grid parameter that misses one
+// update (zero gradient) has a step count of its own from then on, so after a few dozen steps almost every parameter does.
+__global__ void __launch_bounds__(256) k_adam_debias_table(const float beta1, const float beta2, const uint32_t from, const uint32_t to, float* __restrict__ table) {
+	const uint32_t t = from + blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < to) table[t] = adam_debias(beta1, beta2, t);
+}
+
+// One parameter, branch-free (selects instead of early returns, so that a wave whose lanes disagree about "skipped" does not
+// execute the body twice).  common_debias = debias_table[common_step]; parameters with their own step count look theirs up.
 // `updated` reports whether adam.h:76-84 lets this parameter through.
-__device__ inline void adam_one(const AdamArgs& a, const float common_debias, const bool is_matrix, const half_t g_h, float& w_fp, half_t& w_h, float& m1, float& m2, uint32_t& step,
-                                bool& updated) {
+__device__ inline void adam_one(const AdamArgs& a, const float* __restrict__ debias_table, const float common_debias, const bool is_matrix, const half_t g_h, float& w_fp, half_t& w_h,
+                                float& m1, float& m2, uint32_t& step, bool& updated) {
 	// loss_scale is a power of two in practice (128): the reciprocal multiply is then exact, i.e. identical to the division
 	float gradient = a.inv_loss_scale_exact ? (float)g_h * a.inv_loss_scale : (float)g_h / a.loss_scale;
 	updated = is_matrix ? a.optimize_matrix_params != 0 : (a.optimize_non_matrix_params != 0 && gradient != 0);
@@ -202,7 +207,7 @@ __device__ inline void adam_one(const AdamArgs& a, const float common_debias, co
 	if (!is_matrix) learning_rate *= a.non_matrix_learning_rate_factor;
 	const uint32_t current_step = step + 1;
 	float debias = common_debias;
-	if (__builtin_expect(updated && current_step != a.common_step, 0)) debias = adam_debias_slow(a.beta1, a.beta2, current_step);
+	if (updated && current_step != a.common_step) debias = debias_table[min(current_step, a.common_step)]; // a parameter never has more steps than the optimizer
 	learning_rate *= debias;
 	const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), a.lower_lr_bound), a.upper_lr_bound);
 	// weight_decay(rel * lr, abs * lr, w), common_device.h:870-873
@@ -222,10 +227,11 @@ constexpr int ADAM_Q = 1; // quads (of 4 parameters) per thread, one block-width
 template <bool QUAD_UNIFORM>
 __global__ void __launch_bounds__(256) k_adam(
 	const AdamArgs a, const size_t n, const size_t n_matrix,
-	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps
+	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps,
+	const float* __restrict__ debias_table
 ) {
 	const size_t base = (size_t)blockIdx.x * (256 * 4 * ADAM_Q) + threadIdx.x * 4;
-	__shared__ float s_debias;
+	const float debias = debias_table[a.common_step];
 	// phase 1: the gradients of all quads (8 B each).  Grid (non-matrix) quads whose 4 gradients are all zero are skipped
 	// without touching the other 32 B/param (adam.h:76-79 returns before reading anything else).
 	h4 gv[ADAM_Q];
@@ -242,11 +248,6 @@ __global__ void __launch_bounds__(256) k_adam(
 		const bool zero = gv[q][0] == (half_t)0.0f && gv[q][1] == (half_t)0.0f && gv[q][2] == (half_t)0.0f && gv[q][3] == (half_t)0.0f;
 		if (live[q] && i4 >= n_matrix && zero) live[q] = false;
 	}
-	// the common debiasing factor (two powf, ~300 instructions) is evaluated by one wave per workgroup while the loads fly
-	if (threadIdx.x < 64) {
-		const float d = adam_debias(a.beta1, a.beta2, a.common_step);
-		if (threadIdx.x == 0) s_debias = d;
-	}
 	// phase 2: all remaining loads in flight together
 	float4 wf[ADAM_Q], a1[ADAM_Q], a2[ADAM_Q];
 	uint4 st[ADAM_Q];
@@ -260,8 +261,6 @@ __global__ void __launch_bounds__(256) k_adam(
 			st[q] = *(const uint4*)(steps + i4);
 		}
 	}
-	__syncthreads();
-	const float debias = s_debias;
 #pragma unroll
 	for (int q = 0; q < ADAM_Q; ++q) {
 		const size_t i4 = base + (size_t)q * 1024;
@@ -269,10 +268,10 @@ __global__ void __launch_bounds__(256) k_adam(
 			half_t wh[4];
 			bool up[4];
 			const bool quad_matrix = i4 < n_matrix;
-			adam_one(a, debias, QUAD_UNIFORM ? quad_matrix : i4 + 0 < n_matrix, gv[q][0], wf[q].x, wh[0], a1[q].x, a2[q].x, st[q].x, up[0]);
-			adam_one(a, debias, QUAD_UNIFORM ? quad_matrix : i4 + 1 < n_matrix, gv[q][1], wf[q].y, wh[1], a1[q].y, a2[q].y, st[q].y, up[1]);
-			adam_one(a, debias, QUAD_UNIFORM ? quad_matrix : i4 + 2 < n_matrix, gv[q][2], wf[q].z, wh[2], a1[q].z, a2[q].z, st[q].z, up[2]);
-			adam_one(a, debias, QUAD_UNIFORM ? quad_matrix : i4 + 3 < n_matrix, gv[q][3], wf[q].w, wh[3], a1[q].w, a2[q].w, st[q].w, up[3]);
+			adam_one(a, debias_table, debias,QUAD_UNIFORM ? quad_matrix : i4 + 0 < n_matrix, gv[q][0], wf[q].x, wh[0], a1[q].x, a2[q].x, st[q].x, up[0]);
+			adam_one(a, debias_table, debias,QUAD_UNIFORM ? quad_matrix : i4 + 1 < n_matrix, gv[q][1], wf[q].y, wh[1], a1[q].y, a2[q].y, st[q].y, up[1]);
+			adam_one(a, debias_table, debias,QUAD_UNIFORM ? quad_matrix : i4 + 2 < n_matrix, gv[q][2], wf[q].z, wh[2], a1[q].z, a2[q].z, st[q].z, up[2]);
+			adam_one(a, debias_table, debias,QUAD_UNIFORM ? quad_matrix : i4 + 3 < n_matrix, gv[q][3], wf[q].w, wh[3], a1[q].w, a2[q].w, st[q].w, up[3]);
 			*(float4*)(w_fp + i4) = wf[q];
 			*(float4*)(m1 + i4) = a1[q];
 			*(float4*)(m2 + i4) = a2[q];
@@ -287,7 +286,7 @@ __global__ void __launch_bounds__(256) k_adam(
 			for (size_t i = i4; i < n; ++i) {
 				bool up;
 				half_t wh;
-				adam_one(a, debias, i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
+				adam_one(a, debias_table, debias,i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
 				if (up) w[i] = wh;
 			}
 		}
@@ -423,7 +422,7 @@ void reduce_sum(hipStream_t stream, size_t n, const float* values, float* partia
 }
 
 void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
-               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps) {
+               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps, const float* debias_table) {
 	if (n == 0) return;
 	AdamArgs a;
 	a.relative_weight_decay = h.relative_decay;
@@ -449,8 +448,13 @@ void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix
 	a.inv_loss_scale_exact = (std::frexp(loss_scale, &exponent) == 0.5f && loss_scale >= 1.0f / 65536 && loss_scale <= 65536.0f) ? 1 : 0;
 	a.inv_loss_scale = 1.0f / loss_scale;
 	const dim3 grid(blocks_for((n + 3) / 4, 256 * ADAM_Q));
-	if (n_matrix % 4 == 0) hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps);
-	else hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps);
+	if (n_matrix % 4 == 0) hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
+	else hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
+}
+
+void adam_fill_debias_table(hipStream_t stream, float beta1, float beta2, uint32_t from, uint32_t to, float* table) {
+	if (to <= from) return;
+	hipLaunchKernelGGL(k_adam_debias_table, dim3(blocks_for(to - from, 256)), dim3(256), 0, stream, beta1, beta2, from, to, table);
 }
 
 namespace {

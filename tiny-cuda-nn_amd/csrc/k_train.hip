@@ -117,6 +117,31 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 	const uint32_t n_trips = a.n / S;
 	const uint32_t row0 = wave * NB * 16; // this wave's first row inside the LDS images
 
+	// 8 consecutive input features k0..k0+7 of one sample (the B operand of layer 0), from the AoS matrix or from level planes
+	auto load_x = [&](const uint32_t sample, const uint32_t k0) -> h8 {
+		if (a.x_plane_f == 2) { // four 4-byte loads, each a dense 64-byte run per 16 lanes
+			uint4 v;
+			v.x = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 0) * a.n + sample) * 2);
+			v.y = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 1) * a.n + sample) * 2);
+			v.z = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 2) * a.n + sample) * 2);
+			v.w = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 3) * a.n + sample) * 2);
+			return __builtin_bit_cast(h8, v);
+		} else if (a.x_plane_f == 4) {
+			const uint2 lo = *(const uint2*)(a.x + ((size_t)(k0 / 4) * a.n + sample) * 4);
+			const uint2 hi = *(const uint2*)(a.x + ((size_t)(k0 / 4 + 1) * a.n + sample) * 4);
+			uint4 v;
+			v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+			return __builtin_bit_cast(h8, v);
+		} else if (a.x_plane_f == 8) {
+			return *(const h8*)(a.x + ((size_t)(k0 / 8) * a.n + sample) * 8);
+		}
+		return *(const h8*)(a.x + (size_t)sample * in_w + k0);
+	};
+	// The first k-step of the NEXT trip's input is requested while this trip's weight-gradient phase runs: all waves of a
+	// workgroup start a trip together, so nobody else would cover that latency.
+	h8 pre[NB];
+	bool have_pre = false;
+
 	for (uint32_t trip = blockIdx.x; trip < n_trips; trip += gridDim.x) {
 		const uint32_t s0 = trip * S + row0; // first sample of this wave
 
@@ -135,23 +160,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					if (k0 < in_w) {
-						const uint32_t sample = s0 + 16 * b + c;
-						if (a.x_plane_f == 2) { // four 4-byte loads, each a dense 64-byte run per 16 lanes
-							typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-							u4 v;
-#pragma unroll
-							for (int p = 0; p < 4; ++p) v[p] = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + p) * a.n + sample) * 2);
-							bf[b] = __builtin_bit_cast(h8, v);
-						} else if (a.x_plane_f == 4) {
-							const uint2 lo = *(const uint2*)(a.x + ((size_t)(k0 / 4) * a.n + sample) * 4);
-							const uint2 hi = *(const uint2*)(a.x + ((size_t)(k0 / 4 + 1) * a.n + sample) * 4);
-							typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-							bf[b] = __builtin_bit_cast(h8, (u4{lo.x, lo.y, hi.x, hi.y}));
-						} else if (a.x_plane_f == 8) {
-							bf[b] = *(const h8*)(a.x + ((size_t)(k0 / 8) * a.n + sample) * 8);
-						} else {
-							bf[b] = *(const h8*)(a.x + (size_t)sample * in_w + k0);
-						}
+						bf[b] = (s == 0 && have_pre) ? pre[b] : load_x(s0 + 16 * b + c, k0);
 						*(h8*)(lds + xs_off + (row0 + 16 * b + c) * xs_stride + k0) = bf[b];
 					} else {
 						bf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -354,6 +363,15 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 						store_dx(a.dL_dx, a.dx_plane_f, a.n, in_w, s0 + 16 * b + c, 16 * ti + 4 * q, v);
 					}
 				}
+			}
+		}
+
+		{ // request the next trip's input now (see `pre` above)
+			const uint32_t next = trip + gridDim.x;
+			have_pre = next < n_trips;
+			if (have_pre && 8 * q < in_w) {
+#pragma unroll
+				for (int b = 0; b < NB; ++b) pre[b] = load_x(next * S + row0 + 16 * b + c, 8 * q);
 			}
 		}
 

@@ -1020,8 +1020,26 @@ public:
 
 	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) { // adam.h:150-188
 		++m_current_step;
+		ensure_debias_table(stream);
 		adam_step(stream, m_h, m_n_weights, m_n_matrix, loss_scale, m_current_step, weights_full_precision, weights, gradients,
-		          m_first_moments.as<float>(), m_second_moments.as<float>(), m_param_steps.as<uint32_t>());
+		          m_first_moments.as<float>(), m_second_moments.as<float>(), m_param_steps.as<uint32_t>(), m_debias.as<float>());
+	}
+
+	// debias factors for steps [0, m_debias_filled), computed ahead in blocks of 4096 steps; refilled when the betas change
+	void ensure_debias_table(hipStream_t stream) {
+		const bool stale = m_debias_beta1 != m_h.beta1 || m_debias_beta2 != m_h.beta2;
+		if (!stale && m_current_step < m_debias_filled) return;
+		const uint32_t want = next_multiple(m_current_step + 1, 4096u) + 4096u;
+		if ((size_t)want * sizeof(float) > m_debias.bytes()) {
+			HIP_CHECK_THROW(hipStreamSynchronize(stream)); // the old table may still be in use
+			m_debias.resize((size_t)want * 2 * sizeof(float));
+			m_debias_filled = 0;
+		}
+		const uint32_t from = stale ? 0u : m_debias_filled;
+		adam_fill_debias_table(stream, m_h.beta1, m_h.beta2, from, want, m_debias.as<float>());
+		m_debias_filled = want;
+		m_debias_beta1 = m_h.beta1;
+		m_debias_beta2 = m_h.beta2;
 	}
 
 	void update_hyperparams(const Json& p) { // adam.h:210-258
@@ -1068,7 +1086,9 @@ public:
 private:
 	AdamHyper m_h;
 	size_t m_n_weights = 0, m_n_matrix = 0;
-	DeviceBuf m_first_moments, m_second_moments, m_param_steps;
+	DeviceBuf m_first_moments, m_second_moments, m_param_steps, m_debias;
+	uint32_t m_debias_filled = 0;
+	float m_debias_beta1 = -1.0f, m_debias_beta2 = -1.0f;
 	uint32_t m_current_step = 0;
 };
 
