@@ -69,12 +69,59 @@ __global__ void __launch_bounds__(256) k_mlp_prep(const MlpDesc d, const half_t*
 // forward
 // ------------------------------------------------------------------------------------------------------------------
 struct FwdArgs {
-	const half_t* x;      // [n][in_width]
-	half_t* out;          // [n][out_width]
+	const half_t* x;      // [n][in_width], or level planes [in_width / F][n][F] when x_plane_f = F > 0; unused with x_f32
+	half_t* out;          // optional [n][out_width]
 	half_t* hidden;       // optional [n_hidden][n][width]
 	const h8* image;      // forward fragments
 	uint32_t n;
+	uint32_t x_plane_f;
+	// fused Identity encoding (identity.h:46-66): feature k = (half)(x[k] * scale + offset) for k < x_f32_dims, 1 for the padding
+	MatView x_f32;        // data == nullptr: not used
+	uint32_t x_f32_dims;
+	float x_scale, x_offset;
+	// fused trim_and_cast (common_device.h:990-1002): float output of the first out_f32_dims outputs
+	MatViewMut out_f32;   // data == nullptr: not used
+	uint32_t out_f32_dims;
 };
+
+// 8 consecutive input features k0..k0+7 of one sample: the B operand of layer 0
+__device__ inline h8 load_mlp_input(const FwdArgs& a, const uint32_t in_w, const uint32_t sample, const uint32_t k0) {
+	if (a.x_f32.data) {
+		h8 v;
+		if (a.x_f32.stride_dim == 1 && (a.x_f32.stride_sample & 3u) == 0 && k0 + 8 <= a.x_f32_dims) { // two 16-byte loads
+			const float4* p = (const float4*)(a.x_f32.data + (size_t)sample * a.x_f32.stride_sample + k0);
+			const float4 lo = p[0], hi = p[1];
+			v[0] = (half_t)(lo.x * a.x_scale + a.x_offset); v[1] = (half_t)(lo.y * a.x_scale + a.x_offset);
+			v[2] = (half_t)(lo.z * a.x_scale + a.x_offset); v[3] = (half_t)(lo.w * a.x_scale + a.x_offset);
+			v[4] = (half_t)(hi.x * a.x_scale + a.x_offset); v[5] = (half_t)(hi.y * a.x_scale + a.x_offset);
+			v[6] = (half_t)(hi.z * a.x_scale + a.x_offset); v[7] = (half_t)(hi.w * a.x_scale + a.x_offset);
+			return v;
+		}
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const uint32_t k = k0 + j;
+			v[j] = k < a.x_f32_dims ? (half_t)(a.x_f32.data[(size_t)sample * a.x_f32.stride_sample + (size_t)k * a.x_f32.stride_dim] * a.x_scale + a.x_offset) : (half_t)1.0f;
+		}
+		return v;
+	}
+	if (a.x_plane_f == 2) {
+		uint4 v;
+		v.x = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 0) * a.n + sample) * 2);
+		v.y = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 1) * a.n + sample) * 2);
+		v.z = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 2) * a.n + sample) * 2);
+		v.w = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 3) * a.n + sample) * 2);
+		return __builtin_bit_cast(h8, v);
+	}
+	if (a.x_plane_f == 4) {
+		const uint2 lo = *(const uint2*)(a.x + ((size_t)(k0 / 4) * a.n + sample) * 4);
+		const uint2 hi = *(const uint2*)(a.x + ((size_t)(k0 / 4 + 1) * a.n + sample) * 4);
+		uint4 v;
+		v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+		return __builtin_bit_cast(h8, v);
+	}
+	if (a.x_plane_f == 8) return *(const h8*)(a.x + ((size_t)(k0 / 8) * a.n + sample) * 8);
+	return *(const h8*)(a.x + (size_t)sample * in_w + k0);
+}
 
 // pack NB accumulator column blocks of T row tiles into chained B fragments (KS k-steps), applying the activation
 template <int T, int KS, int NB, int ACT>
@@ -123,7 +170,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs 
 				const uint32_t k0 = 32 * s + 8 * q;
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
-					if (k0 < in_w) bf[b] = *(const h8*)(a.x + (size_t)(s0 + 16 * b + c) * in_w + k0);
+					if (k0 < in_w) bf[b] = load_mlp_input(a, in_w, s0 + 16 * b + c, k0);
 					else bf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
 				}
 #pragma unroll
@@ -190,7 +237,17 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs 
 					h4 v;
 #pragma unroll
 					for (int r = 0; r < 4; ++r) v[r] = activation_fwd(d.output_activation, (half_t)o[b][r]);
-					*(h4*)(a.out + (size_t)(s0 + 16 * b + c) * out_w + 16 * to + 4 * q) = v;
+					const uint32_t sample = s0 + 16 * b + c, j0 = 16 * to + 4 * q;
+					if (a.out) *(h4*)(a.out + (size_t)sample * out_w + j0) = v;
+					if (a.out_f32.data) {
+						if (a.out_f32.stride_dim == 1 && (a.out_f32.stride_sample & 3u) == 0 && j0 + 4 <= a.out_f32_dims) {
+							*(float4*)(a.out_f32.data + (size_t)sample * a.out_f32.stride_sample + j0) = float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+						} else {
+#pragma unroll
+							for (int r = 0; r < 4; ++r)
+								if (j0 + r < a.out_f32_dims) a.out_f32.data[(size_t)sample * a.out_f32.stride_sample + (size_t)(j0 + r) * a.out_f32.stride_dim] = (float)v[r];
+						}
+					}
 				}
 			}
 		}
@@ -493,10 +550,20 @@ void mlp_prepare_weights(hipStream_t stream, const MlpDesc& d, const void* param
 }
 
 void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, void* out, void* hidden) {
+	MlpIo io{};
+	io.x_half = x;
+	io.out_half = out;
+	mlp_forward_io(stream, d, image, n, io, hidden);
+}
+
+void mlp_forward_io(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const MlpIo& io, void* hidden) {
 	CHECK_THROW(n % BATCH_SIZE_GRANULARITY == 0);
 	CHECK_THROW(d.n_hidden >= 1);
+	CHECK_THROW(io.x_half != nullptr || io.x_f32.data != nullptr);
+	CHECK_THROW(io.out_half != nullptr || io.out_f32.data != nullptr);
 	if (n == 0) return;
-	FwdArgs a{(const half_t*)x, (half_t*)out, (half_t*)hidden, (const h8*)image, n};
+	FwdArgs a{(const half_t*)io.x_half, (half_t*)io.out_half, (half_t*)hidden, (const h8*)image, n, io.x_plane_features,
+	          io.x_f32, io.x_f32_dims, io.x_scale, io.x_offset, io.out_f32, io.out_f32_dims};
 	switch (d.width) {
 		case 16: return launch_fwd_act<16, nb_for_width(16)>(stream, d, a, mlp_grid(n, nb_for_width(16)));
 		case 32: return launch_fwd_act<32, nb_for_width(32)>(stream, d, a, mlp_grid(n, nb_for_width(32)));

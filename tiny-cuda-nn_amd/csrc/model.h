@@ -229,6 +229,8 @@ public:
 	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) = 0;
 	// > 0: this encoding's backward prefers dL_dy in level planes with that many features per plane (see k_grid_bwd_lds)
 	virtual uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const { return 0; }
+	// true: the encoding is half(x * scale + offset) padded with ones -- cheap enough to apply inside the consumer's load
+	virtual bool as_identity(float& scale, float& offset) const { return false; }
 	// true: backward() (with level planes allowed) prefers 16-byte records {coordinates, gradients} per (level, sample)
 	virtual bool scatter_records_usable(MatView x) const { return false; }
 	// > 0: forward_planes() can write the encoded batch as level planes [padded / F][n][F] (no input gradients in that form)
@@ -566,6 +568,11 @@ public:
 	IdentityEncoding(uint32_t n_dims_to_encode, float scale, float offset, bool fp32) : Encoding{fp32}, m_n_dims{n_dims_to_encode}, m_scale{scale}, m_offset{offset} {}
 	uint32_t input_width() const override { return m_n_dims; }
 	uint32_t output_width() const override { return m_n_dims; }
+	bool as_identity(float& scale, float& offset) const override {
+		scale = m_scale;
+		offset = m_offset;
+		return !m_fp32;
+	}
 	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
 		if (out && padded_output_width() > 0) identity_forward(stream, m_fp32, n, m_n_dims, m_scale, m_offset, x, out, padded_output_width());
 		return {};
@@ -713,6 +720,11 @@ public:
 		ArenaBuf image = prepare(stream, params, false);
 		mlp_forward(stream, m_desc, image.data(), n, input, output, nullptr);
 	}
+	// inference with the input / output conversions fused into the kernel (see MlpIo)
+	void inference_io(hipStream_t stream, uint32_t n, const MlpIo& io, const void* params) const {
+		ArenaBuf image = prepare(stream, params, false);
+		mlp_forward_io(stream, m_desc, image.data(), n, io, nullptr);
+	}
 
 	NetworkContext forward(hipStream_t stream, uint32_t n, const void* input, void* output, const void* params) const {
 		NetworkContext ctx;
@@ -799,6 +811,15 @@ public:
 	virtual std::vector<std::pair<uint32_t, uint32_t>> layer_sizes() const = 0;
 	virtual void initialize_params(Pcg32& rng, float* params_full_precision, float scale) = 0;
 	virtual void inference(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params) = 0;
+	// float output of the unpadded width (object.h:147-176: inference + trim_and_cast_from); models may fuse the conversion
+	virtual void inference_f32(hipStream_t stream, uint32_t n, MatView input, MatViewMut output, const void* params) {
+		check_batch(n);
+		if (n == 0) return;
+		const uint32_t pw = padded_output_width();
+		ArenaBuf tmp{stream, (size_t)n * pw * (precision() == Precision::Fp32 ? 4 : 2)};
+		inference(stream, n, input, tmp.data(), params);
+		trim_and_cast(stream, precision() == Precision::Fp32, n, pw, output_width(), tmp.data(), output);
+	}
 	virtual std::unique_ptr<ModelContext> forward(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params, bool prepare_input_gradients) = 0;
 	virtual void backward(hipStream_t stream, const ModelContext& ctx, uint32_t n, MatView input, const void* output, const void* dL_doutput,
 	                      MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) = 0;
@@ -836,12 +857,40 @@ public:
 	}
 
 	void inference(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params) override {
+		inference_fused(stream, n, input, output, nullptr, params);
+	}
+	void inference_f32(hipStream_t stream, uint32_t n, MatView input, MatViewMut output, const void* params) override {
+		inference_fused(stream, n, input, nullptr, &output, params);
+	}
+
+	// object.h:147-176 for this model, with as few passes over memory as the kernels allow: an Identity encoding is applied
+	// inside the MLP kernel's input load, a grid is evaluated into level planes by the XCD-aware kernel, and the float
+	// output (trim_and_cast_from) is written by the MLP kernel itself.
+	void inference_fused(hipStream_t stream, uint32_t n, MatView input, void* output_half, const MatViewMut* output_f32, const void* params) {
 		check_batch(n);
 		if (n == 0) return;
 		const _Float16* p = (const _Float16*)params;
-		ArenaBuf network_input{stream, (size_t)n * m_encoding->padded_output_width() * 2};
-		m_encoding->forward(stream, n, input, p + m_network->n_params(), network_input.data(), false, false);
-		m_network->inference(stream, n, network_input.data(), output, p);
+		MlpIo io{};
+		io.out_half = output_half;
+		if (output_f32) {
+			io.out_f32 = *output_f32;
+			io.out_f32_dims = m_network->output_width();
+		}
+		ArenaBuf network_input;
+		float scale = 1, offset = 0;
+		if (m_encoding->as_identity(scale, offset)) {
+			io.x_f32 = input;
+			io.x_f32_dims = m_encoding->input_width();
+			io.x_scale = scale;
+			io.x_offset = offset;
+		} else {
+			network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
+			io.x_half = network_input.data();
+			io.x_plane_features = m_encoding->forward_plane_features(n);
+			if (io.x_plane_features) m_encoding->forward_planes(stream, n, input, p + m_network->n_params(), network_input.data(), false);
+			else m_encoding->forward(stream, n, input, p + m_network->n_params(), network_input.data(), false, false);
+		}
+		m_network->inference_io(stream, n, io, p);
 	}
 
 	struct Ctx : public ModelContext {
@@ -1216,10 +1265,7 @@ public:
 	void inference(hipStream_t stream, uint32_t n, MatView input, MatViewMut output, bool use_inference_params) { // object.h:147-176
 		Model::check_batch(n);
 		if (n == 0) return;
-		const uint32_t pw = m_model->padded_output_width();
-		ArenaBuf tmp{stream, (size_t)n * pw * 2};
-		m_model->inference(stream, n, input, tmp.data(), m_params.data());
-		trim_and_cast(stream, false, n, pw, m_model->output_width(), tmp.data(), output);
+		m_model->inference_f32(stream, n, input, output, m_params.data());
 	}
 
 	void set_params_full_precision(const float* params, size_t n_params, bool device_ptr) { // trainer.h:242-254

@@ -150,6 +150,21 @@ size_t mlp_image_bytes(const MlpDesc& d);   // bytes of fwd+bwd images
 void mlp_prepare_weights(hipStream_t stream, const MlpDesc& d, const void* params, void* image, bool want_bwd);
 // x: [n][in_width] half AoS; out: [n][out_width] half; hidden (optional): [n_hidden][n][width] half post-activation
 void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, void* out, void* hidden);
+// The same kernel with its input / output conversions fused in (inference path):
+//   input : x_half AoS [n][in_width], or level planes [in_width / F][n][F] (x_plane_features = F), or -- x_f32.data != nullptr --
+//           the float matrix itself with the Identity encoding applied on the fly ((half)(x * scale + offset), padding = 1);
+//   output: out_half [n][out_width] and / or out_f32: the first out_f32_dims outputs as floats (trim_and_cast, object.cu:61-67).
+struct MlpIo {
+	const void* x_half;
+	uint32_t x_plane_features;
+	MatView x_f32;
+	uint32_t x_f32_dims;
+	float x_scale, x_offset;
+	void* out_half;
+	MatViewMut out_f32;
+	uint32_t out_f32_dims;
+};
+void mlp_forward_io(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const MlpIo& io, void* hidden);
 // Reference-shaped backward: dL_dout [n][out_width]; hidden from mlp_forward; writes dhidden [n_hidden][n][width] and (optional) dL_dx [n][in_width]
 // dx_plane_features = 0: dL_dx is AoS [n][in_width]; = F > 0: "level planes" [in_width / F][n][F] (what the grid scatter reads)
 void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* dL_dout, const void* out, const void* hidden, void* dhidden, void* dL_dx,
