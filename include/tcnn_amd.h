@@ -48,6 +48,10 @@ extern "C" {
 #define TCNN_LOG_ERROR 3
 #define TCNN_LOG_SUCCESS 4
 
+#define TCNN_MEMCPY_HOST_TO_DEVICE 1
+#define TCNN_MEMCPY_DEVICE_TO_HOST 2
+#define TCNN_MEMCPY_DEVICE_TO_DEVICE 3
+
 typedef struct tcnn_module_s* tcnn_module_t;       /* tcnn::cpp::Module            cpp_api.h:86-111 */
 typedef struct tcnn_context_s* tcnn_context_t;     /* tcnn::cpp::Context           cpp_api.h:82-84  */
 typedef struct tcnn_trainer_s* tcnn_trainer_t;     /* tcnn::TrainableModel         config.h:46-51   */
@@ -66,6 +70,14 @@ int      tcnn_has_networks(void);                       /* cpp_api.cu:47  */
 float    tcnn_default_loss_scale(int precision);        /* cpp_api.cu:55  */
 int      tcnn_preferred_precision(void);                /* cpp_api.cu:60  */
 void     tcnn_set_log_callback(void (*callback)(int severity, const char* message, void* user), void* user); /* cpp_api.cu:61 */
+
+/* ---- device memory and stream helpers for callers that do not link the HIP runtime themselves: what GPUMemory<T>
+ * (gpu_memory.h:60-392) and GPUMatrix<T> (gpu_matrix.h:417-470) need from a runtime; used by include/tiny-cuda-nn/ ---- */
+int tcnn_gpu_malloc(size_t bytes, void** out);                              /* gpu_memory.h:93-112  allocate_memory */
+int tcnn_gpu_free(void* ptr);                                               /* gpu_memory.h:114-130 free_memory */
+int tcnn_gpu_memcpy(void* dst, const void* src, size_t bytes, int kind);    /* gpu_memory.h:183-260 copy_from_host / copy_to_host */
+int tcnn_gpu_memset(void* ptr, int value, size_t bytes);                    /* gpu_memory.h:171-181 memset */
+int tcnn_stream_synchronize(tcnn_stream_t stream);
 
 /* ---- factories, cpp_api.h:113-115 / cpp_api.cu:146-165.  The caller owns the returned module. ---- */
 int  tcnn_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims, const char* encoding_json, const char* network_json, tcnn_module_t* out);

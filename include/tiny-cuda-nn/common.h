@@ -1,0 +1,3 @@
+// common.h -- same include path as the reference (include/tiny-cuda-nn/common.h); the declarations live in tcnn_api.h.
+#pragma once
+#include "tcnn_api.h"

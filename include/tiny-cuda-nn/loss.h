@@ -1,0 +1,3 @@
+// loss.h -- same include path as the reference (include/tiny-cuda-nn/loss.h); the declarations live in tcnn_api.h.
+#pragma once
+#include "tcnn_api.h"

@@ -1,0 +1,3 @@
+// object.h -- same include path as the reference (include/tiny-cuda-nn/object.h); the declarations live in tcnn_api.h.
+#pragma once
+#include "tcnn_api.h"

@@ -71,6 +71,30 @@ int tcnn_set_device(int device) {
 }
 
 void tcnn_free_temporary_memory(void) { Arena::instance().release_all(); }
+
+/* device memory for callers that do not link the HIP runtime themselves (GPUMemory<T>, gpu_memory.h:60-392) */
+int tcnn_gpu_malloc(size_t bytes, void** out) {
+	return guarded([&] {
+		CHECK_THROW(out != nullptr);
+		*out = nullptr;
+		if (bytes) HIP_CHECK_THROW(hipMalloc(out, bytes));
+	});
+}
+int tcnn_gpu_free(void* ptr) {
+	return guarded([&] { if (ptr) HIP_CHECK_THROW(hipFree(ptr)); });
+}
+int tcnn_gpu_memcpy(void* dst, const void* src, size_t bytes, int kind) {
+	return guarded([&] {
+		const hipMemcpyKind k = kind == TCNN_MEMCPY_HOST_TO_DEVICE ? hipMemcpyHostToDevice : kind == TCNN_MEMCPY_DEVICE_TO_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+		if (bytes) HIP_CHECK_THROW(hipMemcpy(dst, src, bytes, k));
+	});
+}
+int tcnn_gpu_memset(void* ptr, int value, size_t bytes) {
+	return guarded([&] { if (bytes) HIP_CHECK_THROW(hipMemset(ptr, value, bytes)); });
+}
+int tcnn_stream_synchronize(tcnn_stream_t stream) {
+	return guarded([&] { HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)stream)); });
+}
 int tcnn_has_networks(void) { return 1; }
 float tcnn_default_loss_scale(int precision) { return precision == TCNN_PRECISION_FP32 ? 1.0f : LOSS_SCALE_FP16; }
 int tcnn_preferred_precision(void) { return TCNN_PRECISION_FP16; }

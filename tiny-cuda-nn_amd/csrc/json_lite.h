@@ -1,300 +1,3 @@
-// json_lite.h -- a small self-contained JSON value (parse / query / dump) for config handling.
-//
-// The reference passes nlohmann::json objects through its factories (config.h:53, cpp_api.h:113-115).  This library's
-// boundary is a C ABI that takes JSON *text*; this header is all the JSON we need behind that boundary:
-// objects, arrays, strings, numbers, booleans, null; `value(key, default)`, `contains`, `dump()`.
+// moved: the JSON value class is part of the public C++ surface (tcnn::json)
 #pragma once
-
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <map>
-#include <memory>
-#include <stdexcept>
-#include <string>
-#include <utility>
-#include <vector>
-
-namespace tcnn_amd {
-
-class Json {
-public:
-	enum class Kind { Null, Bool, Number, String, Array, Object };
-
-	Json() = default;
-	Json(bool b) : m_kind{Kind::Bool}, m_bool{b} {}
-	Json(double d) : m_kind{Kind::Number}, m_num{d} {}
-	Json(float d) : m_kind{Kind::Number}, m_num{d}, m_is_float32{true} {}
-	Json(int d) : m_kind{Kind::Number}, m_num{(double)d}, m_is_int{true} {}
-	Json(uint32_t d) : m_kind{Kind::Number}, m_num{(double)d}, m_is_int{true} {}
-	Json(int64_t d) : m_kind{Kind::Number}, m_num{(double)d}, m_is_int{true} {}
-	Json(uint64_t d) : m_kind{Kind::Number}, m_num{(double)d}, m_is_int{true} {}
-	Json(const char* s) : m_kind{Kind::String}, m_str{s} {}
-	Json(const std::string& s) : m_kind{Kind::String}, m_str{s} {}
-
-	static Json object() { Json j; j.m_kind = Kind::Object; return j; }
-	static Json array() { Json j; j.m_kind = Kind::Array; return j; }
-
-	static Json parse(const std::string& text) {
-		Parser p{text};
-		p.skip_ws();
-		Json j = p.parse_value();
-		p.skip_ws();
-		if (p.pos != text.size()) p.fail("trailing characters");
-		return j;
-	}
-
-	Kind kind() const { return m_kind; }
-	bool is_null() const { return m_kind == Kind::Null; }
-	bool is_object() const { return m_kind == Kind::Object; }
-	bool is_array() const { return m_kind == Kind::Array; }
-	bool is_string() const { return m_kind == Kind::String; }
-	bool is_number() const { return m_kind == Kind::Number; }
-	bool is_bool() const { return m_kind == Kind::Bool; }
-
-	bool contains(const std::string& key) const { return m_kind == Kind::Object && find(key) != nullptr; }
-
-	const Json& at(const std::string& key) const {
-		const Json* j = find(key);
-		if (!j) throw std::runtime_error{"json: key '" + key + "' not found"};
-		return *j;
-	}
-	const Json& operator[](const std::string& key) const { return at(key); }
-
-	Json& operator[](const std::string& key) {
-		if (m_kind == Kind::Null) m_kind = Kind::Object;
-		if (m_kind != Kind::Object) throw std::runtime_error{"json: not an object"};
-		for (auto& kv : m_obj) if (kv.first == key) return kv.second;
-		m_obj.emplace_back(key, Json{});
-		return m_obj.back().second;
-	}
-
-	size_t size() const { return m_kind == Kind::Array ? m_arr.size() : (m_kind == Kind::Object ? m_obj.size() : 0); }
-	const Json& at(size_t i) const { return m_arr.at(i); }
-	void push_back(Json j) { if (m_kind == Kind::Null) m_kind = Kind::Array; m_arr.push_back(std::move(j)); }
-	const std::vector<std::pair<std::string, Json>>& items() const { return m_obj; }
-
-	double as_double() const {
-		if (m_kind == Kind::Number) return m_num;
-		if (m_kind == Kind::Bool) return m_bool ? 1.0 : 0.0;
-		throw std::runtime_error{"json: value is not a number"};
-	}
-	bool as_bool() const {
-		if (m_kind == Kind::Bool) return m_bool;
-		if (m_kind == Kind::Number) return m_num != 0.0;
-		throw std::runtime_error{"json: value is not a boolean"};
-	}
-	const std::string& as_string() const {
-		if (m_kind != Kind::String) throw std::runtime_error{"json: value is not a string"};
-		return m_str;
-	}
-
-	// nlohmann-style .value(key, default)
-	uint32_t value(const std::string& key, uint32_t def) const { const Json* j = find(key); return j ? (uint32_t)j->as_double() : def; }
-	int value(const std::string& key, int def) const { const Json* j = find(key); return j ? (int)j->as_double() : def; }
-	float value(const std::string& key, float def) const { const Json* j = find(key); return j ? (float)j->as_double() : def; }
-	double value(const std::string& key, double def) const { const Json* j = find(key); return j ? j->as_double() : def; }
-	bool value(const std::string& key, bool def) const { const Json* j = find(key); return j ? j->as_bool() : def; }
-	std::string value(const std::string& key, const char* def) const { const Json* j = find(key); return j ? j->as_string() : std::string{def}; }
-	std::string value(const std::string& key, const std::string& def) const { const Json* j = find(key); return j ? j->as_string() : def; }
-	Json value(const std::string& key, const Json& def) const { const Json* j = find(key); return j ? *j : def; }
-
-	std::string dump() const {
-		std::string out;
-		dump_to(out);
-		return out;
-	}
-
-private:
-	const Json* find(const std::string& key) const {
-		if (m_kind != Kind::Object) return nullptr;
-		for (const auto& kv : m_obj) if (kv.first == key) return &kv.second;
-		return nullptr;
-	}
-
-	static void dump_string(const std::string& s, std::string& out) {
-		out += '"';
-		for (char ch : s) {
-			switch (ch) {
-				case '"': out += "\\\""; break;
-				case '\\': out += "\\\\"; break;
-				case '\n': out += "\\n"; break;
-				case '\t': out += "\\t"; break;
-				case '\r': out += "\\r"; break;
-				default:
-					if ((unsigned char)ch < 0x20) { char buf[8]; snprintf(buf, sizeof(buf), "\\u%04x", ch); out += buf; }
-					else out += ch;
-			}
-		}
-		out += '"';
-	}
-
-	void dump_to(std::string& out) const {
-		switch (m_kind) {
-			case Kind::Null: out += "null"; break;
-			case Kind::Bool: out += m_bool ? "true" : "false"; break;
-			case Kind::Number: {
-				char buf[64];
-				if (m_is_int || (std::floor(m_num) == m_num && std::fabs(m_num) < 1e15)) {
-					snprintf(buf, sizeof(buf), "%lld", (long long)m_num);
-					if (!m_is_int) { out += buf; out += ".0"; break; }
-				} else if (m_is_float32) {
-					snprintf(buf, sizeof(buf), "%.9g", m_num);
-				} else {
-					snprintf(buf, sizeof(buf), "%.17g", m_num);
-				}
-				out += buf;
-				break;
-			}
-			case Kind::String: dump_string(m_str, out); break;
-			case Kind::Array: {
-				out += '[';
-				for (size_t i = 0; i < m_arr.size(); ++i) { if (i) out += ','; m_arr[i].dump_to(out); }
-				out += ']';
-				break;
-			}
-			case Kind::Object: {
-				out += '{';
-				bool first = true;
-				for (const auto& kv : m_obj) {
-					if (!first) out += ',';
-					first = false;
-					dump_string(kv.first, out);
-					out += ':';
-					kv.second.dump_to(out);
-				}
-				out += '}';
-				break;
-			}
-		}
-	}
-
-	struct Parser {
-		const std::string& s;
-		size_t pos = 0;
-		explicit Parser(const std::string& text) : s{text} {}
-
-		[[noreturn]] void fail(const char* what) const {
-			throw std::runtime_error{std::string{"json parse error at offset "} + std::to_string(pos) + ": " + what};
-		}
-		void skip_ws() { while (pos < s.size() && (s[pos] == ' ' || s[pos] == '\n' || s[pos] == '\t' || s[pos] == '\r')) ++pos; }
-		char peek() const { return pos < s.size() ? s[pos] : '\0'; }
-		void expect(char ch) { if (peek() != ch) fail("unexpected character"); ++pos; }
-
-		Json parse_value() {
-			skip_ws();
-			const char ch = peek();
-			if (ch == '{') return parse_object();
-			if (ch == '[') return parse_array();
-			if (ch == '"') return Json{parse_string()};
-			if (s.compare(pos, 4, "true") == 0) { pos += 4; return Json{true}; }
-			if (s.compare(pos, 5, "false") == 0) { pos += 5; return Json{false}; }
-			if (s.compare(pos, 4, "null") == 0) { pos += 4; return Json{}; }
-			return parse_number();
-		}
-
-		Json parse_number() {
-			const size_t start = pos;
-			bool is_int = true;
-			if (peek() == '-' || peek() == '+') ++pos;
-			while (pos < s.size()) {
-				const char ch = s[pos];
-				if (ch >= '0' && ch <= '9') { ++pos; }
-				else if (ch == '.' || ch == 'e' || ch == 'E' || ch == '-' || ch == '+') { is_int = false; ++pos; }
-				else break;
-			}
-			if (pos == start) fail("invalid value");
-			char* end = nullptr;
-			const std::string tok = s.substr(start, pos - start);
-			const double v = std::strtod(tok.c_str(), &end);
-			if (end == tok.c_str()) fail("invalid number");
-			Json j{v};
-			j.m_is_int = is_int;
-			return j;
-		}
-
-		std::string parse_string() {
-			expect('"');
-			std::string out;
-			while (true) {
-				if (pos >= s.size()) fail("unterminated string");
-				char ch = s[pos++];
-				if (ch == '"') break;
-				if (ch == '\\') {
-					if (pos >= s.size()) fail("bad escape");
-					const char e = s[pos++];
-					switch (e) {
-						case '"': out += '"'; break;
-						case '\\': out += '\\'; break;
-						case '/': out += '/'; break;
-						case 'b': out += '\b'; break;
-						case 'f': out += '\f'; break;
-						case 'n': out += '\n'; break;
-						case 'r': out += '\r'; break;
-						case 't': out += '\t'; break;
-						case 'u': {
-							if (pos + 4 > s.size()) fail("bad \\u escape");
-							const unsigned cp = (unsigned)std::strtoul(s.substr(pos, 4).c_str(), nullptr, 16);
-							pos += 4;
-							if (cp < 0x80) out += (char)cp;
-							else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
-							else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
-							break;
-						}
-						default: fail("bad escape");
-					}
-				} else {
-					out += ch;
-				}
-			}
-			return out;
-		}
-
-		Json parse_array() {
-			expect('[');
-			Json j = Json::array();
-			skip_ws();
-			if (peek() == ']') { ++pos; return j; }
-			while (true) {
-				j.m_arr.push_back(parse_value());
-				skip_ws();
-				if (peek() == ',') { ++pos; continue; }
-				expect(']');
-				break;
-			}
-			return j;
-		}
-
-		Json parse_object() {
-			expect('{');
-			Json j = Json::object();
-			skip_ws();
-			if (peek() == '}') { ++pos; return j; }
-			while (true) {
-				skip_ws();
-				std::string key = parse_string();
-				skip_ws();
-				expect(':');
-				Json v = parse_value();
-				j[key] = std::move(v);
-				skip_ws();
-				if (peek() == ',') { ++pos; continue; }
-				expect('}');
-				break;
-			}
-			return j;
-		}
-	};
-
-	Kind m_kind = Kind::Null;
-	bool m_bool = false;
-	double m_num = 0.0;
-	bool m_is_int = false;
-	bool m_is_float32 = false;
-	std::string m_str;
-	std::vector<Json> m_arr;
-	std::vector<std::pair<std::string, Json>> m_obj;
-};
-
-} // namespace tcnn_amd
+#include "../../include/tiny-cuda-nn/json_lite.h"

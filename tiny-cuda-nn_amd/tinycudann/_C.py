@@ -56,6 +56,11 @@ _SIGNATURES = {
     "tcnn_default_loss_scale": (_f32, [_int]),
     "tcnn_preferred_precision": (_int, []),
     "tcnn_set_log_callback": (None, [_vp, _vp]),
+    "tcnn_gpu_malloc": (_int, [_sz, _pp]),
+    "tcnn_gpu_free": (_int, [_vp]),
+    "tcnn_gpu_memcpy": (_int, [_vp, _vp, _sz, _int]),
+    "tcnn_gpu_memset": (_int, [_vp, _int, _sz]),
+    "tcnn_stream_synchronize": (_int, [_vp]),
     "tcnn_create_network_with_input_encoding": (_int, [_u32, _u32, _cp, _cp, _pp]),
     "tcnn_create_network": (_int, [_u32, _u32, _cp, _pp]),
     "tcnn_create_encoding": (_int, [_u32, _cp, _int, _pp]),
