@@ -50,6 +50,82 @@ WORKLOADS = {
     }),
 }
 
+C4 = {  # BASELINE config 4: FullyFusedMLP 128 x 4, inference only, 32 fp32 inputs -> 16 outputs, 1M rows
+    "loss": {"otype": "L2"},
+    "optimizer": {"otype": "Adam"},
+    "encoding": {"otype": "Identity"},
+    "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 4},
+}
+C4_ROWS, C4_IN, C4_OUT = 1 << 20, 32, 16
+C4_FLOP_PER_ROW = 2 * (32 * 128 + 3 * 128 * 128 + 128 * 16)  # 110 592
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak
+
+
+def run_c4(args):
+    """`--workload c4`: network->inference() on 1M rows.  N > 1: the rows are sharded in contiguous blocks, one per GPU, weights
+    replicated, and ONE collective ends every step: the all-gather of the output rows (tinycudann/parallel.py; RCCL over xGMI).
+    Strong scaling: the job is the same 1M rows whatever N is."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank if world > 1 else 0)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import tinycudann as tcnn
+    from tinycudann.parallel import shard_rows, sharded_inference
+
+    tr = tcnn.Trainer(C4_IN, C4_OUT, C4, seed=1337)  # same seed on every rank = replicated weights
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(42)
+    x = torch.rand((C4_ROWS, C4_IN), device="cuda", generator=gen)  # every rank holds the batch; it evaluates only its rows
+
+    def step():
+        return sharded_inference(lambda rows: tr.inference(rows), x, C4_OUT)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        y = step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        y = step()
+    e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    if rank == 0:
+        b, e = shard_rows(C4_ROWS, world, 0)
+        kernel_ms = e0.elapsed_time(e1) / max(args.steps, 1)  # rank 0's stream: its shard's kernels + the all-gather
+        achieved = (e - b) * C4_FLOP_PER_ROW / (kernel_ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "inference throughput (rows/s) FullyFusedMLP 128x4, batch=1M",
+            "value": C4_ROWS * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "c4: Identity + 128x4 FullyFusedMLP inference, 32 -> 16", "global_batch": C4_ROWS, "rows_per_gpu": e - b,
+                       "parallelism": f"rows x{world} + all_gather", "output_checksum": float(y.double().sum().item())},
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<128>", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "traffic": None, "note": "stream time of rank 0 per step (MLP kernel + weight preparation + all-gather) over its shard's FLOPs"},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ADAM_BYTES_PER_PARAM = 36  # SURVEY 8(d): half grad r 2 + fp32 w/m/v r+w 24 + u32 step r+w 8 + half w write 2
 
@@ -101,10 +177,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="c3a", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3a", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "c4":
+        return run_c4(args)
 
     import torch
     import torch.distributed as dist
