@@ -430,7 +430,8 @@ def test_training_step_variants_agree_bitwise(tcnn, oracle, cfg, n_in, monkeypat
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         tr = tcnn.Trainer(n_in, 3, cfg, seed=1337)
-        ctx = tr.training_step(_t(x), _t(t), run_optimizer=False)
+        for _ in range(3):  # the scatter's task list is re-cut from measured timings after the second launch
+            ctx = tr.training_step(_t(x), _t(t), run_optimizer=False)
         g = _bits(tr.param_gradients())
         out = _bits(ctx.output())
         for k in env:
@@ -439,7 +440,7 @@ def test_training_step_variants_agree_bitwise(tcnn, oracle, cfg, n_in, monkeypat
 
     base_g, base_out = grads({})
     assert np.any(base_g[n_net:] != 0)
-    for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"},):
+    for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_SCATTER_RECORDS": "0", "TCNN_AMD_SCATTER_TUNE": "0"}):
         g, out = grads(env)
         assert np.array_equal(out, base_out), env
         assert np.array_equal(g, base_g), env

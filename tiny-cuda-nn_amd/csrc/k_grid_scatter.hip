@@ -218,6 +218,40 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 		}
 	};
 
+	// the same for a task whose chunk is the whole level (coarse levels): every corner is ours, no test, no compaction
+	auto accumulate_whole = [&](const float (&xin)[D], const vecF& gv) {
+		float pos[D], unused;
+		uint32_t cell[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) cell[d] = pos_fract(xin[d], lv.scale, interpolation, &pos[d], &unused);
+		constexpr int C = 1 << D;
+		const bool nearest = interpolation == (uint32_t)InterpolationType::Nearest; // grid.h:232-246: the cell's own entry, weight 1
+#pragma unroll
+		for (int idx = 0; idx < C; ++idx) {
+			if (idx > 0 && nearest) break;
+			float weight = 1;
+			uint32_t local[D];
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+				if ((idx & (1 << d)) == 0) {
+					weight *= nearest ? 1.0f : 1 - pos[d];
+					local[d] = cell[d];
+				} else {
+					weight *= pos[d];
+					local[d] = cell[d] + 1;
+				}
+			}
+			asm volatile("" : "+v"(weight));
+			const uint32_t index = level_index<D>(lv, primes, hash_type, local);
+			const half_t w = (half_t)weight;
+#pragma unroll
+			for (int f = 0; f < F; ++f) {
+				const half_t c = w * gv[f];
+				__hip_atomic_fetch_add(acc_lds + index * F + f, (unsigned long long)half_to_fixed_fast(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+	};
+
 	// Every wave owns a contiguous block of the task's samples and walks it 64 samples at a time.  Loads of batch k+1 are
 	// issued before batch k is accumulated (two register sets, A and B), so a wave always has a batch in flight.
 	const uint32_t n_task = task.sample_end - task.sample_begin;
@@ -259,8 +293,23 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 
 	const unsigned long long t_loop0 = dbg_times ? __builtin_readcyclecounter() : 0;
 	if (n_blocks > 0) {
-		if (chunk_bits == nullptr || lv.scatter_n_chunks == 1) {
-			// no filter available (or nothing to filter): every sample gets the full treatment
+		if (lv.scatter_n_chunks == 1) {
+			// the chunk is the whole level: every sample, every corner, in lockstep; one batch in flight while the previous one is added
+			float px[D], qx[D];
+			vecF pg, qg;
+			bool p_valid = false;
+			for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+				const uint32_t i = w_begin + blk * 64 + lane;
+				fetch(min(i, w_end - 1), qx, qg);
+				if (p_valid) accumulate_whole(px, pg);
+#pragma unroll
+				for (int d = 0; d < D; ++d) px[d] = qx[d];
+				pg = qg;
+				p_valid = i < w_end;
+			}
+			if (p_valid) accumulate_whole(px, pg);
+		} else if (chunk_bits == nullptr) {
+			// no filter available: every sample gets the full treatment
 			for (uint32_t blk = 0; blk < n_blocks; blk += SB) {
 				uint32_t ids[SB];
 				bool valid[SB];
@@ -389,6 +438,10 @@ __global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __res
 	if (lane < n_chunks) bits[((size_t)level * SCATTER_MAX_CHUNKS + lane) * (n / 64) + i / 64] = mine;
 }
 
+// set by grid_backward_lds for the duration of one launch: device buffer uint64[n_tasks][8] that receives the per-task
+// timestamps (slots 0..3: start / after zeroing / after accumulation / end, 100 MHz clock) -- input of the plan tuner
+thread_local unsigned long long* g_task_times = nullptr;
+
 template <int D, int F, bool REC = false>
 void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x, const void* dy, uint32_t dss, uint32_t dsl,
                     void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate) {
@@ -401,9 +454,9 @@ void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* ta
 	static const bool timing = getenv("TCNN_AMD_SCATTER_TIMING") != nullptr;
 	static int timing_left = 3;
 	unsigned long long* dbg = nullptr;
-	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&dbg, (size_t)n_tasks * 8 * 8));
+	if (timing && timing_left > 0 && !g_task_times) HIP_CHECK_THROW(hipMalloc(&dbg, (size_t)n_tasks * 8 * 8));
 	hipLaunchKernelGGL((k_grid_scatter<D, F, REC>), dim3(n_tasks), dim3(SCATTER_THREADS), SCATTER_LDS_BYTES, s, dm, tasks, n, x, (const half_t*)dy, dss, dsl, (half_t*)grad, chunk_bits,
-	                   scratch, accumulate ? 1 : 0, dbg);
+	                   scratch, accumulate ? 1 : 0, g_task_times ? g_task_times : dbg);
 	HIP_CHECK_THROW(hipGetLastError());
 	if (dbg) {
 		std::vector<unsigned long long> h((size_t)n_tasks * 8);
@@ -472,12 +525,78 @@ void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta*
 	hipLaunchKernelGGL(k_grid_mask_to_bits, dim3(div_round_up(n, 256), meta.n_levels), dim3(256), 0, stream, dev_meta, n, (const unsigned long long*)mask, (unsigned long long*)bits);
 }
 
-void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems) {
+// Splits per level from MEASURED per-level work (microseconds of workgroup time, summed over the level's tasks of a first
+// launch).  Levels cut into many chunks ("fine") cannot be split further cheaply -- every extra split flushes a whole chunk
+// through global atomics -- so their N_f tasks of t_f microseconds each set the rhythm: they need R rounds on the CUs that
+// are left.  Levels with few chunks ("coarse": few entries, cheap shared flush) are cut into just enough LONG tasks to keep
+// x = 256 - ceil(N_f / R) CUs busy for those R rounds; they are launched first.  Without this the coarse tasks were sized
+// like the fine ones and the ~850 equal tasks needed a fourth, nearly empty round (20 of 88 us on C3a).
+static void tuned_splits(const GridMeta& meta, uint32_t n, const std::vector<float>& level_us, std::vector<uint32_t>& splits) {
+	const uint32_t n_cus = 256;
+	double w_coarse = 0, w_fine = 0;
+	uint32_t n_fine = 0;
+	auto is_fine = [&](uint32_t l) { return meta.levels[l].scatter_n_chunks > 8; };
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		if (is_fine(l)) { w_fine += level_us[l]; n_fine += meta.levels[l].scatter_n_chunks; }
+		else w_coarse += level_us[l];
+	}
+	double task_us; // duration the coarse tasks should have
+	uint32_t coarse_cus = n_cus;
+	if (n_fine > 0) {
+		const double t_f = w_fine / n_fine;
+		uint32_t x = n_cus / 4;
+		double best = 1e30;
+		for (uint32_t rounds = 1; rounds <= 64; ++rounds) { // makespan(rounds) = max(fine rounds, coarse work on the CUs that are left)
+			const uint32_t fine_cus = div_round_up(n_fine, rounds);
+			if (fine_cus >= n_cus) continue;
+			const double makespan = std::max(rounds * t_f, w_coarse / (n_cus - fine_cus));
+			if (makespan < best) {
+				best = makespan;
+				x = n_cus - fine_cus;
+			}
+		}
+		coarse_cus = x;
+		task_us = std::max(w_coarse / std::max(x - 1, 1u), 0.25 * t_f);
+	} else {
+		task_us = std::max(w_coarse / n_cus, 4.0);
+	}
+	const uint32_t max_splits = std::max(n / 1024u, 1u);
+	if (getenv("TCNN_AMD_SCATTER_TIMING")) {
+		fprintf(stderr, "scatter tuner: n_fine %u w_fine %.1f w_coarse %.1f task_us %.1f; level_us:", n_fine, w_fine, w_coarse, task_us);
+		for (uint32_t l = 0; l < meta.n_levels; ++l) fprintf(stderr, " %.0f", level_us[l]);
+		fprintf(stderr, "\n");
+	}
+	uint32_t n_coarse_tasks = 0;
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		if (is_fine(l)) { splits[l] = 1; continue; }
+		const double per_chunk_us = level_us[l] / meta.levels[l].scatter_n_chunks;
+		splits[l] = std::min(max_splits, std::max(1u, (uint32_t)(per_chunk_us / task_us + 0.5)));
+		n_coarse_tasks += splits[l] * meta.levels[l].scatter_n_chunks;
+	}
+	// never more long tasks than CUs set aside for them (minus one spare): one too many costs the fine tasks a whole round
+	while (n_fine > 0 && n_coarse_tasks + 1 > coarse_cus) {
+		uint32_t victim = meta.n_levels;
+		double shortest = 1e30;
+		for (uint32_t l = 0; l < meta.n_levels; ++l) {
+			if (is_fine(l) || splits[l] <= 1) continue;
+			const double t = level_us[l] / (meta.levels[l].scatter_n_chunks * splits[l]);
+			if (t < shortest) { shortest = t; victim = l; }
+		}
+		if (victim == meta.n_levels) break;
+		--splits[victim];
+		n_coarse_tasks -= meta.levels[victim].scatter_n_chunks;
+	}
+}
+
+void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems,
+                       const std::vector<float>* measured_level_us) {
 	const uint32_t F = meta.n_features_per_level;
 	const uint32_t corners = meta.interpolation == (uint32_t)InterpolationType::Nearest ? 1u : (1u << meta.n_pos_dims);
 	tasks.clear();
 	shared_ranges.clear();
 	scratch_elems = 0;
+	std::vector<uint32_t> tuned(meta.n_levels, 0);
+	if (measured_level_us) tuned_splits(meta, n, *measured_level_us, tuned);
 
 	// profiling aid: TCNN_AMD_SCATTER_LEVELS="lo,hi" restricts the plan to levels lo..hi (results are then incomplete!)
 	uint32_t dbg_lo = 0, dbg_hi = meta.n_levels;
@@ -493,6 +612,7 @@ void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatter
 		const uint64_t events = (uint64_t)n * corners / n_chunks;
 		uint32_t splits = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(events / 65536, 1), 32);
 		splits = std::min(splits, std::max(n / 1024u, 1u));
+		if (measured_level_us) splits = tuned[l];
 		const uint32_t samples_per_split = next_multiple(div_round_up(n, splits), 64u);
 		for (uint32_t c = 0; c < n_chunks; ++c) {
 			const uint32_t begin = c * per_chunk;
@@ -521,14 +641,35 @@ void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatter
 
 	// Speed-only placement: blocks b and b + 8 usually share an XCD (MI355X_MICROARCH.md "Workgroup dispatch"), so give all
 	// tasks of a level the same residue mod 8 -- its coordinates, bit planes and gradient plane then stay in that XCD's L2.
-	std::vector<uint32_t> order(meta.n_levels);
-	for (uint32_t l = 0; l < meta.n_levels; ++l) order[l] = l;
-	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return per_level[a].size() > per_level[b].size(); });
+	if (measured_level_us) {
+		// tuned plan: the long coarse tasks go first (longest first), one after the other -- they run for the whole kernel
+		std::vector<uint32_t> coarse;
+		for (uint32_t l = 0; l < meta.n_levels; ++l) if (meta.levels[l].scatter_n_chunks <= 8 && !per_level[l].empty()) coarse.push_back(l);
+		std::sort(coarse.begin(), coarse.end(), [&](uint32_t a, uint32_t b) { return (*measured_level_us)[a] / per_level[a].size() > (*measured_level_us)[b] / per_level[b].size(); });
+		for (uint32_t l : coarse) {
+			tasks.insert(tasks.end(), per_level[l].begin(), per_level[l].end());
+			per_level[l].clear();
+		}
+		while (tasks.size() % 8) tasks.push_back(GridScatterTask{0, 0, 0, 0, 0, 0, 0, 0});
+	}
 	std::vector<std::vector<GridScatterTask>> bins(8);
-	for (uint32_t l : order) {
-		size_t best = 0;
-		for (size_t b = 1; b < 8; ++b) if (bins[b].size() < bins[best].size()) best = b;
-		bins[best].insert(bins[best].end(), per_level[l].begin(), per_level[l].end());
+	if (measured_level_us) {
+		// the remaining tasks, level after level, cut into 8 equal runs: every XCD gets the same number of tasks and sees
+		// at most a few levels (whole levels per XCD, as below, leave XCDs idle when levels / 8 is not an integer)
+		std::vector<GridScatterTask> all;
+		for (uint32_t l = 0; l < meta.n_levels; ++l) all.insert(all.end(), per_level[l].begin(), per_level[l].end());
+		const size_t per_bin = (all.size() + 7) / 8;
+		for (size_t i = 0; i < all.size(); ++i) bins[std::min<size_t>(i / std::max<size_t>(per_bin, 1), 7)].push_back(all[i]);
+	} else {
+		std::vector<uint32_t> order(meta.n_levels);
+		for (uint32_t l = 0; l < meta.n_levels; ++l) order[l] = l;
+		std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return per_level[a].size() > per_level[b].size(); });
+		for (uint32_t l : order) {
+			if (per_level[l].empty()) continue;
+			size_t best = 0;
+			for (size_t b = 1; b < 8; ++b) if (bins[b].size() < bins[best].size()) best = b;
+			bins[best].insert(bins[best].end(), per_level[l].begin(), per_level[l].end());
+		}
 	}
 	size_t longest = 0;
 	for (const auto& b : bins) longest = std::max(longest, b.size());
@@ -541,13 +682,28 @@ void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatter
 	while (!tasks.empty() && tasks.back().n_entries == 0) tasks.pop_back();
 }
 
+std::vector<float> grid_scatter_level_costs(const GridMeta& meta, const std::vector<GridScatterTask>& tasks, const std::vector<uint64_t>& times) {
+	std::vector<float> level_us(meta.n_levels, 0.0f);
+	for (size_t i = 0; i < tasks.size(); ++i) {
+		if (!tasks[i].n_entries) continue;
+		const uint64_t t0 = times[i * 8], t3 = times[i * 8 + 3];
+		if (t3 > t0) level_us[tasks[i].level] += (float)(t3 - t0) * 0.01f; // s_memrealtime: 100 MHz
+	}
+	return level_us;
+}
+
 void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
-                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records) {
+                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records,
+                       uint64_t* task_times) {
 	if (n_tasks == 0) return;
 	const unsigned long long* bits = (const unsigned long long*)chunk_bits;
 	unsigned long long* sc = (unsigned long long*)scratch;
 	CHECK_THROW(!dy_records || grid_scatter_records_supported(meta));
+	struct TimesGuard {
+		explicit TimesGuard(uint64_t* p) { g_task_times = (unsigned long long*)p; }
+		~TimesGuard() { g_task_times = nullptr; }
+	} guard{task_times};
 	switch (meta.n_pos_dims) {
 		case 2: dispatch_scatter<2>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
 		case 3: dispatch_scatter<3>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;

@@ -444,9 +444,25 @@ public:
 				ScatterPlan& plan = scatter_plan(n);
 				const uint32_t F = m_meta.n_features_per_level;
 				const uint64_t* mask = (ctx.chunk_mask && ctx.n == n) ? ctx.chunk_mask.as<uint64_t>() : nullptr;
+				// The second filtered launch at this batch size is timed per task and the plan re-cut from the measured
+				// per-level work (grid_scatter_plan): one stream synchronisation, once per (encoding, batch size).
+				const bool tune = !plan.tuned && mask && scatter_tuning_enabled() && ++plan.launches == 2;
+				DeviceBuf times;
+				if (tune) {
+					times.resize((size_t)plan.n_tasks * 8 * sizeof(uint64_t));
+					times.memset(0);
+				}
 				grid_backward_lds(stream, m_meta, dev_meta(), plan.dev_tasks.as<GridScatterTask>(), plan.n_tasks, plan.dev_ranges.as<GridScatterRange>(), plan.n_ranges,
 				                  plan.scratch.as<uint64_t>(), n, x, dL_dy, dy_planes ? F : padded_output_width(), dy_planes ? n * F : F, grads, mask,
-				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records);
+				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, tune ? times.as<uint64_t>() : nullptr);
+				if (tune) {
+					HIP_CHECK_THROW(hipStreamSynchronize(stream));
+					std::vector<uint64_t> h((size_t)plan.n_tasks * 8);
+					HIP_CHECK_THROW(hipMemcpy(h.data(), times.data(), h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+					const std::vector<float> level_us = grid_scatter_level_costs(m_meta, plan.host_tasks, h);
+					build_scatter_plan(plan, n, &level_us);
+					plan.tuned = true;
+				}
 			} else {
 				CHECK_THROW(!dy_planes);
 				if (mode == GradientMode::Overwrite) HIP_CHECK_THROW(hipMemsetAsync(grads, 0, n_params() * elem, stream)); // grid.h:858
@@ -487,24 +503,36 @@ public:
 
 	struct ScatterPlan {
 		DeviceBuf dev_tasks, dev_ranges, scratch;
+		std::vector<GridScatterTask> host_tasks;
 		uint32_t n_tasks = 0, n_ranges = 0;
+		uint32_t launches = 0;
+		bool tuned = false;
 	};
+	// TCNN_AMD_SCATTER_TUNE=0 keeps the untuned task list (A/B runs)
+	static bool scatter_tuning_enabled() { // read per call so that tests can cover both forms in one process
+		const char* e = getenv("TCNN_AMD_SCATTER_TUNE");
+		return !(e && e[0] == '0');
+	}
+	// (re)builds the device-side plan; the caller guarantees that no launch using the old one is still running
+	void build_scatter_plan(ScatterPlan& plan, uint32_t n, const std::vector<float>* measured_level_us) {
+		std::vector<GridScatterRange> ranges;
+		size_t scratch_elems = 0;
+		grid_scatter_plan(m_meta, n, plan.host_tasks, ranges, scratch_elems, measured_level_us);
+		plan.n_tasks = (uint32_t)plan.host_tasks.size();
+		plan.n_ranges = (uint32_t)ranges.size();
+		plan.dev_tasks.resize(plan.host_tasks.size() * sizeof(GridScatterTask));
+		if (!plan.host_tasks.empty()) HIP_CHECK_THROW(hipMemcpy(plan.dev_tasks.data(), plan.host_tasks.data(), plan.host_tasks.size() * sizeof(GridScatterTask), hipMemcpyHostToDevice));
+		plan.dev_ranges.resize(ranges.size() * sizeof(GridScatterRange));
+		if (!ranges.empty()) HIP_CHECK_THROW(hipMemcpy(plan.dev_ranges.data(), ranges.data(), ranges.size() * sizeof(GridScatterRange), hipMemcpyHostToDevice));
+		plan.scratch.resize(0);
+		plan.scratch.resize(scratch_elems * sizeof(uint64_t));
+		plan.scratch.memset(0); // the finalize pass leaves it zeroed again after every step
+	}
 	ScatterPlan& scatter_plan(uint32_t n) {
 		auto it = m_scatter_plans.find(n);
 		if (it != m_scatter_plans.end()) return *it->second;
 		auto plan = std::make_unique<ScatterPlan>();
-		std::vector<GridScatterTask> tasks;
-		std::vector<GridScatterRange> ranges;
-		size_t scratch_elems = 0;
-		grid_scatter_plan(m_meta, n, tasks, ranges, scratch_elems);
-		plan->n_tasks = (uint32_t)tasks.size();
-		plan->n_ranges = (uint32_t)ranges.size();
-		plan->dev_tasks.resize(tasks.size() * sizeof(GridScatterTask));
-		if (!tasks.empty()) HIP_CHECK_THROW(hipMemcpy(plan->dev_tasks.data(), tasks.data(), tasks.size() * sizeof(GridScatterTask), hipMemcpyHostToDevice));
-		plan->dev_ranges.resize(ranges.size() * sizeof(GridScatterRange));
-		if (!ranges.empty()) HIP_CHECK_THROW(hipMemcpy(plan->dev_ranges.data(), ranges.data(), ranges.size() * sizeof(GridScatterRange), hipMemcpyHostToDevice));
-		plan->scratch.resize(scratch_elems * sizeof(uint64_t));
-		plan->scratch.memset(0); // the finalize pass leaves it zeroed again after every step
+		build_scatter_plan(*plan, n, nullptr);
 		return *(m_scatter_plans[n] = std::move(plan));
 	}
 

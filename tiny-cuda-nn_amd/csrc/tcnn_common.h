@@ -104,7 +104,11 @@ struct GridScatterRange { size_t grad_begin; uint32_t n_elems; uint32_t scratch_
 uint32_t grid_scatter_max_chunks();                 // chunks per level the sample filter can describe (64)
 void grid_scatter_setup_levels(GridMeta& meta);     // fills GridLevel::scatter_* (how each level's table is cut into chunks)
 // Plans the task list for a batch of n samples (half gradients, F >= 2).
-void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems);
+// measured_level_us (optional): per-level workgroup time of a first launch (grid_scatter_level_costs) -> tuned task sizes
+void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems,
+                       const std::vector<float>* measured_level_us = nullptr);
+// times: uint64[tasks.size()][8] copied back from grid_backward_lds(task_times)
+std::vector<float> grid_scatter_level_costs(const GridMeta& meta, const std::vector<GridScatterTask>& tasks, const std::vector<uint64_t>& times);
 // chunk_mask [n_levels][n] uint64 -> chunk_bits [n_levels][64][n / 64] uint64 (one ballot word per 64 samples per (level, chunk))
 void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, const uint64_t* chunk_mask, uint64_t* chunk_bits);
 // dL_dy element (sample i, level l, feature f) at dL_dy[i * dy_stride_sample + l * dy_stride_level + f].
@@ -113,7 +117,8 @@ void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta*
 // accumulate = GradientMode::Accumulate.
 void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
-                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records = false);
+                       const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records = false,
+                       uint64_t* task_times = nullptr); // task_times (optional): device uint64[n_tasks][8], per-task timestamps for the plan tuner
 // dy_records: dL_dy is float4 [n_levels][n] scatter records {coordinates, F halves} (see mlp_train_fused); x is then not read
 bool grid_scatter_records_supported(const GridMeta& meta);
 void grid_backward_input(hipStream_t stream, const GridMeta& meta, bool fp32, uint32_t n, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
