@@ -444,3 +444,10 @@ def test_training_step_variants_agree_bitwise(tcnn, oracle, cfg, n_in, monkeypat
         g, out = grads(env)
         assert np.array_equal(out, base_out), env
         assert np.array_equal(g, base_g), env
+    # the private weight-gradient form of the MLP kernel sums in another order: same forward pass and grid gradients, MLP
+    # weight gradients equal up to fp32 summation order before the one rounding to fp16
+    g, out = grads({"TCNN_AMD_MLP_PW": "1"})
+    assert np.array_equal(out, base_out)
+    assert np.array_equal(g[n_net:], base_g[n_net:])
+    a, b = _f32(g[:n_net]), _f32(base_g[:n_net])
+    assert float(np.linalg.norm(a - b)) <= 2e-3 * float(np.linalg.norm(b))

@@ -46,7 +46,13 @@ struct TrainArgs {
 	uint32_t x_plane_f;     // 0: x is AoS [n][in_width]; F: x is level planes [in_width / F][n][F] (k_grid_planes.hip)
 };
 
-template <int W, int NB, int NW, int MAXT, int ACT>
+// PW ("private weight gradients"): every wave accumulates ALL weight-gradient tiles over its own 16 samples per trip
+// (v_mfma_f32_16x16x16_f16, k = the wave's 16 rows of the LDS images) instead of sharing the tiles and the k axis with the
+// other waves.  Nothing a wave reads was written by another wave, so the trip loop needs no workgroup barrier at all -- the
+// two barriers per trip were where the shared form spent most of its time.  Costs 2x the (cheap) MFMA work and 128
+// accumulator registers; the waves' partial sums are combined through LDS once, after the last trip.
+// Requires NB == 1, W == 64, n_hidden <= 2, in_width <= 32, out_width <= 32 (static tile slots: 8 + 16 + 8).
+template <int W, int NB, int NW, int MAXT, int ACT, bool PW = false>
 __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const TrainArgs a) {
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
@@ -376,6 +382,53 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 		}
 
 		// =================================================================== phase B: weight gradients from the LDS images
+		if constexpr (PW) {
+			if (a.slabs) {
+				// transposing reads (see the shared form below), k = this wave's 16 rows: lane (li, grp) gets rows 4 grp .. 4 grp + 3 of column li
+				const uint32_t grp = lane >> 4, li = lane & 15;
+				const uint32_t rowp = row0 + 4 * grp + (li >> 2), colo = 4 * (li & 3);
+				auto frag = [&](uint32_t image_off, uint32_t stride, uint32_t tile) { return lds_read_tr(lds + image_off + rowp * stride + 16 * tile + colo); };
+				// slots 0..7: dW0 = dH_0^T X (T x in_w/16 tiles)
+				{
+					h4 bx[2];
+#pragma unroll
+					for (int tc = 0; tc < 2; ++tc) bx[tc] = 16 * tc < (int)in_w ? frag(xs_off, xs_stride, tc) : h4{0, 0, 0, 0};
+#pragma unroll
+					for (int tr = 0; tr < T; ++tr) {
+						const h4 af = frag(dhs_off, hs_stride, tr);
+#pragma unroll
+						for (int tc = 0; tc < 2; ++tc) wacc[tr * 2 + tc] = mfma16(af, bx[tc], wacc[tr * 2 + tc]);
+					}
+				}
+				// slots 8..23: dW1 = dH_1^T H_0 (T x T tiles), only with two hidden layers
+				if (nh == 2) {
+					h4 bh[T];
+#pragma unroll
+					for (int tc = 0; tc < T; ++tc) bh[tc] = frag(hs_off, hs_stride, tc);
+#pragma unroll
+					for (int tr = 0; tr < T; ++tr) {
+						const h4 af = frag(dhs_off + S * hs_stride, hs_stride, tr);
+#pragma unroll
+						for (int tc = 0; tc < T; ++tc) wacc[8 + tr * T + tc] = mfma16(af, bh[tc], wacc[8 + tr * T + tc]);
+					}
+				}
+				// slots 24..31: dWout = dY^T H_last (out_w/16 x T tiles)
+				{
+					h4 bh[T];
+#pragma unroll
+					for (int tc = 0; tc < T; ++tc) bh[tc] = frag(hs_off + (nh - 1) * S * hs_stride, hs_stride, tc);
+#pragma unroll
+					for (int to = 0; to < (MAXT - 24) / T; ++to) {
+						if (to < (int)m_out) {
+							const h4 af = frag(dys_off, dys_stride, to);
+#pragma unroll
+							for (int tc = 0; tc < T; ++tc) wacc[24 + to * T + tc] = mfma16(af, bh[tc], wacc[24 + to * T + tc]);
+						}
+					}
+				}
+			}
+			continue; // no barrier: the next trip overwrites only this wave's own rows
+		}
 		__syncthreads();
 		if (a.slabs) {
 			const uint32_t grp = lane >> 4, li = lane & 15;
@@ -403,6 +456,50 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 		__syncthreads();
 	}
 
+	if constexpr (PW) {
+		if (a.slabs) {
+			// combine the waves' partial sums in LDS (plain read-add-write, one wave at a time: LDS float atomics are slow), then
+			// write the workgroup's slab with coalesced stores
+			float* red = (float*)smem;
+			const uint32_t grp = lane >> 4, li = lane & 15;
+			__syncthreads(); // every wave is done with the images
+			for (uint32_t w = 0; w < (uint32_t)NW; ++w) {
+				if (wave == w) {
+					auto put = [&](const f4& v, uint32_t out, uint32_t ld) {
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							float* p = red + out + (size_t)(4 * grp + r) * ld + li;
+							*p = w == 0 ? v[r] : *p + v[r];
+						}
+					};
+					const MlpLayer L0 = d.layers[0];
+#pragma unroll
+					for (int tr = 0; tr < T; ++tr)
+#pragma unroll
+						for (int tc = 0; tc < 2; ++tc)
+							if (16 * tc < (int)in_w) put(wacc[tr * 2 + tc], L0.w_off + 16 * tr * L0.cols + 16 * tc, L0.cols);
+					if (nh == 2) {
+						const MlpLayer L1 = d.layers[1];
+#pragma unroll
+						for (int tr = 0; tr < T; ++tr)
+#pragma unroll
+							for (int tc = 0; tc < T; ++tc) put(wacc[8 + tr * T + tc], L1.w_off + 16 * tr * L1.cols + 16 * tc, L1.cols);
+					}
+					const MlpLayer Lo = d.layers[d.n_layers - 1];
+#pragma unroll
+					for (int to = 0; to < (MAXT - 24) / T; ++to)
+						if (to < (int)m_out) {
+#pragma unroll
+							for (int tc = 0; tc < T; ++tc) put(wacc[24 + to * T + tc], Lo.w_off + 16 * to * Lo.cols + 16 * tc, Lo.cols);
+						}
+				}
+				__syncthreads();
+			}
+			float* slab = a.slabs + (size_t)blockIdx.x * a.n_params;
+			for (uint32_t i = tid; i < a.n_params; i += NW * 64) slab[i] = red[i];
+		}
+		return;
+	}
 	if (a.slabs) {
 		float* slab = a.slabs + (size_t)blockIdx.x * a.n_params;
 		const uint32_t grp = lane >> 4, li = lane & 15;
@@ -421,6 +518,7 @@ struct TrainConfig {
 	int nb, nw, maxt;
 	uint32_t lds_bytes, s;
 	bool ok, image_in_lds;
+	bool pw; // private weight gradients (barrier-free trips), see k_mlp_train
 };
 
 // (NB, NW, MAXT) triples that are instantiated; pick_config only ever returns one of them
@@ -438,6 +536,28 @@ inline TrainConfig pick_config(const MlpDesc& d) {
 	for (uint32_t l = 0; l < d.n_layers; ++l) total_tiles += (d.layers[l].rows / 16) * (d.layers[l].cols / 16);
 	const uint32_t image_bytes = (d.n_frags_fwd + d.n_frags_bwd) * 1024;
 	const uint32_t budget = 160 * 1024 - 512;
+	// TCNN_AMD_MLP_PW=1 selects the barrier-free private weight-gradient form.  Off by default: measured on C3a it takes 92 us
+	// against 78 us for the shared form -- the trips are bound by dependent LDS-read -> MFMA chains at 2 waves per SIMD, not
+	// by the barriers, and the private form doubles the MFMA and accumulator work.  Read per call so that tests can cover both.
+	const char* pw_env = getenv("TCNN_AMD_MLP_PW");
+	const bool pw_allowed = pw_env && pw_env[0] == '1';
+	if (pw_allowed && d.width == 64 && d.n_hidden <= 2 && d.in_width <= 32 && d.out_width <= 32) {
+		const uint32_t s = 8 * 16;
+		const uint32_t images = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + TR_PAD) + (d.out_width + TR_PAD));
+		size_t n_params = 0;
+		for (uint32_t l = 0; l < d.n_layers; ++l) n_params += (size_t)d.layers[l].rows * d.layers[l].cols;
+		if (images + image_bytes <= budget && n_params * sizeof(float) <= images) { // the final reduction reuses the image space
+			cfg.nb = 1;
+			cfg.nw = 8;
+			cfg.maxt = d.out_width <= 16 ? 28 : 32; // 8 + 16 + 4 (or 8) tile slots
+			cfg.s = s;
+			cfg.lds_bytes = images + image_bytes;
+			cfg.image_in_lds = true;
+			cfg.pw = true;
+			cfg.ok = true;
+			return cfg;
+		}
+	}
 	// first choice: a variant whose activation images AND the weight images fit in LDS together; else weights stay in L2
 	for (int pass = 0; pass < 2; ++pass) {
 		for (const TrainVariant& v : TRAIN_VARIANTS) {
@@ -471,6 +591,21 @@ void launch_train(hipStream_t stream, const MlpDesc& d, const TrainArgs& a, uint
 }
 
 void dispatch_train(hipStream_t stream, const MlpDesc& d, const TrainArgs& a, const TrainConfig& cfg, uint32_t grid) {
+	if (cfg.pw) {
+		auto go = [&](auto kernel) {
+			HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes));
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(8 * 64), cfg.lds_bytes, stream, d, a);
+			HIP_CHECK_THROW(hipGetLastError());
+		};
+		if (cfg.maxt == 28) {
+			if (d.activation == (uint32_t)Activation::ReLU) go(k_mlp_train<64, 1, 8, 28, (int)Activation::ReLU, true>);
+			else go(k_mlp_train<64, 1, 8, 28, -1, true>);
+		} else {
+			if (d.activation == (uint32_t)Activation::ReLU) go(k_mlp_train<64, 1, 8, 32, (int)Activation::ReLU, true>);
+			else go(k_mlp_train<64, 1, 8, 32, -1, true>);
+		}
+		return;
+	}
 #define TCNN_TRAIN_CASE(W_, NB_, NW_, MAXT_) \
 	if ((int)d.width == W_ && cfg.nb == NB_ && cfg.nw == NW_ && cfg.maxt == MAXT_) return launch_train<W_, NB_, NW_, MAXT_>(stream, d, a, grid, cfg.lds_bytes);
 	TCNN_TRAIN_CASE(64, 1, 8, 8)

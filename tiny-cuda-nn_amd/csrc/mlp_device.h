@@ -61,6 +61,8 @@ template <int ACT> __device__ inline half_t act_bwd_t(uint32_t act, half_t g, ha
 }
 
 __device__ inline f4 mfma(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// k = 16: A lane l holds A[row = l & 15][k = 4 (l >> 4) + j], B lane l holds B[k = 4 (l >> 4) + j][col = l & 15], j = 0..3
+__device__ inline f4 mfma16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
 
 // k index of element j of a chained-layer fragment
 __host__ __device__ inline uint32_t k_chain(uint32_t s, uint32_t q, uint32_t j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
