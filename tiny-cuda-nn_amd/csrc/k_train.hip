@@ -559,9 +559,14 @@ inline TrainConfig pick_config(const MlpDesc& d) {
 		}
 	}
 	// first choice: a variant whose activation images AND the weight images fit in LDS together; else weights stay in L2
-	for (int pass = 0; pass < 2; ++pass) {
+	const char* img_env = getenv("TCNN_AMD_MLP_IMAGE_LDS"); // development aid: "0" keeps the weight images in L2
+	for (int pass = (img_env && img_env[0] == '0') ? 1 : 0; pass < 2; ++pass) {
 		for (const TrainVariant& v : TRAIN_VARIANTS) {
 			if (v.width_class != (int)d.width) continue;
+			if (const char* e = getenv("TCNN_AMD_MLP_VARIANT")) { // development aid: "nb,nw,maxt" forces one instantiated variant
+				int nb = 0, nw = 0, maxt = 0;
+				if (sscanf(e, "%d,%d,%d", &nb, &nw, &maxt) == 3 && (nb != v.nb || nw != v.nw || maxt != v.maxt)) continue;
+			}
 			const uint32_t s = v.nw * v.nb * 16;
 			const uint32_t bytes = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + TR_PAD) + (d.out_width + TR_PAD)) + (pass == 0 ? image_bytes : 0);
 			const uint32_t per = (total_tiles + v.nw - 1) / v.nw;
