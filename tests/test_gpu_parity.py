@@ -451,3 +451,21 @@ def test_training_step_variants_agree_bitwise(tcnn, oracle, cfg, n_in, monkeypat
     assert np.array_equal(g[n_net:], base_g[n_net:])
     a, b = _f32(g[:n_net]), _f32(base_g[:n_net])
     assert float(np.linalg.norm(a - b)) <= 2e-3 * float(np.linalg.norm(b))
+
+
+def test_wide_inference_forms_agree(tcnn, oracle, monkeypatch):
+    """BASELINE config 4 (FullyFusedMLP 128 x 4, 32 -> 16): the LDS-resident-weights form used for large batches computes the
+    same per-sample MFMA sequence as the L2-resident form -- bit-identical outputs -- and both match the oracle."""
+    cfg = {"loss": {"otype": "L2"}, "optimizer": {"otype": "Adam"}, "encoding": {"otype": "Identity"},
+           "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 4}}
+    n = 1 << 17
+    tr = tcnn.Trainer(32, 16, cfg, seed=1337)
+    x = oracle.Pcg32(11).uniform_strided(n * 32).reshape(n, 32)
+    y_lds = tr.inference(_t(x)).cpu().numpy()
+    monkeypatch.setenv("TCNN_AMD_MLP_FWD_LDS", "0")
+    y_l2 = tr.inference(_t(x)).cpu().numpy()
+    monkeypatch.delenv("TCNN_AMD_MLP_FWD_LDS")
+    assert np.array_equal(y_lds, y_l2)
+    ref = oracle.Trainer(32, 16, cfg, seed=1337)
+    want = ref.inference(x[:1024])
+    assert rel_err(y_lds[:1024], want) < 1e-2

@@ -142,8 +142,12 @@ __device__ inline void activate_pack(const f4 (&acc)[T][NB], h8 (&hf)[KS][NB], u
 	}
 }
 
-template <int W, int NB, int ACT>
-__global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
+// IMG_LDS: the forward fragment image is copied into LDS once per workgroup (persistent workgroups, one per CU) and read
+// with ds_read_b128 -- for wide, deep networks (C4: 108 KB of fragments) whose image falls out of the 32 KB L1, where every
+// MFMA otherwise waits on a 1 KB fetch from L2.  Used for inference with NB = 4 column blocks per wave (one fragment read
+// feeds 4 MFMAs) and 8 waves per workgroup (2 per SIMD: one wave's activation VALU work under the other's MFMAs).
+template <int W, int NB, int ACT, bool IMG_LDS = false, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
 	const uint32_t lane = threadIdx.x & 63;
@@ -152,6 +156,20 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs 
 	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
 	const uint32_t n_iters = a.n / (16 * NB);
 	const uint32_t in_w = d.in_width, out_w = d.out_width;
+
+	extern __shared__ __attribute__((aligned(16))) char fwd_smem[];
+	typedef __attribute__((address_space(3))) const h8 lds_h8;
+	if constexpr (IMG_LDS) {
+		h8* dst = (h8*)fwd_smem;
+		const uint32_t n16 = d.n_frags_fwd * 64;
+		for (uint32_t i = threadIdx.x; i < n16; i += THREADS) dst[i] = a.image[i];
+		__syncthreads();
+	}
+	// fragment `index` of the forward image (1 KB = 64 lanes x 16 B)
+	auto frag = [&](const uint32_t index) -> h8 {
+		if constexpr (IMG_LDS) return *((lds_h8*)fwd_smem + index * 64 + lane);
+		else return a.image[(size_t)index * 64 + lane];
+	};
 
 	for (uint32_t it = wave; it < n_iters; it += n_waves) {
 		const uint32_t s0 = it * 16 * NB;
@@ -164,7 +182,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs 
 			for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
 		{
 			const uint32_t ks0 = d.layers[0].ks_fwd;
-			const h8* img = a.image + (size_t)d.layers[0].fwd_off * 64 + lane;
+			const uint32_t img = d.layers[0].fwd_off;
 			for (uint32_t s = 0; s < ks0; ++s) {
 				h8 bf[NB];
 				const uint32_t k0 = 32 * s + 8 * q;
@@ -175,7 +193,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs 
 				}
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
-					const h8 af = img[(size_t)(t * ks0 + s) * 64];
+					const h8 af = frag(img + t * ks0 + s);
 #pragma unroll
 					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, bf[b], acc[t][b]);
 				}
@@ -200,7 +218,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs 
 
 		// ---- hidden layers 1 .. n_hidden-1: chained in registers
 		for (uint32_t l = 1; l < d.n_hidden; ++l) {
-			const h8* img = a.image + (size_t)d.layers[l].fwd_off * 64 + lane;
+			const uint32_t img = d.layers[l].fwd_off;
 #pragma unroll
 			for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -209,7 +227,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs 
 			for (int s = 0; s < KS; ++s) {
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
-					const h8 af = img[(size_t)(t * KS + s) * 64];
+					const h8 af = frag(img + t * KS + s);
 #pragma unroll
 					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
 				}
@@ -221,14 +239,14 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpDesc d, const FwdArgs 
 		// ---- output layer: out_width / 16 row tiles
 		{
 			const MlpLayer Lo = d.layers[d.n_layers - 1];
-			const h8* img = a.image + (size_t)Lo.fwd_off * 64 + lane;
+			const uint32_t img = Lo.fwd_off;
 			for (uint32_t to = 0; to < out_w / 16; ++to) {
 				f4 o[NB];
 #pragma unroll
 				for (int b = 0; b < NB; ++b) o[b] = f4{0, 0, 0, 0};
 #pragma unroll
 				for (int s = 0; s < KS; ++s) {
-					const h8 af = img[(size_t)(to * KS + s) * 64];
+					const h8 af = frag(img + to * KS + s);
 #pragma unroll
 					for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], o[b]);
 				}
@@ -564,6 +582,22 @@ void mlp_forward_io(hipStream_t stream, const MlpDesc& d, const void* image, uin
 	if (n == 0) return;
 	FwdArgs a{(const half_t*)io.x_half, (half_t*)io.out_half, (half_t*)hidden, (const h8*)image, n, io.x_plane_features,
 	          io.x_f32, io.x_f32_dims, io.x_scale, io.x_offset, io.out_f32, io.out_f32_dims};
+	// wide inference: fragment image in LDS, 4 column blocks per wave, persistent workgroups of 8 waves (see k_mlp_fwd)
+	const uint32_t image_bytes = d.n_frags_fwd * 1024;
+	const char* lds_env = getenv("TCNN_AMD_MLP_FWD_LDS"); // "0": the L2-resident form (A/B runs; read per call so that tests cover both)
+	const bool lds_inference = !(lds_env && lds_env[0] == '0');
+	if (lds_inference && d.width == 128 && hidden == nullptr && image_bytes <= 150 * 1024 && n >= 256 * 8 * 64) {
+		constexpr int NB = 4, THREADS = 512;
+		const uint32_t grid = std::min<uint32_t>(256, div_round_up(n / (16 * NB), THREADS / 64));
+		auto go = [&](auto kernel) {
+			HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)image_bytes));
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(THREADS), image_bytes, stream, d, a);
+			HIP_CHECK_THROW(hipGetLastError());
+		};
+		if (d.activation == (uint32_t)Activation::ReLU) go(k_mlp_fwd<128, NB, (int)Activation::ReLU, true, THREADS>);
+		else go(k_mlp_fwd<128, NB, -1, true, THREADS>);
+		return;
+	}
 	switch (d.width) {
 		case 16: return launch_fwd_act<16, nb_for_width(16)>(stream, d, a, mlp_grid(n, nb_for_width(16)));
 		case 32: return launch_fwd_act<32, nb_for_width(32)>(stream, d, a, mlp_grid(n, nb_for_width(32)));
