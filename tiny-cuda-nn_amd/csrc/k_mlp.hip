@@ -220,16 +220,12 @@ __global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdA
 		for (uint32_t l = 1; l < d.n_hidden; ++l) {
 			const uint32_t img = d.layers[l].fwd_off;
 #pragma unroll
-			for (int t = 0; t < T; ++t)
-#pragma unroll
-				for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
-#pragma unroll
 			for (int s = 0; s < KS; ++s) {
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
 					const h8 af = frag(img + t * KS + s);
 #pragma unroll
-					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
+					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], s == 0 ? f4{0, 0, 0, 0} : acc[t][b]); // first k-step: C = inline 0, no register clearing
 				}
 			}
 			activate_pack<T, KS, NB, ACT>(acc, hf, d.activation);
@@ -243,12 +239,10 @@ __global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdA
 			for (uint32_t to = 0; to < out_w / 16; ++to) {
 				f4 o[NB];
 #pragma unroll
-				for (int b = 0; b < NB; ++b) o[b] = f4{0, 0, 0, 0};
-#pragma unroll
 				for (int s = 0; s < KS; ++s) {
 					const h8 af = frag(img + to * KS + s);
 #pragma unroll
-					for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], o[b]);
+					for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], s == 0 ? f4{0, 0, 0, 0} : o[b]);
 				}
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
