@@ -205,7 +205,7 @@ struct EncodingContext {
 	ArenaBuf dy_dx;       // grid only: float [n][L*F][D]
 	ArenaBuf chunk_mask;  // grid only: uint64 [L][32][n/64] bit planes, which samples touch which scatter chunk (filter for the LDS scatter)
 	uint32_t n = 0;
-	bool dy_records = false; // the level planes handed to backward() hold 16-byte scatter records {coordinates, gradients} (mlp_train_fused)
+	mutable bool dy_records = false; // the level planes handed to backward() hold 16-byte scatter records {coordinates, gradients} (mlp_train_fused); set by the caller of backward()
 };
 
 class Encoding {
@@ -922,16 +922,30 @@ public:
 	}
 
 	struct Ctx : public ModelContext {
-		ArenaBuf network_input;
+		ArenaBuf network_input;     // AoS [n][padded], or level planes when x_plane_f > 0
 		EncodingContext encoding_ctx;
-		NetworkContext network_ctx;
+		NetworkContext network_ctx; // hidden activations; empty for fused contexts
+		uint32_t x_plane_f = 0;
+		bool fused = false;         // produced by fused_encode(): backward() goes through the fused MLP kernel
 	};
 
+	// cpp_api.cu:84-95.  Without input gradients the forward pass keeps nothing but the encoded batch: backward() recomputes the
+	// MLP's forward pass inside the fused kernel (k_train.hip) from it, which is cheaper than storing and re-reading the hidden
+	// activations (k_mlp_fwd with hidden stores + k_mlp_bwd + 3 x k_wgrad: 158 us; the fused kernel: 78 us on C3a).
 	std::unique_ptr<ModelContext> forward(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params, bool prepare_input_gradients) override {
 		check_batch(n);
 		auto ctx = std::make_unique<Ctx>();
 		if (n == 0) return ctx;
 		const _Float16* p = (const _Float16*)params;
+		if (!prepare_input_gradients && fused_step_supported(n)) {
+			fused_encode(stream, *ctx, n, input, params, false, true);
+			MlpIo io{};
+			io.x_half = ctx->network_input.data();
+			io.x_plane_features = ctx->x_plane_f;
+			io.out_half = output;
+			m_network->inference_io(stream, n, io, p);
+			return ctx;
+		}
 		ctx->network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
 		ctx->encoding_ctx = m_encoding->forward(stream, n, input, p + m_network->n_params(), ctx->network_input.data(), prepare_input_gradients, true);
 		ctx->network_ctx = m_network->forward(stream, n, ctx->network_input.data(), output, p);
@@ -945,6 +959,11 @@ public:
 		const Ctx& ctx = dynamic_cast<const Ctx&>(mctx);
 		const _Float16* p = (const _Float16*)params;
 		_Float16* g = (_Float16*)gradients;
+		if (ctx.fused) {
+			if (dL_dinput) throw std::runtime_error{"NetworkWithInputEncoding::backward: input gradients were not prepared by forward()"};
+			fused_mlp_and_scatter(stream, ctx, n, input, nullptr, nullptr, dL_doutput, LossType::L2, 1.0f, nullptr, nullptr, nullptr, nullptr, params, gradients, mode);
+			return;
+		}
 		ArenaBuf dL_dnetwork_input;
 		if (m_encoding->n_params() > 0 || dL_dinput) { // :93-96
 			dL_dnetwork_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
@@ -975,22 +994,38 @@ public:
 	                                         void* gradients, GradientMode mode) {
 		check_batch(n);
 		auto ctx = std::make_unique<Ctx>();
+		fused_encode(stream, *ctx, n, input, params, dL_dinput != nullptr, mode != GradientMode::Ignore);
+		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, dL_dinput, params, gradients, mode);
+		return ctx;
+	}
+
+	// first half of the fused step: the encoding, as level planes where the encoding can produce them
+	void fused_encode(hipStream_t stream, Ctx& ctx, uint32_t n, MatView input, const void* params, bool prepare_input_gradients, bool prepare_param_gradients) {
+		const _Float16* p = (const _Float16*)params;
+		const uint32_t n_net = (uint32_t)m_network->n_params();
+		ctx.network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
+		// grids hand the encoded batch over as level planes (XCD-aware forward kernel, scatter filter produced on the way)
+		ctx.x_plane_f = prepare_input_gradients ? 0 : m_encoding->forward_plane_features(n);
+		if (ctx.x_plane_f) ctx.encoding_ctx = m_encoding->forward_planes(stream, n, input, p + n_net, ctx.network_input.data(), prepare_param_gradients);
+		else ctx.encoding_ctx = m_encoding->forward(stream, n, input, p + n_net, ctx.network_input.data(), prepare_input_gradients, prepare_param_gradients);
+		ctx.fused = true;
+	}
+
+	// second half: ONE MLP kernel (forward recomputed in registers, loss or external dL/doutput, backward, weight gradients),
+	// the slab reduction and the encoding's backward pass.  target == nullptr requires external_dL_dy.
+	void fused_mlp_and_scatter(hipStream_t stream, const Ctx& ctx, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
+	                           LossType loss, float loss_scale, void* out, void* dL_dout, float* L, MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) {
 		const _Float16* p = (const _Float16*)params;
 		_Float16* g = (_Float16*)gradients;
 		const uint32_t n_net = (uint32_t)m_network->n_params();
-		ctx->network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
-		// grids hand the encoded batch over as level planes (XCD-aware forward kernel, scatter filter produced on the way)
-		const uint32_t x_plane_f = dL_dinput ? 0 : m_encoding->forward_plane_features(n);
-		if (x_plane_f) ctx->encoding_ctx = m_encoding->forward_planes(stream, n, input, p + n_net, ctx->network_input.data(), mode != GradientMode::Ignore);
-		else ctx->encoding_ctx = m_encoding->forward(stream, n, input, p + n_net, ctx->network_input.data(), dL_dinput != nullptr, mode != GradientMode::Ignore);
-
+		const uint32_t x_plane_f = ctx.x_plane_f;
 		const bool need_dx = m_encoding->n_params() > 0 || dL_dinput;
 		ArenaBuf dL_dnetwork_input;
 		const uint32_t plane_f = need_dx ? m_encoding->level_plane_features(dL_dinput != nullptr, mode) : 0;
 		// scatter records: the MLP kernel interleaves the samples' coordinates with dL/d(encoding) so that the grid scatter needs one gather per hit
 		const bool records = plane_f > 0 && m_encoding->padded_output_width() == m_encoding->output_width() && m_encoding->scatter_records_usable(input);
 		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, records ? (size_t)n * (m_encoding->output_width() / plane_f) * 16 : (size_t)n * m_encoding->padded_output_width() * 2};
-		ctx->encoding_ctx.dy_records = records;
+		ctx.encoding_ctx.dy_records = records;
 
 		ArenaBuf image = m_network->prepare(stream, params, true);
 		const MlpDesc& d = m_network->desc();
@@ -1001,13 +1036,12 @@ public:
 			n_slabs = mlp_train_fused_grid(d, n);
 			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
 		}
-		mlp_train_fused(stream, d, image.data(), n, ctx->network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L,
+		mlp_train_fused(stream, d, image.data(), n, ctx.network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L,
 		                dL_dnetwork_input.data(), plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u, slabs.as<float>(), n_net);
 		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
 		if (need_dx) {
-			m_encoding->backward(stream, ctx->encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + n_net, g ? g + n_net : nullptr, mode, plane_f > 0);
+			m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + n_net, g ? g + n_net : nullptr, mode, plane_f > 0);
 		}
-		return ctx;
 	}
 
 	Json hyperparams() const override {
