@@ -24,6 +24,11 @@
 namespace tcnn_amd {
 namespace {
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL store of the wave
+// (s_waitcnt vmcnt(0)); the trips' stores (outputs, loss values, scatter records) need no such wait -- nobody in the
+// workgroup reads them -- and waiting for their write acknowledgements twice per trip is pure latency.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int TR_PAD = 8; // halves of row padding of the LDS images (rows stay 16-byte aligned)
 
 struct TrainArgs {
@@ -44,7 +49,14 @@ struct TrainArgs {
 	const float* rec_x;     // dL_dx as 16-byte scatter records (mlp_device.h store_dx_record): the samples' coordinates, AoS [n][rec_dims]
 	uint32_t rec_dims;
 	uint32_t x_plane_f;     // 0: x is AoS [n][in_width]; F: x is level planes [in_width / F][n][F] (k_grid_planes.hip)
+	unsigned long long* dbg; // development aid (TCNN_AMD_MLP_TIMING): shader clocks per phase, summed over workgroup 0 / wave 0's trips
 };
+
+// phase timer (development aid): adds the clocks since the previous mark to slot i
+#define TCNN_T(i) do { if (a.dbg) { const unsigned long long tcnn_now = __builtin_readcyclecounter(); tcnn_t[i] += tcnn_now - tcnn_t_prev; tcnn_t_prev = tcnn_now; } } while (0)
+
+// A operand of an MFMA: register slot (REGW) or a 16-byte load from the fragment image
+#define TCNN_FRAG(slot, load_expr) ([&]() -> h8 { if constexpr (REGW) return rw[(slot)]; else return (load_expr); }())
 
 // PW ("private weight gradients"): every wave accumulates ALL weight-gradient tiles over its own 16 samples per trip
 // (v_mfma_f32_16x16x16_f16, k = the wave's 16 rows of the LDS images) instead of sharing the tiles and the k axis with the
@@ -52,7 +64,10 @@ struct TrainArgs {
 // two barriers per trip were where the shared form spent most of its time.  Costs 2x the (cheap) MFMA work and 128
 // accumulator registers; the waves' partial sums are combined through LDS once, after the last trip.
 // Requires NB == 1, W == 64, n_hidden <= 2, in_width <= 32, out_width <= 32 (static tile slots: 8 + 16 + 8).
-template <int W, int NB, int NW, int MAXT, int ACT, bool PW = false>
+// REGW ("weights in registers"): a 64-wide network with two hidden layers, <= 32 inputs and 16 outputs has 14 forward and
+// 16 backward weight fragments -- 120 VGPRs per lane.  Held in registers for the whole kernel, every MFMA of a trip takes its
+// A operand from a register instead of waiting on a 1 KB LDS (or L2) fetch, and the fragment images need no LDS space.
+template <int W, int NB, int NW, int MAXT, int ACT, bool PW = false, bool REGW = false>
 __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const TrainArgs a) {
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
@@ -119,6 +134,22 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 	}
 	const h8* img_f = image + lane;
 	const h8* img_b = image + (size_t)d.n_frags_fwd * 64 + lane;
+	// REGW slots: 0..3 W0 (t) | 4..11 W1 (t * 2 + s) | 12..13 Wout (s) | 14..17 Wout^T (t) | 18..25 W1^T (t * 2 + s) | 26..29 W0^T (ti * 2 + s)
+	h8 rw[REGW ? 30 : 1];
+	if constexpr (REGW) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) rw[i] = img_f[(size_t)(d.layers[0].fwd_off + i) * 64];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) rw[4 + i] = img_f[(size_t)(d.layers[1].fwd_off + i) * 64];
+#pragma unroll
+		for (int i = 0; i < 2; ++i) rw[12 + i] = img_f[(size_t)(d.layers[2].fwd_off + i) * 64];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) rw[14 + i] = img_b[(size_t)(d.layers[2].bwd_off + i) * 64];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) rw[18 + i] = img_b[(size_t)(d.layers[1].bwd_off + i) * 64];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) rw[26 + i] = img_b[(size_t)(d.layers[0].bwd_off + i) * 64];
+	}
 	const uint32_t n_total = a.n * a.dims; // loss normalisation (relative_l2.h:58)
 	const uint32_t n_trips = a.n / S;
 	const uint32_t row0 = wave * NB * 16; // this wave's first row inside the LDS images
@@ -147,10 +178,31 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 	// workgroup start a trip together, so nobody else would cover that latency.
 	h8 pre[NB];
 	bool have_pre = false;
+	// ... and so are the targets of the first output tile and the coordinates for the scatter records: vmcnt returns in order,
+	// so a load issued where its value is needed also waits for the write acknowledgement of every store issued before it
+	// (outputs, loss values, records) -- measured: 28 % of the kernel sat in the loss section, waiting for 3 floats.
+	float pre_t[NB][4], pre_pdf[NB][4], pre_x[NB][3];
+	auto load_aux = [&](const uint32_t trip_s0) {
+#pragma unroll
+		for (int b = 0; b < NB; ++b) {
+			const uint32_t sample = trip_s0 + 16 * b + c;
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const uint32_t j = 4 * q + r;
+				pre_t[b][r] = (!a.ext_dy && j < a.dims) ? a.target[sample * a.dims + j] : 0.0f;
+				pre_pdf[b][r] = (!a.ext_dy && a.data_pdf && j < a.dims) ? a.data_pdf[sample * a.dims + j] : 1.0f;
+			}
+#pragma unroll
+			for (int k = 0; k < 3; ++k) pre_x[b][k] = (a.rec_x && k < (int)a.rec_dims) ? a.rec_x[(size_t)sample * a.rec_dims + k] : 0.0f;
+		}
+	};
+	if (blockIdx.x < n_trips) load_aux(blockIdx.x * S + row0);
 
+	unsigned long long tcnn_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	for (uint32_t trip = blockIdx.x; trip < n_trips; trip += gridDim.x) {
 		const uint32_t s0 = trip * S + row0; // first sample of this wave
 
+		unsigned long long tcnn_t_prev = a.dbg ? __builtin_readcyclecounter() : 0;
 		// =================================================================== phase A: forward
 		f4 acc[T][NB];
 #pragma unroll
@@ -174,7 +226,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 				}
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
-					const h8 af = img[(size_t)(t * ks0 + s) * 64];
+					const h8 af = TCNN_FRAG(t, img[(size_t)(t * ks0 + s) * 64]);
 #pragma unroll
 					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, bf[b], acc[t][b]);
 				}
@@ -212,7 +264,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 			for (int s = 0; s < KS; ++s) {
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
-					const h8 af = img[(size_t)(t * KS + s) * 64];
+					const h8 af = TCNN_FRAG(4 + t * KS + s, img[(size_t)(t * KS + s) * 64]);
 #pragma unroll
 					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
 				}
@@ -220,6 +272,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 			finish_layer(l);
 		}
 
+		TCNN_T(0);
 		// =================================================================== output layer + loss (on the accumulator tile)
 		h8 dyf[NB]; // dL/d(pre-activation output) as the B fragment of the first backward product (k = output index)
 #pragma unroll
@@ -235,7 +288,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 					for (int b = 0; b < NB; ++b) o[b] = f4{0, 0, 0, 0};
 #pragma unroll
 					for (int s = 0; s < KS; ++s) {
-						const h8 af = img[(size_t)(to * KS + s) * 64];
+						const h8 af = TCNN_FRAG(12 + to * KS + s, img[(size_t)(to * KS + s) * 64]);
 #pragma unroll
 						for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], o[b]);
 					}
@@ -258,8 +311,8 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 								if (j < a.dims) {
 									const uint32_t target_idx = sample * a.dims + j;
 									const float prediction = (float)ov[r];
-									const float pdf = a.data_pdf ? a.data_pdf[target_idx] : 1;
-									const float difference = prediction - a.target[target_idx];
+									const float pdf = to == 0 ? pre_pdf[b][r] : (a.data_pdf ? a.data_pdf[target_idx] : 1);
+									const float difference = prediction - (to == 0 ? pre_t[b][r] : a.target[target_idx]);
 									float gradient;
 									if (a.loss_type == (uint32_t)LossType::RelativeL2) {
 										const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
@@ -291,6 +344,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 			}
 		}
 
+		TCNN_T(1);
 		// =================================================================== backward chain
 #pragma unroll
 		for (int t = 0; t < T; ++t)
@@ -300,7 +354,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 			const h8* img = img_b + (size_t)d.layers[d.n_layers - 1].bwd_off * 64; // Wout^T: T row tiles, one k-step (out_width <= 32)
 #pragma unroll
 			for (int t = 0; t < T; ++t) {
-				const h8 af = img[(size_t)t * 64];
+				const h8 af = TCNN_FRAG(14 + t, img[(size_t)t * 64]);
 #pragma unroll
 				for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, dyf[b], acc[t][b]);
 			}
@@ -336,38 +390,53 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 				for (int s = 0; s < KS; ++s) {
 #pragma unroll
 					for (int t = 0; t < T; ++t) {
-						const h8 af = img[(size_t)(t * KS + s) * 64];
+						const h8 af = TCNN_FRAG(18 + t * KS + s, img[(size_t)(t * KS + s) * 64]);
 #pragma unroll
 						for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
 					}
 				}
 			}
 		}
+		TCNN_T(2);
 		if (a.dL_dx) { // dX = W0^T dH_0
 			const h8* img = img_b + (size_t)d.layers[0].bwd_off * 64;
-			for (uint32_t ti = 0; ti < in_w / 16; ++ti) {
+			auto dx_tile = [&](const uint32_t ti, const h8 (&af)[KS]) {
 				f4 o[NB];
 #pragma unroll
 				for (int b = 0; b < NB; ++b) o[b] = f4{0, 0, 0, 0};
 #pragma unroll
 				for (int s = 0; s < KS; ++s) {
-					const h8 af = img[(size_t)(ti * KS + s) * 64];
 #pragma unroll
-					for (int b = 0; b < NB; ++b) o[b] = mfma(af, hf[s][b], o[b]);
+					for (int b = 0; b < NB; ++b) o[b] = mfma(af[s], hf[s][b], o[b]);
 				}
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					const h4 v = h4{(half_t)o[b][0], (half_t)o[b][1], (half_t)o[b][2], (half_t)o[b][3]};
 					if (a.rec_x) {
 						const uint32_t sample = s0 + 16 * b + c;
-						float xs[3];
-						xs[0] = a.rec_x[(size_t)sample * a.rec_dims];
-						xs[1] = a.rec_x[(size_t)sample * a.rec_dims + 1];
-						xs[2] = a.rec_dims == 3 ? a.rec_x[(size_t)sample * a.rec_dims + 2] : 0.0f;
+						const float xs[3] = {pre_x[b][0], pre_x[b][1], pre_x[b][2]};
 						store_dx_record(a.dL_dx, a.dx_plane_f, a.rec_dims, a.n, sample, 16 * ti + 4 * q, v, xs);
 					} else {
 						store_dx(a.dL_dx, a.dx_plane_f, a.n, in_w, s0 + 16 * b + c, 16 * ti + 4 * q, v);
 					}
+				}
+			};
+			if constexpr (REGW) { // at most 2 input tiles, fragment slots 26 + ti * KS + s
+				static_assert(KS == 2, "REGW is laid out for 64-wide networks");
+				{
+					const h8 af[KS] = {rw[26], rw[27]};
+					dx_tile(0, af);
+				}
+				if (in_w > 16) {
+					const h8 af[KS] = {rw[28], rw[29]};
+					dx_tile(1, af);
+				}
+			} else {
+				for (uint32_t ti = 0; ti < in_w / 16; ++ti) {
+					h8 af[KS];
+#pragma unroll
+					for (int s = 0; s < KS; ++s) af[s] = img[(size_t)(ti * KS + s) * 64];
+					dx_tile(ti, af);
 				}
 			}
 		}
@@ -379,6 +448,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 #pragma unroll
 				for (int b = 0; b < NB; ++b) pre[b] = load_x(next * S + row0 + 16 * b + c, 8 * q);
 			}
+			if (have_pre) load_aux(next * S + row0);
 		}
 
 		// =================================================================== phase B: weight gradients from the LDS images
@@ -429,7 +499,9 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 			}
 			continue; // no barrier: the next trip overwrites only this wave's own rows
 		}
-		__syncthreads();
+		TCNN_T(3);
+		lds_barrier();
+		TCNN_T(4);
 		if (a.slabs) {
 			const uint32_t grp = lane >> 4, li = lane & 15;
 			const uint32_t row_in_step = 8 * grp + (li >> 2), colo = 4 * (li & 3);
@@ -453,7 +525,9 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 				}
 			}
 		}
-		__syncthreads();
+		TCNN_T(5);
+		lds_barrier();
+		TCNN_T(6);
 	}
 
 	if constexpr (PW) {
@@ -500,6 +574,9 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 		}
 		return;
 	}
+	if (a.dbg && blockIdx.x == 0 && tid == 0) {
+		for (int i = 0; i < 8; ++i) a.dbg[i] = tcnn_t[i];
+	}
 	if (a.slabs) {
 		float* slab = a.slabs + (size_t)blockIdx.x * a.n_params;
 		const uint32_t grp = lane >> 4, li = lane & 15;
@@ -519,6 +596,7 @@ struct TrainConfig {
 	uint32_t lds_bytes, s;
 	bool ok, image_in_lds;
 	bool pw; // private weight gradients (barrier-free trips), see k_mlp_train
+	bool regw; // all weight fragments in registers, see k_mlp_train
 };
 
 // (NB, NW, MAXT) triples that are instantiated; pick_config only ever returns one of them
@@ -557,6 +635,20 @@ inline TrainConfig pick_config(const MlpDesc& d) {
 			cfg.ok = true;
 			return cfg;
 		}
+	}
+	// 64 x 2 networks with <= 32 inputs and 16 outputs: all 30 weight fragments live in registers (TCNN_AMD_MLP_REGW=0: A/B runs)
+	const char* regw_env = getenv("TCNN_AMD_MLP_REGW");
+	if (!(regw_env && regw_env[0] == '0') && d.width == 64 && d.n_hidden == 2 && d.in_width <= 32 && d.out_width == 16 && d.layers[0].ks_fwd == 1) {
+		const uint32_t s = 8 * 16;
+		cfg.nb = 1;
+		cfg.nw = 8;
+		cfg.maxt = 8;
+		cfg.s = s;
+		cfg.lds_bytes = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + TR_PAD) + (d.out_width + TR_PAD));
+		cfg.image_in_lds = false;
+		cfg.regw = true;
+		cfg.ok = true;
+		return cfg;
 	}
 	// first choice: a variant whose activation images AND the weight images fit in LDS together; else weights stay in L2
 	const char* img_env = getenv("TCNN_AMD_MLP_IMAGE_LDS"); // development aid: "0" keeps the weight images in L2
@@ -611,6 +703,16 @@ void dispatch_train(hipStream_t stream, const MlpDesc& d, const TrainArgs& a, co
 		}
 		return;
 	}
+	if (cfg.regw) {
+		auto go = [&](auto kernel) {
+			HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes));
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(8 * 64), cfg.lds_bytes, stream, d, a);
+			HIP_CHECK_THROW(hipGetLastError());
+		};
+		if (d.activation == (uint32_t)Activation::ReLU) go(k_mlp_train<64, 1, 8, 8, (int)Activation::ReLU, false, true>);
+		else go(k_mlp_train<64, 1, 8, 8, -1, false, true>);
+		return;
+	}
 #define TCNN_TRAIN_CASE(W_, NB_, NW_, MAXT_) \
 	if ((int)d.width == W_ && cfg.nb == NB_ && cfg.nw == NW_ && cfg.maxt == MAXT_) return launch_train<W_, NB_, NW_, MAXT_>(stream, d, a, grid, cfg.lds_bytes);
 	TCNN_TRAIN_CASE(64, 1, 8, 8)
@@ -647,8 +749,17 @@ void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, ui
 	const TrainConfig cfg = pick_config(d);
 	CHECK_THROW(cfg.ok && n % cfg.s == 0);
 	TrainArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)dL_dout, L, (half_t*)dL_dx, slabs, (const h8*)image,
-	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u, dx_record_x, dx_record_dims, x_plane_features};
+	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u, dx_record_x, dx_record_dims, x_plane_features, nullptr};
+	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
+	static int timing_left = 5;
+	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&a.dbg, 64));
 	dispatch_train(stream, d, a, cfg, mlp_train_fused_grid(d, n));
+	if (a.dbg) {
+		unsigned long long h[8];
+		HIP_CHECK_THROW(hipMemcpy(h, a.dbg, 64, hipMemcpyDeviceToHost));
+		if (--timing_left == 0) fprintf(stderr, "k_mlp_train wave 0 clocks over its trips: fwd %llu loss %llu bwd %llu dX+stores %llu barrier1 %llu wgrad %llu barrier2 %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+		(void)hipFree(a.dbg);
+	}
 }
 
 } // namespace tcnn_amd
