@@ -194,6 +194,58 @@ def test_grid_gradient_exact(tcnn, oracle, n_in, enc_cfg, n, accumulate):
     assert float(np.linalg.norm(a - b)) <= 2e-2 * float(np.linalg.norm(a))
 
 
+MANY_CHUNK_CASES = [
+    # tables cut into > 64 LDS chunks per level: 128 (2^19 entries x F = 4) and 1024 (2^22 entries x F = 4, the C5 shape)
+    {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0},
+    {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 4, "log2_hashmap_size": 22, "base_resolution": 64, "per_level_scale": 2.0},
+]
+
+
+@pytest.mark.parametrize("enc_cfg", MANY_CHUNK_CASES)
+def test_grid_gradient_exact_many_chunks(tcnn, oracle, enc_cfg):
+    """The fused step's own route to dL/dgrid for big tables: k_grid_fwd_planes writes the sample filter as up to 1024 bit
+    planes per level and k_grid_scatter walks them.  Checked bit for bit through the C ABI of a whole
+    NetworkWithInputEncoding: with no activation and weights in {-1, 0, 1} every sum of the MLP's backward pass is exact
+    in fp32 whatever its order, so dL/d(encoded) has the oracle's bits and the grid gradients must equal the oracle's exact
+    scatter of it.  A filter bit missing anywhere would drop a contribution."""
+    import torch
+
+    n, n_in, n_out = 4096, 3, 16
+    net_cfg = {"otype": "FullyFusedMLP", "activation": "None", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}
+    m = tcnn.NetworkWithInputEncoding(n_in, n_out, enc_cfg, net_cfg)
+    native = m.native_tcnn_module
+    ref = oracle.NetworkWithInputEncoding(n_in, n_out, enc_cfg, net_cfg)
+    n_net = ref.network.n_params
+    assert native.n_params() == ref.n_params
+
+    rs = np.random.RandomState(5)
+    params = np.zeros(ref.n_params, dtype=np.float32)  # the grid values do not enter the backward pass of a linear network
+    params[:n_net] = rs.choice([-1.0, 0.0, 1.0], size=n_net, p=[1 / 16, 7 / 8, 1 / 16])
+    params_h = oracle.half_bits(params)
+    x = oracle.Pcg32(42).uniform_strided(n * n_in).reshape(n, n_in)
+    dy = oracle.half_bits((rs.randint(-128, 129, size=(n, ref.padded_output_width)) / 64.0).astype(np.float32))
+    dy[::7] = 0
+
+    out, ctx = ref.forward(x, params_h)
+    _, dnet_in = ref.backward(x, params_h, ctx, out, dy)
+    assert np.any(_f32(dnet_in) != 0)
+    want = np.zeros(ref.encoding.n_params, dtype=np.uint16)
+    ref.encoding.backward_exact(x, dnet_in, want)
+
+    xt = _t(x)
+    pt = _t(params_h.view(np.float16)).requires_grad_(True)
+    gctx, gout = native.fwd(xt, pt)
+    _, g = native.bwd(gctx, xt, pt, gout, _t(dy.view(np.float16)))
+    got = _bits(g)[n_net:]
+    assert np.count_nonzero(want) > 0
+    assert np.array_equal(got, want)
+    # the step after the tuner re-cut the plan (second filtered launch) and the one after it give the same bits
+    for _ in range(2):
+        gctx, gout = native.fwd(xt, pt)
+        _, g2 = native.bwd(gctx, xt, pt, gout, _t(dy.view(np.float16)))
+        assert torch.equal(g, g2)
+
+
 @pytest.mark.parametrize("n_bins", [4, 16, 64])
 def test_oneblob_forward(tcnn, oracle, n_bins):
     """oneblob.h:47-67 in definition form; fp32 arithmetic is restated operation by operation -> identical bits expected."""

@@ -38,7 +38,7 @@ constexpr uint32_t SCATTER_WAVES = SCATTER_THREADS / 64;
 constexpr int SCATTER_SUB_BATCHES = 2;             // 64-sample batches whose gathers are in flight together per wave
 constexpr uint32_t SCATTER_QUEUE_IDS = 64 * SCATTER_SUB_BATCHES + 64; // wave-private compaction queue (sample ids)
 constexpr uint32_t SCATTER_LDS_BYTES = SCATTER_ACC_BYTES + SCATTER_WAVES * SCATTER_QUEUE_IDS * 4;
-constexpr uint32_t SCATTER_MAX_CHUNKS = 64;        // bit planes per level (the forward mask is a uint64)
+constexpr uint32_t SCATTER_MAX_CHUNKS = 64;        // chunks per level the uint64 mask of the AoS forward kernel can describe (the plane forward kernel: 1024)
 
 // h * 2^24 as an integer: exact for every finite fp16 value
 __device__ inline long long half_to_fixed(half_t h) {
@@ -88,7 +88,7 @@ template <int D, int F, bool REC>
 __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	const GridMeta* __restrict__ meta, const GridScatterTask* __restrict__ tasks, const uint32_t n, const MatView x,
 	const half_t* __restrict__ dL_dy, const uint32_t dy_stride_sample, const uint32_t dy_stride_level, half_t* __restrict__ grad,
-	const unsigned long long* __restrict__ chunk_bits, unsigned long long* __restrict__ scratch, const int accumulate_mode,
+	const unsigned long long* __restrict__ chunk_bits, const uint32_t planes_per_level, unsigned long long* __restrict__ scratch, const int accumulate_mode,
 	unsigned long long* __restrict__ dbg_times
 ) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 			// One bit per sample says whether it touches this chunk.  A wave reads 64 words at once (one word = the ballot of
 			// one 64-sample block), compacts the hits into its LDS queue and runs the expensive part on full batches of 64.
 			const unsigned long long* __restrict__ words =
-				chunk_bits + ((size_t)task.level * SCATTER_MAX_CHUNKS + scatter_chunk(lv, task.entry_begin)) * (n / 64) + w_begin / 64;
+				chunk_bits + ((size_t)task.level * planes_per_level + scatter_chunk(lv, task.entry_begin)) * (n / 64) + w_begin / 64;
 			uint32_t queued = 0; // wave-uniform
 			unsigned long long w_next = lane < n_blocks ? words[lane] : 0ull;
 			for (uint32_t blk0 = 0; blk0 < n_blocks; blk0 += 64) {
@@ -422,7 +422,8 @@ __global__ void __launch_bounds__(256) k_grid_scatter_finalize(const GridScatter
 
 // [n_levels][n] uint64 masks (written by k_grid_fwd) -> bit planes [n_levels][64][n / 64] uint64: word w of plane (l, c)
 // is the ballot "sample 64 w + lane touches chunk c of level l".  One wave per 64 samples of one level.
-__global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __restrict__ meta, const uint32_t n, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ bits) {
+__global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __restrict__ meta, const uint32_t n, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ bits,
+                                                          const uint32_t planes_per_level) {
 	const uint32_t level = blockIdx.y;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return; // n is a multiple of 64: whole waves leave together
@@ -435,12 +436,13 @@ __global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __res
 		const unsigned long long b = __ballot((m >> c) & 1ull);
 		if (lane == c) mine = b;
 	}
-	if (lane < n_chunks) bits[((size_t)level * SCATTER_MAX_CHUNKS + lane) * (n / 64) + i / 64] = mine;
+	if (lane < n_chunks) bits[((size_t)level * planes_per_level + lane) * (n / 64) + i / 64] = mine;
 }
 
 // set by grid_backward_lds for the duration of one launch: device buffer uint64[n_tasks][8] that receives the per-task
 // timestamps (slots 0..3: start / after zeroing / after accumulation / end, 100 MHz clock) -- input of the plan tuner
 thread_local unsigned long long* g_task_times = nullptr;
+thread_local uint32_t g_planes_per_level = SCATTER_MAX_CHUNKS; // bit planes per level of the chunk_bits buffer of the launch being issued
 
 template <int D, int F, bool REC = false>
 void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x, const void* dy, uint32_t dss, uint32_t dsl,
@@ -456,7 +458,7 @@ void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* ta
 	unsigned long long* dbg = nullptr;
 	if (timing && timing_left > 0 && !g_task_times) HIP_CHECK_THROW(hipMalloc(&dbg, (size_t)n_tasks * 8 * 8));
 	hipLaunchKernelGGL((k_grid_scatter<D, F, REC>), dim3(n_tasks), dim3(SCATTER_THREADS), SCATTER_LDS_BYTES, s, dm, tasks, n, x, (const half_t*)dy, dss, dsl, (half_t*)grad, chunk_bits,
-	                   scratch, accumulate ? 1 : 0, g_task_times ? g_task_times : dbg);
+	                   g_planes_per_level, scratch, accumulate ? 1 : 0, g_task_times ? g_task_times : dbg);
 	HIP_CHECK_THROW(hipGetLastError());
 	if (dbg) {
 		std::vector<unsigned long long> h((size_t)n_tasks * 8);
@@ -522,7 +524,8 @@ void grid_scatter_setup_levels(GridMeta& meta) {
 
 void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, const uint64_t* mask, uint64_t* bits) {
 	if (n == 0) return;
-	hipLaunchKernelGGL(k_grid_mask_to_bits, dim3(div_round_up(n, 256), meta.n_levels), dim3(256), 0, stream, dev_meta, n, (const unsigned long long*)mask, (unsigned long long*)bits);
+	hipLaunchKernelGGL(k_grid_mask_to_bits, dim3(div_round_up(n, 256), meta.n_levels), dim3(256), 0, stream, dev_meta, n, (const unsigned long long*)mask, (unsigned long long*)bits,
+	                   grid_planes_per_level(meta));
 }
 
 // Splits per level from MEASURED per-level work (microseconds of workgroup time, summed over the level's tasks of a first
@@ -704,6 +707,7 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
 		explicit TimesGuard(uint64_t* p) { g_task_times = (unsigned long long*)p; }
 		~TimesGuard() { g_task_times = nullptr; }
 	} guard{task_times};
+	g_planes_per_level = grid_planes_per_level(meta);
 	switch (meta.n_pos_dims) {
 		case 2: dispatch_scatter<2>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
 		case 3: dispatch_scatter<3>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;

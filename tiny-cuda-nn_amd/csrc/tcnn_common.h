@@ -82,8 +82,10 @@ struct MatViewMut {
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx,
                   uint64_t* chunk_mask);
 // ---- training-step forward (k_grid_planes.hip): half, F >= 2, D in {2, 3}; level-major and XCD-aware.
-// out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][64][n / 64], written for levels with > 1 scatter chunk.
+// out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][grid_planes_per_level()][n / 64], written for levels with > 1 scatter chunk.
 bool grid_planes_supported(const GridMeta& meta, uint32_t n);
+uint32_t grid_planes_spt(const GridMeta& meta);        // samples per thread of the kernel shape used for this grid
+uint32_t grid_planes_per_level(const GridMeta& meta);  // bit planes per level in chunk_bits: max scatter chunks of any level, rounded up to 64
 void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd);
 void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
                          MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits);
