@@ -22,18 +22,19 @@ namespace {
 
 constexpr int FP_THREADS = 128; // 2 waves per workgroup
 
-// Two shapes: SPT = 8 samples per thread with up to 64 scatter chunks per level (tables up to 2^19 entries at F = 2), and
-// SPT = 2 with up to 1024 chunks per level (2^22 entries at F = 4): the LDS bit planes are [waves][SPT][NCH] words.
-// FP_SPT = consecutive 64-sample groups per wave; a work item is FP_THREADS * FP_SPT samples of one level.
-template <int D, int F, int FP_SPT, int NCH>
+constexpr int FP_MAX_CHUNKS = 64; // bit planes per level: levels cut into more chunks get no filter (they are binned, k_grid_bin.hip)
+
+// FP_SPT = samples per thread = consecutive 64-sample groups per wave; a work item is FP_THREADS * FP_SPT samples of one level.
+// Two shapes: 8 (32 gathers in flight per thread), and 2 for the big 3-D grids whose 8 corners x 4 features would not fit the registers.
+template <int D, int F, int FP_SPT>
 __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 	const GridMeta* __restrict__ meta, const uint32_t* __restrict__ work, const uint32_t max_items, const uint32_t blocks_per_xcd, const uint32_t n, const MatView x,
-	const half_t* __restrict__ grid, half_t* __restrict__ out, unsigned long long* __restrict__ bits, const uint32_t planes_per_level
+	const half_t* __restrict__ grid, half_t* __restrict__ out, unsigned long long* __restrict__ bits
 ) {
 	typedef typename VecOf<half_t, F>::type vecF;
 	constexpr int FP_WAVE_SAMPLES = 64 * FP_SPT;
 	constexpr int FP_ITEM_SAMPLES = FP_THREADS * FP_SPT;
-	__shared__ unsigned long long planes[FP_THREADS / 64][FP_SPT][NCH];
+	__shared__ unsigned long long planes[FP_THREADS / 64][FP_SPT][FP_MAX_CHUNKS];
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
@@ -59,14 +60,13 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 		const half_t* __restrict__ lgrid = grid + (size_t)lv.offset * F;
 		half_t* __restrict__ lout = out + (size_t)level * n * F;
 		const uint32_t n_chunks = lv.scatter_n_chunks;
-		const bool want_bits = bits != nullptr && n_chunks > 1;
+		const bool want_bits = bits != nullptr && n_chunks > 1 && n_chunks <= FP_MAX_CHUNKS;
 		const bool lds_or = want_bits && n_chunks > 8;
 		const bool nearest = interpolation == (uint32_t)InterpolationType::Nearest;
 
 		if (lds_or) {
 #pragma unroll
-			for (int k = 0; k < FP_SPT; ++k)
-				for (uint32_t cg = 0; cg < n_chunks; cg += 64) planes[wave][k][cg + lane] = 0ull; // NCH is a multiple of 64
+			for (int k = 0; k < FP_SPT; ++k) planes[wave][k][lane] = 0ull;
 		}
 
 		// ---- phase 1: positions, indices, all gathers in flight.
@@ -173,45 +173,42 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 			}
 		}
 
-		// ---- phase 3: bit planes.  Lane c ends up with the FP_SPT consecutive words of chunk c (c + 64, ...): one dense run per lane.
+		// ---- phase 3: bit planes.  Lane c ends up with the FP_SPT consecutive words of chunk c: one dense run per lane.
 		if (want_bits) {
-			if (lds_or) __builtin_amdgcn_wave_barrier(); // LDS serves one wave's instructions in order; keep the compiler from moving the reads up
-			for (uint32_t cg = 0; cg < n_chunks; cg += 64) {
-				unsigned long long mine[FP_SPT];
-				if (lds_or) {
+			unsigned long long mine[FP_SPT];
+			if (lds_or) {
+				__builtin_amdgcn_wave_barrier(); // LDS serves one wave's instructions in order; keep the compiler from moving the reads up
 #pragma unroll
-					for (int k = 0; k < FP_SPT; ++k) mine[k] = planes[wave][k][cg + lane];
-				} else { // n_chunks <= 8: one pass
+				for (int k = 0; k < FP_SPT; ++k) mine[k] = planes[wave][k][lane];
+			} else {
 #pragma unroll
-					for (int k = 0; k < FP_SPT; ++k) {
-						mine[k] = 0;
-						for (uint32_t c = 0; c < n_chunks; ++c) {
-							const unsigned long long b = __ballot((touched[k] >> c) & 1ull);
-							if (lane == c) mine[k] = b;
-						}
+				for (int k = 0; k < FP_SPT; ++k) {
+					mine[k] = 0;
+					for (uint32_t c = 0; c < n_chunks; ++c) {
+						const unsigned long long b = __ballot((touched[k] >> c) & 1ull);
+						if (lane == c) mine[k] = b;
 					}
 				}
-				if (cg + lane < n_chunks) {
-					unsigned long long* dst = bits + ((size_t)level * planes_per_level + cg + lane) * n_words + base / 64;
-					if (base + FP_WAVE_SAMPLES <= n) {
-						typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+			}
+			if (lane < n_chunks) {
+				unsigned long long* dst = bits + ((size_t)level * FP_MAX_CHUNKS + lane) * n_words + base / 64;
+				if (base + FP_WAVE_SAMPLES <= n) {
+					typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-						for (int k = 0; k < FP_SPT; k += 2) *(u64x2*)&dst[k] = u64x2{mine[k], mine[k + 1]};
-					} else {
+					for (int k = 0; k < FP_SPT; k += 2) *(u64x2*)&dst[k] = u64x2{mine[k], mine[k + 1]};
+				} else {
 #pragma unroll
-						for (int k = 0; k < FP_SPT; ++k) if (base + k * 64 < n) dst[k] = mine[k];
-					}
+					for (int k = 0; k < FP_SPT; ++k) if (base + k * 64 < n) dst[k] = mine[k];
 				}
 			}
 		}
 	}
 }
 
-template <int D, int F, int SPT, int NCH>
-void launch_planes(hipStream_t s, const GridMeta* dm, const uint32_t* work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n, MatView x, const void* grid, void* out, uint64_t* bits,
-                   uint32_t planes_per_level) {
-	hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT, NCH>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
-	                   (unsigned long long*)bits, planes_per_level);
+template <int D, int F, int SPT>
+void launch_planes(hipStream_t s, const GridMeta* dm, const uint32_t* work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n, MatView x, const void* grid, void* out, uint64_t* bits) {
+	hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
+	                   (unsigned long long*)bits);
 	HIP_CHECK_THROW(hipGetLastError());
 }
 
@@ -223,15 +220,13 @@ uint32_t max_scatter_chunks(const GridMeta& meta) {
 
 } // namespace
 
-// samples per thread of the kernel shape used for this grid (see k_grid_fwd_planes): 8 up to 64 chunks per level, else 2
+// samples per thread of the kernel shape used for this grid (see k_grid_fwd_planes)
 uint32_t grid_planes_spt(const GridMeta& meta) { return max_scatter_chunks(meta) <= 64 ? 8u : 2u; }
-// bit planes per level in the chunk_bits buffer: the largest chunk count, rounded up to whole 64-lane groups
-uint32_t grid_planes_per_level(const GridMeta& meta) { return next_multiple(max_scatter_chunks(meta), 64u); }
 
 bool grid_planes_supported(const GridMeta& meta, uint32_t n) {
 	const uint32_t F = meta.n_features_per_level;
 	return (F == 2 || F == 4 || F == 8) && (meta.n_pos_dims == 2 || meta.n_pos_dims == 3) && meta.n_levels < 256 && n % 64 == 0 && n > 0 &&
-	       div_round_up(n, FP_THREADS * grid_planes_spt(meta)) < (1u << 24) && max_scatter_chunks(meta) <= 1024;
+	       div_round_up(n, FP_THREADS * grid_planes_spt(meta)) < (1u << 24);
 }
 
 // Work list: [0..7] = number of items of XCD x, then 8 runs of max_items entries (level << 24 | item index inside the level).
@@ -282,15 +277,14 @@ void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMet
                          MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits) {
 	CHECK_THROW(grid_planes_supported(meta, n));
 	const uint32_t F = meta.n_features_per_level;
-	const uint32_t ppl = grid_planes_per_level(meta);
-#define TCNN_PLANES_F(D, SPT, NCH) \
+#define TCNN_PLANES_F(D, SPT) \
 	switch (F) { \
-		case 2: return launch_planes<D, 2, SPT, NCH>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, ppl); \
-		case 4: return launch_planes<D, 4, SPT, NCH>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, ppl); \
-		default: return launch_planes<D, 8, SPT, NCH>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, ppl); \
+		case 2: return launch_planes<D, 2, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
+		case 4: return launch_planes<D, 4, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
+		default: return launch_planes<D, 8, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
 	}
 #define TCNN_PLANES(D) \
-	if (grid_planes_spt(meta) == 8) { TCNN_PLANES_F(D, 8, 64) } else { TCNN_PLANES_F(D, 2, 1024) }
+	if (grid_planes_spt(meta) == 8) { TCNN_PLANES_F(D, 8) } else { TCNN_PLANES_F(D, 2) }
 	if (meta.n_pos_dims == 2) { TCNN_PLANES(2) } else { TCNN_PLANES(3) }
 #undef TCNN_PLANES
 #undef TCNN_PLANES_F

@@ -23,7 +23,7 @@
 //     Coarse levels, where every sample hits the same few entries, are split over several workgroups by sample range;
 //     their exact partial sums are merged with 64-bit integer atomics in a small scratch table and rounded by
 //     k_grid_scatter_finalize.
-#include "grid_device.h"
+#include "grid_fixed.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -38,49 +38,7 @@ constexpr uint32_t SCATTER_WAVES = SCATTER_THREADS / 64;
 constexpr int SCATTER_SUB_BATCHES = 2;             // 64-sample batches whose gathers are in flight together per wave
 constexpr uint32_t SCATTER_QUEUE_IDS = 64 * SCATTER_SUB_BATCHES + 64; // wave-private compaction queue (sample ids)
 constexpr uint32_t SCATTER_LDS_BYTES = SCATTER_ACC_BYTES + SCATTER_WAVES * SCATTER_QUEUE_IDS * 4;
-constexpr uint32_t SCATTER_MAX_CHUNKS = 64;        // chunks per level the uint64 mask of the AoS forward kernel can describe (the plane forward kernel: 1024)
-
-// h * 2^24 as an integer: exact for every finite fp16 value
-__device__ inline long long half_to_fixed(half_t h) {
-	const uint16_t b = __builtin_bit_cast(uint16_t, h);
-	const uint32_t e = (b >> 10) & 31u, f = b & 1023u;
-	const unsigned long long m = e ? ((unsigned long long)(1024u | f) << (e - 1)) : (unsigned long long)f;
-	return (b & 0x8000u) ? -(long long)m : (long long)m;
-}
-
-// the same for the common case |h| < 64: h * 2^24 fits an int32 and the float detour is exact (3 instructions instead of ~12)
-__device__ inline long long half_to_fixed_fast(half_t h) {
-	const float f = (float)h;
-	long long v = (long long)(int)(f * 16777216.0f);
-	if (__builtin_expect(!(__builtin_fabsf(f) < 64.0f), 0)) v = half_to_fixed(h);
-	return v;
-}
-
-// s * 2^-24 rounded to fp16, round-to-nearest-even, one rounding
-__device__ inline half_t fixed_to_half(long long s) {
-	const bool neg = s < 0;
-	unsigned long long m = neg ? (unsigned long long)(-s) : (unsigned long long)s;
-	if (m == 0) return (half_t)0.0f;
-	const int p = 63 - __builtin_clzll(m);
-	float v;
-	if (p <= 10) {
-		v = (float)(uint32_t)m * 5.9604644775390625e-08f; // 2^-24, exact
-	} else {
-		const int shift = p - 10;
-		unsigned long long q = m >> shift;
-		const unsigned long long rem = m & ((1ull << shift) - 1), half = 1ull << (shift - 1);
-		if (rem > half || (rem == half && (q & 1ull))) ++q;
-		v = ldexpf((float)(uint32_t)q, shift - 24); // <= 12 significant bits: exact; >= 65520 becomes inf in the cast below
-	}
-	const half_t r = (half_t)v;
-	return neg ? -r : r;
-}
-
-// |s| < 2^24 (|value| < 1): s is exact as a float, the scaling is exact, and the hardware float -> half conversion is the one RNE rounding
-__device__ inline half_t fixed_to_half_fast(long long s) {
-	if (__builtin_expect((unsigned long long)(s + (1ll << 24)) < (1ull << 25), 1)) return (half_t)((float)(int)s * 5.9604644775390625e-08f);
-	return fixed_to_half(s);
-}
+constexpr uint32_t SCATTER_MAX_CHUNKS = 64;        // bit planes per level (the forward mask is a uint64); levels cut finer are binned (k_grid_bin.hip)
 
 // REC: dL_dy holds 16-byte records float4 [level][n] = {D coordinates, F gradient halves} written by the fused MLP kernel
 // (mlp_device.h store_dx_record): one gather per hit instead of two -- gathers cost ~2 clk per lane per CU whatever their width.
@@ -88,7 +46,7 @@ template <int D, int F, bool REC>
 __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	const GridMeta* __restrict__ meta, const GridScatterTask* __restrict__ tasks, const uint32_t n, const MatView x,
 	const half_t* __restrict__ dL_dy, const uint32_t dy_stride_sample, const uint32_t dy_stride_level, half_t* __restrict__ grad,
-	const unsigned long long* __restrict__ chunk_bits, const uint32_t planes_per_level, unsigned long long* __restrict__ scratch, const int accumulate_mode,
+	const unsigned long long* __restrict__ chunk_bits, unsigned long long* __restrict__ scratch, const int accumulate_mode,
 	unsigned long long* __restrict__ dbg_times
 ) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -325,7 +283,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 			// One bit per sample says whether it touches this chunk.  A wave reads 64 words at once (one word = the ballot of
 			// one 64-sample block), compacts the hits into its LDS queue and runs the expensive part on full batches of 64.
 			const unsigned long long* __restrict__ words =
-				chunk_bits + ((size_t)task.level * planes_per_level + scatter_chunk(lv, task.entry_begin)) * (n / 64) + w_begin / 64;
+				chunk_bits + ((size_t)task.level * SCATTER_MAX_CHUNKS + scatter_chunk(lv, task.entry_begin)) * (n / 64) + w_begin / 64;
 			uint32_t queued = 0; // wave-uniform
 			unsigned long long w_next = lane < n_blocks ? words[lane] : 0ull;
 			for (uint32_t blk0 = 0; blk0 < n_blocks; blk0 += 64) {
@@ -422,13 +380,12 @@ __global__ void __launch_bounds__(256) k_grid_scatter_finalize(const GridScatter
 
 // [n_levels][n] uint64 masks (written by k_grid_fwd) -> bit planes [n_levels][64][n / 64] uint64: word w of plane (l, c)
 // is the ballot "sample 64 w + lane touches chunk c of level l".  One wave per 64 samples of one level.
-__global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __restrict__ meta, const uint32_t n, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ bits,
-                                                          const uint32_t planes_per_level) {
+__global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __restrict__ meta, const uint32_t n, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ bits) {
 	const uint32_t level = blockIdx.y;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return; // n is a multiple of 64: whole waves leave together
 	const uint32_t n_chunks = meta->levels[level].scatter_n_chunks;
-	if (n_chunks <= 1) return;
+	if (n_chunks <= 1 || n_chunks > SCATTER_MAX_CHUNKS) return; // one chunk: no filter; more than 64: binned level, no filter either
 	const unsigned long long m = mask[(size_t)level * n + i];
 	const uint32_t lane = threadIdx.x & 63;
 	unsigned long long mine = 0;
@@ -436,13 +393,12 @@ __global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __res
 		const unsigned long long b = __ballot((m >> c) & 1ull);
 		if (lane == c) mine = b;
 	}
-	if (lane < n_chunks) bits[((size_t)level * planes_per_level + lane) * (n / 64) + i / 64] = mine;
+	if (lane < n_chunks) bits[((size_t)level * SCATTER_MAX_CHUNKS + lane) * (n / 64) + i / 64] = mine;
 }
 
 // set by grid_backward_lds for the duration of one launch: device buffer uint64[n_tasks][8] that receives the per-task
 // timestamps (slots 0..3: start / after zeroing / after accumulation / end, 100 MHz clock) -- input of the plan tuner
 thread_local unsigned long long* g_task_times = nullptr;
-thread_local uint32_t g_planes_per_level = SCATTER_MAX_CHUNKS; // bit planes per level of the chunk_bits buffer of the launch being issued
 
 template <int D, int F, bool REC = false>
 void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x, const void* dy, uint32_t dss, uint32_t dsl,
@@ -458,7 +414,7 @@ void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* ta
 	unsigned long long* dbg = nullptr;
 	if (timing && timing_left > 0 && !g_task_times) HIP_CHECK_THROW(hipMalloc(&dbg, (size_t)n_tasks * 8 * 8));
 	hipLaunchKernelGGL((k_grid_scatter<D, F, REC>), dim3(n_tasks), dim3(SCATTER_THREADS), SCATTER_LDS_BYTES, s, dm, tasks, n, x, (const half_t*)dy, dss, dsl, (half_t*)grad, chunk_bits,
-	                   g_planes_per_level, scratch, accumulate ? 1 : 0, g_task_times ? g_task_times : dbg);
+	                   scratch, accumulate ? 1 : 0, g_task_times ? g_task_times : dbg);
 	HIP_CHECK_THROW(hipGetLastError());
 	if (dbg) {
 		std::vector<unsigned long long> h((size_t)n_tasks * 8);
@@ -519,13 +475,19 @@ void grid_scatter_setup_levels(GridMeta& meta) {
 			lv.scatter_shift = 0;
 			while ((1u << lv.scatter_shift) < lv.scatter_per_chunk) ++lv.scatter_shift;
 		}
+		// More chunks than the sample filter describes: the level's gradients are binned instead (k_grid_bin.hip).  Where a visit
+		// of the filtered form costs several gathers (no 16-byte records: 3-D with F = 4) binning already wins from 9 chunks on
+		// (measured on C5: the 64-chunk level 2.4x faster; on C3a, with records, the filtered form is 1.5x faster at 64 chunks).
+		// TCNN_AMD_BIN_MIN_CHUNKS=k moves the threshold (levels with more than k chunks are binned), for A/B runs.
+		uint32_t bin_above = grid_scatter_records_supported(meta) ? SCATTER_MAX_CHUNKS : 8u;
+		if (const char* e = getenv("TCNN_AMD_BIN_MIN_CHUNKS")) bin_above = std::min<uint32_t>((uint32_t)std::max(atoi(e), 1), SCATTER_MAX_CHUNKS);
+		lv.scatter_binned = (lv.scatter_n_chunks > bin_above && lv.scatter_n_chunks <= grid_bin_max_chunks() && grid_bin_supported(meta)) ? 1u : 0u;
 	}
 }
 
 void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, const uint64_t* mask, uint64_t* bits) {
 	if (n == 0) return;
-	hipLaunchKernelGGL(k_grid_mask_to_bits, dim3(div_round_up(n, 256), meta.n_levels), dim3(256), 0, stream, dev_meta, n, (const unsigned long long*)mask, (unsigned long long*)bits,
-	                   grid_planes_per_level(meta));
+	hipLaunchKernelGGL(k_grid_mask_to_bits, dim3(div_round_up(n, 256), meta.n_levels), dim3(256), 0, stream, dev_meta, n, (const unsigned long long*)mask, (unsigned long long*)bits);
 }
 
 // Splits per level from MEASURED per-level work (microseconds of workgroup time, summed over the level's tasks of a first
@@ -540,6 +502,7 @@ static void tuned_splits(const GridMeta& meta, uint32_t n, const std::vector<flo
 	uint32_t n_fine = 0;
 	auto is_fine = [&](uint32_t l) { return meta.levels[l].scatter_n_chunks > 8; };
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		if (meta.levels[l].scatter_binned) continue;
 		if (is_fine(l)) { w_fine += level_us[l]; n_fine += meta.levels[l].scatter_n_chunks; }
 		else w_coarse += level_us[l];
 	}
@@ -571,7 +534,7 @@ static void tuned_splits(const GridMeta& meta, uint32_t n, const std::vector<flo
 	}
 	uint32_t n_coarse_tasks = 0;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
-		if (is_fine(l)) { splits[l] = 1; continue; }
+		if (is_fine(l) || meta.levels[l].scatter_binned) { splits[l] = 1; continue; }
 		const double per_chunk_us = level_us[l] / meta.levels[l].scatter_n_chunks;
 		splits[l] = std::min(max_splits, std::max(1u, (uint32_t)(per_chunk_us / task_us + 0.5)));
 		n_coarse_tasks += splits[l] * meta.levels[l].scatter_n_chunks;
@@ -609,6 +572,7 @@ void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatter
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
 		if (l < dbg_lo || l > dbg_hi) continue;
 		const GridLevel& lv = meta.levels[l];
+		if (lv.scatter_binned) continue; // grid_backward_binned serves this level
 		const uint32_t n_chunks = lv.scatter_n_chunks;
 		const uint32_t per_chunk = lv.scatter_per_chunk;
 		// corner events landing in one chunk; beyond ~64k the adds dominate: split the samples over several workgroups
@@ -707,7 +671,6 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
 		explicit TimesGuard(uint64_t* p) { g_task_times = (unsigned long long*)p; }
 		~TimesGuard() { g_task_times = nullptr; }
 	} guard{task_times};
-	g_planes_per_level = grid_planes_per_level(meta);
 	switch (meta.n_pos_dims) {
 		case 2: dispatch_scatter<2>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
 		case 3: dispatch_scatter<3>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;

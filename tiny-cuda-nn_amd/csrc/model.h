@@ -228,7 +228,7 @@ public:
 	// dy_planes: dL_dy is laid out as level planes [padded / F][n][F] (only if level_plane_features() allowed it), else AoS
 	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) = 0;
 	// > 0: this encoding's backward prefers dL_dy in level planes with that many features per plane (see k_grid_bwd_lds)
-	virtual uint32_t level_plane_features(bool need_dL_dx, GradientMode mode, bool filter_available) const { return 0; }
+	virtual uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const { return 0; }
 	// true: the encoding is half(x * scale + offset) padded with ones -- cheap enough to apply inside the consumer's load
 	virtual bool as_identity(float& scale, float& offset) const { return false; }
 	// true: backward() (with level planes allowed) prefers 16-byte records {coordinates, gradients} per (level, sample)
@@ -342,8 +342,9 @@ public:
 		if (F >= 2) {
 			grid_scatter_setup_levels(m_meta);
 			for (uint32_t i = 0; i < n_levels; ++i) {
-				m_scatter_mask_ok &= m_meta.levels[i].scatter_n_chunks <= grid_scatter_max_chunks(); // the AoS forward kernel's filter is a uint64 per (level, sample)
-				m_scatter_planes_ok &= m_meta.levels[i].scatter_n_chunks <= 1024;                    // the plane forward kernel builds up to 1024 bit planes per level
+				// the sample filter describes 64 chunks per level; levels cut finer go through the binned kernels (F <= 4, up to 4096 chunks)
+				m_scatter_levels_ok &= m_meta.levels[i].scatter_binned || m_meta.levels[i].scatter_n_chunks <= grid_scatter_max_chunks();
+				m_any_binned |= m_meta.levels[i].scatter_binned != 0;
 			}
 		}
 	}
@@ -378,12 +379,12 @@ public:
 		EncodingContext ctx;
 		if ((!out && !prepare_input_gradients) || padded_output_width() == 0 || n == 0) return ctx;
 		if (prepare_input_gradients) ctx.dy_dx = ArenaBuf{stream, (size_t)n * m_n_features * m_meta.n_pos_dims * sizeof(float)};
-		const bool want_filter = prepare_param_gradients && lds_scatter_usable() && m_scatter_mask_ok && n % 64 == 0;
+		const bool want_filter = prepare_param_gradients && lds_scatter_usable() && n % 64 == 0;
 		ArenaBuf mask;
 		if (want_filter) mask = ArenaBuf{stream, (size_t)m_meta.n_levels * n * sizeof(uint64_t)};
 		grid_forward(stream, m_meta, dev_meta(), m_fp32, n, x, params, out, padded_output_width(), ctx.dy_dx.as<float>(), mask.as<uint64_t>());
 		if (want_filter) {
-			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_planes_per_level(m_meta) * (n / 64) * sizeof(uint64_t)};
+			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_scatter_max_chunks() * (n / 64) * sizeof(uint64_t)};
 			ctx.n = n;
 			grid_mask_to_bits(stream, m_meta, dev_meta(), n, mask.as<uint64_t>(), ctx.chunk_mask.as<uint64_t>());
 		}
@@ -422,7 +423,7 @@ public:
 		CHECK_THROW(forward_plane_features(n) > 0);
 		const bool want_filter = prepare_param_gradients && lds_scatter_usable();
 		if (want_filter) {
-			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_planes_per_level(m_meta) * (n / 64) * sizeof(uint64_t)};
+			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_scatter_max_chunks() * (n / 64) * sizeof(uint64_t)};
 			ctx.n = n;
 		}
 		PlanesPlan& plan = planes_plan(n);
@@ -442,22 +443,28 @@ public:
 				else cast_half_to_float(stream, n_params(), grads, tmp.as<float>());
 				grid_backward(stream, m_meta, dev_meta(), true, n, x, dL_dy, false, padded_output_width(), tmp.data());
 				cast_float_to_half(stream, n_params(), tmp.as<float>(), grads);
-			} else if (lds_scatter_usable() && n % 64 == 0 && (m_scatter_mask_ok || (ctx.chunk_mask && ctx.n == n))) {
+			} else if (lds_scatter_usable() && n % 64 == 0) {
 				// MI355X path: LDS owner-computes scatter with exact integer accumulation; writes every element (k_grid_scatter.hip)
 				ScatterPlan& plan = scatter_plan(n);
 				const uint32_t F = m_meta.n_features_per_level;
 				const uint64_t* mask = (ctx.chunk_mask && ctx.n == n) ? ctx.chunk_mask.as<uint64_t>() : nullptr;
 				// The second filtered launch at this batch size is timed per task and the plan re-cut from the measured
 				// per-level work (grid_scatter_plan): one stream synchronisation, once per (encoding, batch size).
-				const bool tune = !plan.tuned && mask && scatter_tuning_enabled() && ++plan.launches == 2;
+				const bool tune = !plan.tuned && mask && plan.n_tasks > 0 && scatter_tuning_enabled() && ++plan.launches == 2;
 				DeviceBuf times;
 				if (tune) {
 					times.resize((size_t)plan.n_tasks * 8 * sizeof(uint64_t));
 					times.memset(0);
 				}
+				const uint32_t dy_stride_sample = dy_planes ? F : padded_output_width(), dy_stride_level = dy_planes ? n * F : F;
 				grid_backward_lds(stream, m_meta, dev_meta(), plan.dev_tasks.as<GridScatterTask>(), plan.n_tasks, plan.dev_ranges.as<GridScatterRange>(), plan.n_ranges,
-				                  plan.scratch.as<uint64_t>(), n, x, dL_dy, dy_planes ? F : padded_output_width(), dy_planes ? n * F : F, grads, mask,
+				                  plan.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, mask,
 				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, tune ? times.as<uint64_t>() : nullptr);
+				if (m_any_binned) { // levels cut into more than 64 chunks (k_grid_bin.hip)
+					CHECK_THROW(!(dy_planes && ctx.dy_records));
+					ArenaBuf workspace{stream, grid_bin_workspace_bytes(m_meta, n)};
+					grid_backward_binned(stream, m_meta, dev_meta(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, mode == GradientMode::Accumulate, workspace.data());
+				}
 				if (tune) {
 					HIP_CHECK_THROW(hipStreamSynchronize(stream));
 					std::vector<uint64_t> h((size_t)plan.n_tasks * 8);
@@ -479,12 +486,9 @@ public:
 		}
 	}
 
-	// filter_available: the context that will be handed to backward() carries the sample filter.  Tables cut into more chunks
-	// than the AoS forward kernel's uint64 mask describes get one only from forward_planes(); without it every chunk's
-	// workgroup would walk every sample, so those fall back to the global-atomic kernel (AoS gradients).
-	uint32_t level_plane_features(bool need_dL_dx, GradientMode mode, bool filter_available) const override {
+	uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const override {
 		const uint32_t F = m_meta.n_features_per_level;
-		return (lds_scatter_usable() && (filter_available || m_scatter_mask_ok) && !need_dL_dx && mode != GradientMode::Ignore) ? F : 0;
+		return (lds_scatter_usable() && !need_dL_dx && mode != GradientMode::Ignore) ? F : 0;
 	}
 
 	// The MLP kernel writes {coordinates, gradient} records and the scatter does one gather per hit instead of two: measured on
@@ -492,11 +496,11 @@ public:
 	bool scatter_records_usable(MatView x) const override {
 		const char* e = getenv("TCNN_AMD_SCATTER_RECORDS"); // read per step so that tests can cover both forms in one process
 		const bool enabled = !(e && e[0] == '0');
-		return enabled && lds_scatter_usable() && grid_scatter_records_supported(m_meta) && x.stride_dim == 1 && x.stride_sample == m_meta.n_pos_dims;
+		return enabled && lds_scatter_usable() && !m_any_binned && grid_scatter_records_supported(m_meta) && x.stride_dim == 1 && x.stride_sample == m_meta.n_pos_dims;
 	}
 
-	// half precision, F >= 2, and every level's table cut into at most 1024 chunks (the bit planes of the sample filter)
-	bool lds_scatter_usable() const { return !m_fp32 && m_meta.n_features_per_level >= 2 && use_lds_scatter() && m_scatter_planes_ok; }
+	// half precision, F >= 2, and every level's table either cut into at most 64 chunks (the sample filter) or binned
+	bool lds_scatter_usable() const { return !m_fp32 && m_meta.n_features_per_level >= 2 && use_lds_scatter() && m_scatter_levels_ok; }
 
 	// TCNN_AMD_GRID_SCATTER=atomic selects the reference-shaped global-atomic kernel (kept for A/B runs and as the fp32 / F==1 path)
 	static bool use_lds_scatter() {
@@ -564,8 +568,8 @@ private:
 	DeviceBuf m_dev_meta;
 	std::map<uint32_t, std::unique_ptr<ScatterPlan>> m_scatter_plans;
 	std::map<uint32_t, std::unique_ptr<PlanesPlan>> m_planes_plans;
-	bool m_scatter_mask_ok = true;
-	bool m_scatter_planes_ok = true;
+	bool m_scatter_levels_ok = true;
+	bool m_any_binned = false;
 	std::vector<uint32_t> m_resolutions;
 	uint32_t m_n_features, m_log2_hashmap_size, m_base_resolution, m_n_entries;
 	float m_per_level_scale;
@@ -976,7 +980,7 @@ public:
 			dL_dnetwork_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
 		}
 		// the grid scatter reads dL/d(encoding) with unit stride when the MLP writes it as level planes
-		const uint32_t plane_f = dL_dnetwork_input ? m_encoding->level_plane_features(dL_dinput != nullptr, mode, (bool)ctx.encoding_ctx.chunk_mask) : 0;
+		const uint32_t plane_f = dL_dnetwork_input ? m_encoding->level_plane_features(dL_dinput != nullptr, mode) : 0;
 		m_network->backward(stream, ctx.network_ctx, n, ctx.network_input.data(), output, dL_doutput, dL_dnetwork_input.data(), p, g, mode, plane_f);
 		if (dL_dnetwork_input) {
 			m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + m_network->n_params(),
@@ -1028,7 +1032,7 @@ public:
 		const uint32_t x_plane_f = ctx.x_plane_f;
 		const bool need_dx = m_encoding->n_params() > 0 || dL_dinput;
 		ArenaBuf dL_dnetwork_input;
-		const uint32_t plane_f = need_dx ? m_encoding->level_plane_features(dL_dinput != nullptr, mode, (bool)ctx.encoding_ctx.chunk_mask) : 0;
+		const uint32_t plane_f = need_dx ? m_encoding->level_plane_features(dL_dinput != nullptr, mode) : 0;
 		// scatter records: the MLP kernel interleaves the samples' coordinates with dL/d(encoding) so that the grid scatter needs one gather per hit
 		const bool records = plane_f > 0 && m_encoding->padded_output_width() == m_encoding->output_width() && m_encoding->scatter_records_usable(input);
 		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, records ? (size_t)n * (m_encoding->output_width() / plane_f) * 16 : (size_t)n * m_encoding->padded_output_width() * 2};

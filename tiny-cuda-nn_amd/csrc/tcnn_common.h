@@ -52,6 +52,7 @@ struct GridLevel {
 	uint32_t scatter_per_chunk;
 	uint32_t scatter_shift;    // log2(scatter_per_chunk) if it is a power of two, else 0xffffffff
 	uint32_t scatter_n_chunks;
+	uint32_t scatter_binned;   // 1: too many chunks for the sample filter -- the level's gradients go through k_grid_bin.hip
 };
 
 struct GridMeta {
@@ -82,10 +83,9 @@ struct MatViewMut {
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx,
                   uint64_t* chunk_mask);
 // ---- training-step forward (k_grid_planes.hip): half, F >= 2, D in {2, 3}; level-major and XCD-aware.
-// out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][grid_planes_per_level()][n / 64], written for levels with > 1 scatter chunk.
+// out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][64][n / 64], written for levels with 2 .. 64 scatter chunks.
 bool grid_planes_supported(const GridMeta& meta, uint32_t n);
 uint32_t grid_planes_spt(const GridMeta& meta);        // samples per thread of the kernel shape used for this grid
-uint32_t grid_planes_per_level(const GridMeta& meta);  // bit planes per level in chunk_bits: max scatter chunks of any level, rounded up to 64
 void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd);
 void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
                          MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits);
@@ -123,6 +123,14 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
                        uint64_t* task_times = nullptr); // task_times (optional): device uint64[n_tasks][8], per-task timestamps for the plan tuner
 // dy_records: dL_dy is float4 [n_levels][n] scatter records {coordinates, F halves} (see mlp_train_fused); x is then not read
 bool grid_scatter_records_supported(const GridMeta& meta);
+
+// ---- binned form for levels cut into more than 64 chunks (k_grid_bin.hip; GridLevel::scatter_binned): no filter, no gathers.
+// Same exact result as grid_backward_lds; writes every gradient element of the binned levels.  workspace: grid_bin_workspace_bytes().
+bool grid_bin_supported(const GridMeta& meta); // F in {2, 4}
+uint32_t grid_bin_max_chunks();                // chunks per level (4096)
+size_t grid_bin_workspace_bytes(const GridMeta& meta, uint32_t n);
+void grid_backward_binned(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, MatView x, const void* dL_dy, uint32_t dy_stride_sample,
+                          uint32_t dy_stride_level, void* grad, bool accumulate, void* workspace);
 void grid_backward_input(hipStream_t stream, const GridMeta& meta, bool fp32, uint32_t n, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
 
 // OneBlob / Identity (AoS output, T = half or float)
