@@ -46,7 +46,11 @@ __device__ inline half_t fixed_to_half(long long s) {
 
 // |s| < 2^24 (|value| < 1): s is exact as a float, the scaling is exact, and the hardware float -> half conversion is the one RNE rounding
 __device__ inline half_t fixed_to_half_fast(long long s) {
-	if (__builtin_expect((unsigned long long)(s + (1ll << 24)) < (1ull << 25), 1)) return (half_t)((float)(int)s * 5.9604644775390625e-08f);
+	if (__builtin_expect((unsigned long long)(s + (1ll << 24)) < (1ull << 25), 1)) {
+		int lo = (int)s;
+		asm volatile("" : "+v"(lo)); // hidden from the optimiser, which otherwise widens (float)(int)s back into a 13-instruction 64-bit conversion
+		return (half_t)((float)lo * 5.9604644775390625e-08f);
+	}
 	return fixed_to_half(s);
 }
 

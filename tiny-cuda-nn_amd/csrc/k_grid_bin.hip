@@ -31,7 +31,7 @@ constexpr uint32_t BIN_MAX_CHUNKS = 4096;    // chunks per level (LDS: three uin
 constexpr uint32_t BIN_COUNT_THREADS = 256;
 constexpr uint32_t BIN_FILL_THREADS = 512;
 constexpr uint32_t BIN_ACC_THREADS = 1024;
-constexpr uint32_t BIN_ACC_BYTES = 128 * 1024; // must hold scatter_per_chunk * F accumulators (grid_scatter_setup_levels)
+constexpr uint32_t BIN_ACC_BYTES_MAX = 128 * 1024;
 
 struct BinArgs {
 	const GridMeta* meta;
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(BIN_FILL_THREADS) k_bin_fill(
 // the (first, count) pair of the one after that while the adds run, so no phase waits for HBM.
 template <int F>
 __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
-	const BinArgs a, const uint32_t n_slots, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ base, const uint16_t* __restrict__ in_idx,
+	const BinArgs a, const uint32_t n_slots, const uint32_t acc_bytes, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ base, const uint16_t* __restrict__ in_idx,
 	const half_t* __restrict__ in_val, half_t* __restrict__ grad, const int accumulate_mode, unsigned long long* __restrict__ dbg
 ) {
 	typedef typename VecOf<half_t, F>::type vecF;
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
 	{
 		typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 		u4* a4 = (u4*)smem;
-		for (uint32_t i = tid; i < BIN_ACC_BYTES / 16; i += BIN_ACC_THREADS) a4[i] = u4{0, 0, 0, 0};
+		for (uint32_t i = tid; i < acc_bytes / 16; i += BIN_ACC_THREADS) a4[i] = u4{0, 0, 0, 0};
 	}
 	__syncthreads();
 	const uint32_t n_tasks = slots[n_slots].task_begin;
@@ -317,11 +317,15 @@ __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
 	uint32_t e[PRE];
 	vecF v[PRE];
 	auto prefetch = [&](const Task& k) {
+		// unconditional loads from clamped addresses: a load under `if (j < count)` into a register that is still live makes the
+		// compiler wait for each load before issuing the next (measured: the 8 loads cost 4 HBM latencies in a row)
 		const size_t at = (size_t)k.slot * a.n * a.per_sample + k.first;
 #pragma unroll
 		for (int p = 0; p < PRE; ++p) {
 			const uint32_t j = tid + p * BIN_ACC_THREADS;
-			if (j < k.count) { e[p] = in_idx[at + j]; v[p] = ((const vecF*)in_val)[at + j]; }
+			const size_t src = k.count ? at + min(j, k.count - 1) : 0;
+			e[p] = in_idx[src];
+			v[p] = ((const vecF*)in_val)[src];
 		}
 	};
 	auto add = [&](const uint32_t entry, const vecF& c) {
@@ -369,7 +373,19 @@ __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
 		for (uint32_t i = tid; i < n_vals / 2; i += BIN_ACC_THREADS) {
 			const i64x2 s = ((i64x2*)acc)[i];
 			((i64x2*)acc)[i] = i64x2{0, 0};
-			((h2*)g)[i] = h2{fixed_to_half_fast(s[0]), fixed_to_half_fast(s[1])};
+			// one branch for the pair: |s| < 2^24 (|value| < 1) for both -> the low words are the values, exact as floats, and the
+			// float -> half conversion is the one rounding.  (The low words are hidden from the optimiser, which otherwise turns
+			// (float)(int)s back into a 13-instruction 64-bit conversion.)
+			const bool small = (unsigned long long)(s[0] + (1ll << 24)) < (1ull << 25) && (unsigned long long)(s[1] + (1ll << 24)) < (1ull << 25);
+			h2 out;
+			if (__builtin_expect(small, 1)) {
+				int lo0 = (int)s[0], lo1 = (int)s[1];
+				asm volatile("" : "+v"(lo0), "+v"(lo1));
+				out = h2{(half_t)((float)lo0 * 5.9604644775390625e-08f), (half_t)((float)lo1 * 5.9604644775390625e-08f)};
+			} else {
+				out = h2{fixed_to_half(s[0]), fixed_to_half(s[1])};
+			}
+			((h2*)g)[i] = out;
 		}
 		lds_barrier();
 		lap(t_flush);
@@ -437,19 +453,20 @@ void launch_binned(hipStream_t s, const BinLayout& l, MatView x, const void* dy,
 	static bool configured = false;
 	if (!configured) { // more than 64 KiB of dynamic LDS has to be opted into once per kernel
 		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_bin_fill<D, F>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_TILE_CONTRIBS * (F * 2 + 4) + 3 * BIN_MAX_CHUNKS * 4));
-		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_bin_accum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_ACC_BYTES));
+		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_bin_accum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_ACC_BYTES_MAX));
 		configured = true;
 	}
 	hipLaunchKernelGGL((k_bin_count<D>), dim3(a.n_tiles, l.n_slots), dim3(BIN_COUNT_THREADS), 0, s, a, x, counts);
 	hipLaunchKernelGGL(k_bin_scan_tiles, dim3(a.stride / 64, l.n_slots), dim3(1024), 0, s, a, counts, rel, totals);
 	hipLaunchKernelGGL(k_bin_scan_chunks, dim3(l.n_slots), dim3(1024), 0, s, a, totals, base);
 	hipLaunchKernelGGL((k_bin_fill<D, F>), dim3(a.n_tiles, l.n_slots), dim3(BIN_FILL_THREADS), fill_lds, s, a, x, (const half_t*)dy, dss, dsl, counts, rel, base, idx, val);
-	const uint32_t acc_blocks = std::min(l.n_chunks_total, 256u);
+	const uint32_t acc_bytes = grid_bin_acc_bytes();
+	const uint32_t acc_blocks = std::min(l.n_chunks_total, 256u * std::max(1u, (160u * 1024u) / (acc_bytes + 4096u)));
 	static const bool timing = getenv("TCNN_AMD_BIN_TIMING") != nullptr;
 	static int timing_left = 3;
 	unsigned long long* dbg = nullptr;
 	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&dbg, acc_blocks * 4 * 8));
-	hipLaunchKernelGGL((k_bin_accum<F>), dim3(acc_blocks), dim3(BIN_ACC_THREADS), BIN_ACC_BYTES, s, a, l.n_slots, totals, base, idx, val, (half_t*)grad, accumulate ? 1 : 0, dbg);
+	hipLaunchKernelGGL((k_bin_accum<F>), dim3(acc_blocks), dim3(BIN_ACC_THREADS), acc_bytes, s, a, l.n_slots, acc_bytes, totals, base, idx, val, (half_t*)grad, accumulate ? 1 : 0, dbg);
 	if (dbg) {
 		std::vector<unsigned long long> h(acc_blocks * 4);
 		HIP_CHECK_THROW(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
@@ -467,6 +484,16 @@ void launch_binned(hipStream_t s, const BinLayout& l, MatView x, const void* dy,
 
 uint32_t grid_bin_max_chunks() { return BIN_MAX_CHUNKS; }
 
+// LDS accumulators per workgroup of k_bin_accum = chunk size of the binned levels.  TCNN_AMD_BIN_ACC_KB: A/B runs.
+uint32_t grid_bin_acc_bytes() {
+	static const uint32_t v = [] {
+		uint32_t kb = 128;
+		if (const char* e = getenv("TCNN_AMD_BIN_ACC_KB")) kb = (uint32_t)std::min(std::max(atoi(e), 16), 128);
+		return kb * 1024u;
+	}();
+	return v;
+}
+
 bool grid_bin_supported(const GridMeta& meta) {
 	const uint32_t D = meta.n_pos_dims, F = meta.n_features_per_level;
 	return (F == 2 || F == 4) && D >= 2 && D <= 4;
@@ -482,7 +509,7 @@ void grid_backward_binned(hipStream_t stream, const GridMeta& meta, const GridMe
 	CHECK_THROW(l.args.stride <= BIN_MAX_CHUNKS);
 	for (uint32_t s = 0; s < l.n_slots; ++s) {
 		const GridLevel& lv = meta.levels[l.args.level_of_slot[s]];
-		CHECK_THROW(lv.scatter_per_chunk * meta.n_features_per_level * 8 <= BIN_ACC_BYTES && lv.scatter_per_chunk <= 65536);
+		CHECK_THROW(lv.scatter_per_chunk * meta.n_features_per_level * 8 <= grid_bin_acc_bytes() && lv.scatter_per_chunk <= 65536);
 	}
 	const uint32_t F = meta.n_features_per_level;
 	char* ws = (char*)workspace;

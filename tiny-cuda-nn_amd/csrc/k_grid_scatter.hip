@@ -466,22 +466,27 @@ bool grid_scatter_records_supported(const GridMeta& meta) {
 
 void grid_scatter_setup_levels(GridMeta& meta) {
 	const uint32_t capacity = SCATTER_ACC_BYTES / (meta.n_features_per_level * 8); // entries one workgroup can own (64-bit accumulators)
-	for (uint32_t l = 0; l < meta.n_levels; ++l) {
-		GridLevel& lv = meta.levels[l];
-		lv.scatter_n_chunks = div_round_up(lv.size, capacity);
+	auto cut = [](GridLevel& lv, uint32_t entries_per_chunk) {
+		lv.scatter_n_chunks = div_round_up(lv.size, entries_per_chunk);
 		lv.scatter_per_chunk = next_multiple(div_round_up(lv.size, lv.scatter_n_chunks), 8u);
 		lv.scatter_shift = 0xffffffffu;
 		if ((lv.scatter_per_chunk & (lv.scatter_per_chunk - 1)) == 0) {
 			lv.scatter_shift = 0;
 			while ((1u << lv.scatter_shift) < lv.scatter_per_chunk) ++lv.scatter_shift;
 		}
+	};
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		GridLevel& lv = meta.levels[l];
+		cut(lv, capacity);
 		// More chunks than the sample filter describes: the level's gradients are binned instead (k_grid_bin.hip).  Where a visit
 		// of the filtered form costs several gathers (no 16-byte records: 3-D with F = 4) binning already wins from 9 chunks on
 		// (measured on C5: the 64-chunk level 2.4x faster; on C3a, with records, the filtered form is 1.5x faster at 64 chunks).
 		// TCNN_AMD_BIN_MIN_CHUNKS=k moves the threshold (levels with more than k chunks are binned), for A/B runs.
 		uint32_t bin_above = grid_scatter_records_supported(meta) ? SCATTER_MAX_CHUNKS : 8u;
 		if (const char* e = getenv("TCNN_AMD_BIN_MIN_CHUNKS")) bin_above = std::min<uint32_t>((uint32_t)std::max(atoi(e), 1), SCATTER_MAX_CHUNKS);
-		lv.scatter_binned = (lv.scatter_n_chunks > bin_above && lv.scatter_n_chunks <= grid_bin_max_chunks() && grid_bin_supported(meta)) ? 1u : 0u;
+		const uint32_t bin_capacity = grid_bin_acc_bytes() / (meta.n_features_per_level * 8); // the binned kernels have their own chunk size
+		lv.scatter_binned = (lv.scatter_n_chunks > bin_above && div_round_up(lv.size, bin_capacity) <= grid_bin_max_chunks() && grid_bin_supported(meta)) ? 1u : 0u;
+		if (lv.scatter_binned) cut(lv, bin_capacity);
 	}
 }
 

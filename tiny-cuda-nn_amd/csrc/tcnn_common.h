@@ -128,6 +128,7 @@ bool grid_scatter_records_supported(const GridMeta& meta);
 // Same exact result as grid_backward_lds; writes every gradient element of the binned levels.  workspace: grid_bin_workspace_bytes().
 bool grid_bin_supported(const GridMeta& meta); // F in {2, 4}
 uint32_t grid_bin_max_chunks();                // chunks per level (4096)
+uint32_t grid_bin_acc_bytes();                 // LDS accumulators per workgroup = chunk size of binned levels
 size_t grid_bin_workspace_bytes(const GridMeta& meta, uint32_t n);
 void grid_backward_binned(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, MatView x, const void* dL_dy, uint32_t dy_stride_sample,
                           uint32_t dy_stride_level, void* grad, bool accumulate, void* workspace);
