@@ -30,6 +30,9 @@ namespace {
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int TR_PAD = 8; // halves of row padding of the LDS images (rows stay 16-byte aligned)
+// The hidden-activation / hidden-gradient images are only touched 8 bytes at a time (h4 rows in, ds_read_b64_tr_b16 out), so
+// 128-wide networks pad them by 4: 8 waves x 16 samples then fit the 160 KB (2 waves per SIMD instead of 1).
+constexpr int hs_pad(int width) { return width == 128 ? 4 : TR_PAD; }
 
 struct TrainArgs {
 	const half_t* x;        // [n][in_width] encoded input
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 	const uint32_t m_out = out_w / 16; // 1 or 2 output tiles (host guarantees out_width <= 32)
 
 	// LDS images, [S rows][features + pad] halves each
-	const uint32_t xs_stride = in_w + TR_PAD, hs_stride = W + TR_PAD, dys_stride = out_w + TR_PAD;
+	const uint32_t xs_stride = in_w + TR_PAD, hs_stride = W + hs_pad(W), dys_stride = out_w + TR_PAD;
 	const uint32_t xs_off = 0;
 	const uint32_t hs_off = xs_off + S * xs_stride;           // + l * S * hs_stride
 	const uint32_t dhs_off = hs_off + nh * S * hs_stride;     // + l * S * hs_stride
@@ -621,7 +624,7 @@ inline TrainConfig pick_config(const MlpDesc& d) {
 	const bool pw_allowed = pw_env && pw_env[0] == '1';
 	if (pw_allowed && d.width == 64 && d.n_hidden <= 2 && d.in_width <= 32 && d.out_width <= 32) {
 		const uint32_t s = 8 * 16;
-		const uint32_t images = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + TR_PAD) + (d.out_width + TR_PAD));
+		const uint32_t images = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + hs_pad((int)d.width)) + (d.out_width + TR_PAD));
 		size_t n_params = 0;
 		for (uint32_t l = 0; l < d.n_layers; ++l) n_params += (size_t)d.layers[l].rows * d.layers[l].cols;
 		if (images + image_bytes <= budget && n_params * sizeof(float) <= images) { // the final reduction reuses the image space
@@ -644,7 +647,7 @@ inline TrainConfig pick_config(const MlpDesc& d) {
 		cfg.nw = 8;
 		cfg.maxt = 8;
 		cfg.s = s;
-		cfg.lds_bytes = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + TR_PAD) + (d.out_width + TR_PAD));
+		cfg.lds_bytes = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + hs_pad((int)d.width)) + (d.out_width + TR_PAD));
 		cfg.image_in_lds = false;
 		cfg.regw = true;
 		cfg.ok = true;
@@ -660,7 +663,7 @@ inline TrainConfig pick_config(const MlpDesc& d) {
 				if (sscanf(e, "%d,%d,%d", &nb, &nw, &maxt) == 3 && (nb != v.nb || nw != v.nw || maxt != v.maxt)) continue;
 			}
 			const uint32_t s = v.nw * v.nb * 16;
-			const uint32_t bytes = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + TR_PAD) + (d.out_width + TR_PAD)) + (pass == 0 ? image_bytes : 0);
+			const uint32_t bytes = 2 * s * ((d.in_width + TR_PAD) + 2 * d.n_hidden * (d.width + hs_pad((int)d.width)) + (d.out_width + TR_PAD)) + (pass == 0 ? image_bytes : 0);
 			const uint32_t per = (total_tiles + v.nw - 1) / v.nw;
 			if (bytes > budget || (int)per > v.maxt) continue;
 			cfg.nb = v.nb;
