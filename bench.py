@@ -165,8 +165,11 @@ def pmc_traffic(kernel, workload):
     or if it was taken on another workload."""
     import glob
 
+    # profile sets are named r<round><letter>[_<workload>]; the default workload (c3a) has no suffix
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
-    if not files or workload != "c3a":
+    suffix = "" if workload == "c3a" else "_" + workload
+    files = [f for f in files if os.path.basename(f)[:-len("_pmc_hbm.json")].partition("_")[1:] == (("_", workload) if suffix else ("", ""))]
+    if not files:
         return None, None
     d = json.load(open(files[-1])).get("kernels", {}).get(kernel, {})
     return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
