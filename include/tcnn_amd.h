@@ -78,6 +78,10 @@ int tcnn_gpu_free(void* ptr);                                               /* g
 int tcnn_gpu_memcpy(void* dst, const void* src, size_t bytes, int kind);    /* gpu_memory.h:183-260 copy_from_host / copy_to_host */
 int tcnn_gpu_memset(void* ptr, int value, size_t bytes);                    /* gpu_memory.h:171-181 memset */
 int tcnn_stream_synchronize(tcnn_stream_t stream);
+/* random.h:58-70 generate_random_uniform<float>(stream, rng, n, out, lower, upper): thread i of the reference's kernel advances a
+ * copy of the pcg32 by 4 i and writes elements i + n_threads j (j < 4); the caller's generator is then advanced by n.
+ * rng_state_inc = {state, inc} of a pcg32 (include/tiny-cuda-nn/random.h keeps them), updated in place. */
+int tcnn_generate_random_uniform(tcnn_stream_t stream, uint64_t rng_state_inc[2], size_t n, float* out, float lower, float upper);
 
 /* ---- factories, cpp_api.h:113-115 / cpp_api.cu:146-165.  The caller owns the returned module. ---- */
 int  tcnn_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims, const char* encoding_json, const char* network_json, tcnn_module_t* out);

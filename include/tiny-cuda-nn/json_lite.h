@@ -114,9 +114,10 @@ public:
 	std::string value(const std::string& key, const std::string& def) const { const Json* j = find(key); return j ? j->as_string() : def; }
 	Json value(const std::string& key, const Json& def) const { const Json* j = find(key); return j ? *j : def; }
 
-	std::string dump() const {
+	// indent < 0: compact; else pretty-printed with that many spaces per level (nlohmann's dump(4))
+	std::string dump(int indent = -1) const {
 		std::string out;
-		dump_to(out);
+		dump_to(out, indent, 0);
 		return out;
 	}
 
@@ -144,7 +145,8 @@ private:
 		out += '"';
 	}
 
-	void dump_to(std::string& out) const {
+	void dump_to(std::string& out, int indent = -1, int depth = 0) const {
+		auto newline = [&](int d) { if (indent >= 0) { out += '\n'; out.append((size_t)indent * d, ' '); } };
 		switch (m_kind) {
 			case Kind::Null: out += "null"; break;
 			case Kind::Bool: out += m_bool ? "true" : "false"; break;
@@ -164,7 +166,8 @@ private:
 			case Kind::String: dump_string(m_str, out); break;
 			case Kind::Array: {
 				out += '[';
-				for (size_t i = 0; i < m_arr.size(); ++i) { if (i) out += ','; m_arr[i].dump_to(out); }
+				for (size_t i = 0; i < m_arr.size(); ++i) { if (i) out += ','; newline(depth + 1); m_arr[i].dump_to(out, indent, depth + 1); }
+				if (!m_arr.empty()) newline(depth);
 				out += ']';
 				break;
 			}
@@ -174,10 +177,12 @@ private:
 				for (const auto& kv : m_obj) {
 					if (!first) out += ',';
 					first = false;
+					newline(depth + 1);
 					dump_string(kv.first, out);
-					out += ':';
-					kv.second.dump_to(out);
+					out += indent >= 0 ? ": " : ":";
+					kv.second.dump_to(out, indent, depth + 1);
 				}
+				if (!m_obj.empty()) newline(depth);
 				out += '}';
 				break;
 			}
@@ -192,7 +197,20 @@ private:
 		[[noreturn]] void fail(const char* what) const {
 			throw std::runtime_error{std::string{"json parse error at offset "} + std::to_string(pos) + ": " + what};
 		}
-		void skip_ws() { while (pos < s.size() && (s[pos] == ' ' || s[pos] == '\n' || s[pos] == '\t' || s[pos] == '\r')) ++pos; }
+		// white space and comments (// ... and /* ... */): the reference's samples parse their configs with skip_comments = true
+		void skip_ws() {
+			for (;;) {
+				while (pos < s.size() && (s[pos] == ' ' || s[pos] == '\n' || s[pos] == '\t' || s[pos] == '\r')) ++pos;
+				if (pos + 1 < s.size() && s[pos] == '/' && s[pos + 1] == '/') {
+					while (pos < s.size() && s[pos] != '\n') ++pos;
+				} else if (pos + 1 < s.size() && s[pos] == '/' && s[pos + 1] == '*') {
+					const size_t end = s.find("*/", pos + 2);
+					pos = end == std::string::npos ? s.size() : end + 2;
+				} else {
+					return;
+				}
+			}
+		}
 		char peek() const { return pos < s.size() ? s[pos] : '\0'; }
 		void expect(char ch) { if (peek() != ch) fail("unexpected character"); ++pos; }
 

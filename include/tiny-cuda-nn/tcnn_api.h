@@ -20,6 +20,7 @@
 
 #include "../tcnn_amd.h"
 #include "json_lite.h"
+#include "random.h" // trainer.h includes random.h in the reference: callers get default_rng_t / generate_random_uniform from config.h
 
 #include <cstdint>
 #include <cstring>

@@ -41,6 +41,18 @@ static int host_checks() {
 	threw = false;
 	try { Loss<network_precision_t> l{json{{"otype", "Huber"}}}; } catch (const std::runtime_error&) { threw = true; }
 	REQUIRE(threw);
+
+	// <tiny-cuda-nn/random.h>: the stream of default_rng_t{1337} (tests/golden/reference_kat.json "pcg32", computed from the
+	// reference's own dependencies/pcg32 at survey time), advance(), comments in configs, pretty-printed dump
+	default_rng_t rng{1337};
+	REQUIRE(rng.state_inc[1] == 3u);
+	const float want[4] = {0.147699356f, 0.471029401f, 0.173984647f, 0.129117727f};
+	for (float w : want) REQUIRE(rng.next_float() == w);
+	default_rng_t jump{1337};
+	jump.advance(2);
+	REQUIRE(jump.next_float() == 0.173984647f);
+	const json commented = json::parse("{ // line comment\n \"a\": 1, /* block */ \"b\": [1, 2] }");
+	REQUIRE(commented.value("a", 0) == 1 && json::parse(commented.dump(4)).dump() == commented.dump());
 	std::printf("host checks ok\n");
 	return 0;
 }
@@ -101,6 +113,28 @@ static int gpu_checks() {
 	const std::vector<float> q = soa_out.to_cpu_vector();
 	for (uint32_t i = 0; i < 256; ++i)
 		for (uint32_t j = 0; j < 3; ++j) REQUIRE(q[j * 256 + i] == p[3 * i + j]);
+
+	// generate_random_uniform (random.h:58-70): element i + n_threads * j is draw j of a copy of the generator advanced by 4 i;
+	// afterwards the caller's generator has moved on by n
+	{
+		const size_t n = 1000; // n_threads = 250
+		GPUMemory<float> dev(n);
+		default_rng_t gen{1337}, host{1337};
+		generate_random_uniform<float>(nullptr, gen, n, dev.data());
+		tcnn_stream_synchronize(nullptr);
+		std::vector<float> got;
+		dev.copy_to_host(got);
+		const size_t n_threads = (n + 3) / 4;
+		// the reference launches whole blocks of 128 threads: n_threads rounds up to a multiple of 128 for the stride
+		const size_t stride = (n_threads + 127) / 128 * 128;
+		for (size_t i = 0; i < 5; ++i) {
+			default_rng_t t{1337};
+			t.advance((int64_t)(4 * i));
+			for (size_t j = 0; j < 4; ++j) if (i + stride * j < n) REQUIRE(got[i + stride * j] == t.next_float());
+		}
+		host.advance((int64_t)n);
+		REQUIRE(gen.state_inc[0] == host.state_inc[0]);
+	}
 	free_all_gpu_memory_arenas();
 	std::printf("gpu checks ok\n");
 	return 0;

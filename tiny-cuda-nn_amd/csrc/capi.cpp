@@ -95,6 +95,13 @@ int tcnn_gpu_memset(void* ptr, int value, size_t bytes) {
 int tcnn_stream_synchronize(tcnn_stream_t stream) {
 	return guarded([&] { HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)stream)); });
 }
+int tcnn_generate_random_uniform(tcnn_stream_t stream, uint64_t rng_state_inc[2], size_t n, float* out, float lower, float upper) {
+	return guarded([&] {
+		CHECK_THROW(rng_state_inc != nullptr && (out != nullptr || n == 0));
+		generate_random_uniform((hipStream_t)stream, rng_state_inc, n, out, lower, upper);
+		HIP_CHECK_THROW(hipGetLastError());
+	});
+}
 int tcnn_has_networks(void) { return 1; }
 float tcnn_default_loss_scale(int precision) { return precision == TCNN_PRECISION_FP32 ? 1.0f : LOSS_SCALE_FP16; }
 int tcnn_preferred_precision(void) { return TCNN_PRECISION_FP16; }

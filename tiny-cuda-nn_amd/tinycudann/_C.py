@@ -61,6 +61,7 @@ _SIGNATURES = {
     "tcnn_gpu_memcpy": (_int, [_vp, _vp, _sz, _int]),
     "tcnn_gpu_memset": (_int, [_vp, _int, _sz]),
     "tcnn_stream_synchronize": (_int, [_vp]),
+    "tcnn_generate_random_uniform": (_int, [_vp, _vp, _sz, _vp, C.c_float, C.c_float]),
     "tcnn_create_network_with_input_encoding": (_int, [_u32, _u32, _cp, _cp, _pp]),
     "tcnn_create_network": (_int, [_u32, _u32, _cp, _pp]),
     "tcnn_create_encoding": (_int, [_u32, _cp, _int, _pp]),
