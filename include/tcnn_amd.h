@@ -153,6 +153,14 @@ int      tcnn_trainer_set_params(tcnn_trainer_t t, const void* params_half, size
 int      tcnn_trainer_initialize_params(tcnn_trainer_t t);        /* trainer.h:68-87 (re-initialise, continues the rng stream) */
 int      tcnn_trainer_update_hyperparams(tcnn_trainer_t t, const char* json); /* trainer.h:213 */
 const char* tcnn_trainer_hyperparams(tcnn_trainer_t t);           /* trainer.h:218; JSON text owned by the trainer */
+/* Snapshot wire format, trainer.h:275-315 (json serialize(bool) / deserialize(const json&)) with adam.h:278-299 and
+ * gpu_memory_json.h:36-71: the object {"n_params", "params_type": "__half", "params_binary": <bin>, ["optimizer":
+ * {"current_step", "base_learning_rate", "first_moments_binary", "second_moments_binary", "param_steps_binary"}]} as
+ * MessagePack bytes, encoded the way nlohmann::json::to_msgpack encodes it (what instant-ngp-style callers write to disk).
+ * serialize: the buffer belongs to the trainer and stays valid until its next serialize call or its destruction.
+ * deserialize: accepts "params_type" "__half" or "float", binary values or their text form {"bytes": [...]}. */
+int      tcnn_trainer_serialize(tcnn_trainer_t t, int serialize_optimizer, const void** out_bytes, size_t* out_size);
+int      tcnn_trainer_deserialize(tcnn_trainer_t t, const void* bytes, size_t size);
 const char* tcnn_trainer_network_hyperparams(tcnn_trainer_t t);   /* network->hyperparams() */
 uint32_t tcnn_trainer_optimizer_step_count(tcnn_trainer_t t);     /* optimizer->step() adam.h:198 */
 

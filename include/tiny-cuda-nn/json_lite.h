@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <initializer_list>
 #include <map>
 #include <memory>
@@ -21,7 +22,7 @@ namespace tcnn_amd {
 
 class Json {
 public:
-	enum class Kind { Null, Bool, Number, String, Array, Object };
+	enum class Kind { Null, Bool, Number, String, Array, Object, Binary };
 
 	Json() = default;
 	Json(bool b) : m_kind{Kind::Bool}, m_bool{b} {}
@@ -49,6 +50,13 @@ public:
 
 	static Json object() { Json j; j.m_kind = Kind::Object; return j; }
 	static Json array() { Json j; j.m_kind = Kind::Array; return j; }
+	// nlohmann::json::binary_t: what the snapshot format keeps its parameter blobs in (gpu_memory_json.h:36-71)
+	static Json binary(std::vector<uint8_t> bytes) { Json j; j.m_kind = Kind::Binary; j.m_bin = std::move(bytes); return j; }
+	bool is_binary() const { return m_kind == Kind::Binary; }
+	const std::vector<uint8_t>& get_binary() const {
+		if (m_kind != Kind::Binary) throw std::runtime_error{"json: value is not binary"};
+		return m_bin;
+	}
 
 	static Json parse(const std::string& text) {
 		Parser p{text};
@@ -164,6 +172,12 @@ private:
 				break;
 			}
 			case Kind::String: dump_string(m_str, out); break;
+			case Kind::Binary: {
+				out += "{\"bytes\":[";
+				for (size_t i = 0; i < m_bin.size(); ++i) { if (i) out += ','; out += std::to_string((unsigned)m_bin[i]); }
+				out += "],\"subtype\":null}";
+				break;
+			}
 			case Kind::Array: {
 				out += '[';
 				for (size_t i = 0; i < m_arr.size(); ++i) { if (i) out += ','; newline(depth + 1); m_arr[i].dump_to(out, indent, depth + 1); }
@@ -327,6 +341,163 @@ private:
 	std::string m_str;
 	std::vector<Json> m_arr;
 	std::vector<std::pair<std::string, Json>> m_obj;
+	std::vector<uint8_t> m_bin;
+
+public:
+	// ---- MessagePack, the byte format callers store snapshots in (instant-ngp: json::to_msgpack(trainer->serialize())).
+	// Encoding choices follow nlohmann::json so that the bytes match: object keys in sorted order (its objects are std::map),
+	// integers in the smallest format, a float as float32 when that is exact and float64 otherwise, binary as bin8/16/32.
+	static std::vector<uint8_t> to_msgpack(const Json& j) {
+		std::vector<uint8_t> out;
+		j.pack(out);
+		return out;
+	}
+	static Json from_msgpack(const uint8_t* data, size_t size) {
+		Unpacker u{data, size};
+		Json j = u.value();
+		if (u.pos != size) throw std::runtime_error{"msgpack: trailing bytes"};
+		return j;
+	}
+	static Json from_msgpack(const std::vector<uint8_t>& bytes) { return from_msgpack(bytes.data(), bytes.size()); }
+
+private:
+	static void put_be(std::vector<uint8_t>& out, uint64_t v, int n_bytes) {
+		for (int i = n_bytes - 1; i >= 0; --i) out.push_back((uint8_t)(v >> (8 * i)));
+	}
+	static void pack_length(std::vector<uint8_t>& out, size_t n, uint8_t fix_base, size_t fix_max, uint8_t code8, uint8_t code16, uint8_t code32) {
+		if (fix_base && n <= fix_max) out.push_back((uint8_t)(fix_base | n));
+		else if (code8 && n <= 0xff) { out.push_back(code8); out.push_back((uint8_t)n); }
+		else if (n <= 0xffff) { out.push_back(code16); put_be(out, n, 2); }
+		else { out.push_back(code32); put_be(out, n, 4); }
+	}
+	void pack(std::vector<uint8_t>& out) const {
+		switch (m_kind) {
+			case Kind::Null: out.push_back(0xc0); break;
+			case Kind::Bool: out.push_back(m_bool ? 0xc3 : 0xc2); break;
+			case Kind::Number: {
+				if (m_is_int) {
+					if (m_num >= 0) {
+						const uint64_t v = (uint64_t)m_num;
+						if (v < 128) out.push_back((uint8_t)v);
+						else if (v <= 0xff) { out.push_back(0xcc); put_be(out, v, 1); }
+						else if (v <= 0xffff) { out.push_back(0xcd); put_be(out, v, 2); }
+						else if (v <= 0xffffffffull) { out.push_back(0xce); put_be(out, v, 4); }
+						else { out.push_back(0xcf); put_be(out, v, 8); }
+					} else {
+						const int64_t v = (int64_t)m_num;
+						if (v >= -32) out.push_back((uint8_t)v);
+						else if (v >= -128) { out.push_back(0xd0); put_be(out, (uint64_t)v, 1); }
+						else if (v >= -32768) { out.push_back(0xd1); put_be(out, (uint64_t)v, 2); }
+						else if (v >= -2147483648ll) { out.push_back(0xd2); put_be(out, (uint64_t)v, 4); }
+						else { out.push_back(0xd3); put_be(out, (uint64_t)v, 8); }
+					}
+				} else if ((double)(float)m_num == m_num) {
+					const float f = (float)m_num;
+					uint32_t bits;
+					memcpy(&bits, &f, 4);
+					out.push_back(0xca);
+					put_be(out, bits, 4);
+				} else {
+					uint64_t bits;
+					memcpy(&bits, &m_num, 8);
+					out.push_back(0xcb);
+					put_be(out, bits, 8);
+				}
+				break;
+			}
+			case Kind::String:
+				pack_length(out, m_str.size(), 0xa0, 31, 0xd9, 0xda, 0xdb);
+				out.insert(out.end(), m_str.begin(), m_str.end());
+				break;
+			case Kind::Binary:
+				pack_length(out, m_bin.size(), 0, 0, 0xc4, 0xc5, 0xc6);
+				out.insert(out.end(), m_bin.begin(), m_bin.end());
+				break;
+			case Kind::Array:
+				pack_length(out, m_arr.size(), 0x90, 15, 0, 0xdc, 0xdd);
+				for (const Json& e : m_arr) e.pack(out);
+				break;
+			case Kind::Object: {
+				pack_length(out, m_obj.size(), 0x80, 15, 0, 0xde, 0xdf);
+				std::vector<const std::pair<std::string, Json>*> sorted;
+				for (const auto& kv : m_obj) sorted.push_back(&kv);
+				for (size_t i = 1; i < sorted.size(); ++i) // insertion sort: snapshots have a handful of keys
+					for (size_t k = i; k > 0 && sorted[k]->first < sorted[k - 1]->first; --k) std::swap(sorted[k], sorted[k - 1]);
+				for (const auto* kv : sorted) {
+					Json(kv->first).pack(out);
+					kv->second.pack(out);
+				}
+				break;
+			}
+		}
+	}
+
+	struct Unpacker {
+		const uint8_t* data;
+		size_t size, pos = 0;
+		Unpacker(const uint8_t* d, size_t n) : data{d}, size{n} {}
+		void need(size_t n) const { if (size - pos < n) throw std::runtime_error{"msgpack: truncated input"}; }
+		uint64_t be(int n_bytes) {
+			need((size_t)n_bytes);
+			uint64_t v = 0;
+			for (int i = 0; i < n_bytes; ++i) v = v << 8 | data[pos++];
+			return v;
+		}
+		Json string(size_t n) { need(n); Json j(std::string((const char*)data + pos, n)); pos += n; return j; }
+		Json bin(size_t n) { need(n); Json j = Json::binary(std::vector<uint8_t>(data + pos, data + pos + n)); pos += n; return j; }
+		Json array(size_t n) { Json j = Json::array(); for (size_t i = 0; i < n; ++i) j.push_back(value()); return j; }
+		Json map(size_t n) {
+			Json j = Json::object();
+			for (size_t i = 0; i < n; ++i) {
+				const Json key = value();
+				j[key.as_string()] = value();
+			}
+			return j;
+		}
+		Json value() {
+			need(1);
+			const uint8_t c = data[pos++];
+			if (c < 0x80) return Json((uint64_t)c);
+			if (c >= 0xe0) return Json((int64_t)(int8_t)c);
+			if ((c & 0xf0) == 0x80) return map(c & 0x0f);
+			if ((c & 0xf0) == 0x90) return array(c & 0x0f);
+			if ((c & 0xe0) == 0xa0) return string(c & 0x1f);
+			switch (c) {
+				case 0xc0: return Json{};
+				case 0xc2: return Json(false);
+				case 0xc3: return Json(true);
+				case 0xc4: return bin((size_t)be(1));
+				case 0xc5: return bin((size_t)be(2));
+				case 0xc6: return bin((size_t)be(4));
+				case 0xc7: { const size_t n = (size_t)be(1); be(1); return bin(n); } // ext: nlohmann writes binaries with a subtype this way
+				case 0xc8: { const size_t n = (size_t)be(2); be(1); return bin(n); }
+				case 0xc9: { const size_t n = (size_t)be(4); be(1); return bin(n); }
+				case 0xca: { const uint32_t b = (uint32_t)be(4); float f; memcpy(&f, &b, 4); return Json(f); }
+				case 0xcb: { const uint64_t b = be(8); double d; memcpy(&d, &b, 8); return Json(d); }
+				case 0xcc: return Json((uint64_t)be(1));
+				case 0xcd: return Json((uint64_t)be(2));
+				case 0xce: return Json((uint64_t)be(4));
+				case 0xcf: return Json((uint64_t)be(8));
+				case 0xd0: return Json((int64_t)(int8_t)be(1));
+				case 0xd1: return Json((int64_t)(int16_t)be(2));
+				case 0xd2: return Json((int64_t)(int32_t)be(4));
+				case 0xd3: return Json((int64_t)be(8));
+				case 0xd4: be(1); return bin(1);
+				case 0xd5: be(1); return bin(2);
+				case 0xd6: be(1); return bin(4);
+				case 0xd7: be(1); return bin(8);
+				case 0xd8: be(1); return bin(16);
+				case 0xd9: return string((size_t)be(1));
+				case 0xda: return string((size_t)be(2));
+				case 0xdb: return string((size_t)be(4));
+				case 0xdc: return array((size_t)be(2));
+				case 0xdd: return array((size_t)be(4));
+				case 0xde: return map((size_t)be(2));
+				case 0xdf: return map((size_t)be(4));
+				default: throw std::runtime_error{"msgpack: unsupported type byte"};
+			}
+		}
+	};
 };
 
 } // namespace tcnn_amd

@@ -266,6 +266,18 @@ public:
 	json hyperparams() const { return json::parse(tcnn_trainer_hyperparams(m_handle)); }
 	uint32_t optimizer_step_count() const { return tcnn_trainer_optimizer_step_count(m_handle); }
 
+	// trainer.h:275-315: the snapshot object (binary values inside); store it with json::to_msgpack like callers of the reference do
+	json serialize(bool serialize_optimizer = false) {
+		const void* bytes = nullptr;
+		size_t size = 0;
+		detail::check(tcnn_trainer_serialize(m_handle, serialize_optimizer ? 1 : 0, &bytes, &size));
+		return json::from_msgpack((const uint8_t*)bytes, size);
+	}
+	void deserialize(const json& data) {
+		const std::vector<uint8_t> bytes = json::to_msgpack(data);
+		detail::check(tcnn_trainer_deserialize(m_handle, bytes.data(), bytes.size()));
+	}
+
 	std::shared_ptr<NetworkWithInputEncoding<COMPUTE_T>> model() const { return m_model; }
 	tcnn_trainer_t handle() const { return m_handle; }
 

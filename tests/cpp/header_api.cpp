@@ -5,6 +5,7 @@
 #include <tiny-cuda-nn/config.h>
 #include <tiny-cuda-nn/cpp_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -53,6 +54,27 @@ static int host_checks() {
 	REQUIRE(jump.next_float() == 0.173984647f);
 	const json commented = json::parse("{ // line comment\n \"a\": 1, /* block */ \"b\": [1, 2] }");
 	REQUIRE(commented.value("a", 0) == 1 && json::parse(commented.dump(4)).dump() == commented.dump());
+
+	// MessagePack as nlohmann::json::to_msgpack writes it: sorted keys, smallest integer formats, float32 where exact, bin8/16/32
+	{
+		json j = json::object();
+		j["b"] = json{true, json(), 1.5, "x"};
+		j["a"] = 1;
+		const std::vector<uint8_t> want = {0x82, 0xa1, 0x61, 0x01, 0xa1, 0x62, 0x94, 0xc3, 0xc0, 0xca, 0x3f, 0xc0, 0x00, 0x00, 0xa1, 0x78};
+		REQUIRE(json::to_msgpack(j) == want);
+		json k = json::object();
+		k["n_params"] = (uint64_t)70000;
+		k["lr"] = 0.1; // not exact as float32 -> float64
+		k["neg"] = -33;
+		k["blob"] = json::binary(std::vector<uint8_t>(300, 0xab));
+		const std::vector<uint8_t> bytes = json::to_msgpack(k);
+		const std::vector<uint8_t> head = {0x84, 0xa4, 'b', 'l', 'o', 'b', 0xc5, 0x01, 0x2c}; // map of 4, "blob" first, bin16 of 300
+		REQUIRE(std::equal(head.begin(), head.end(), bytes.begin()));
+		const json back = json::from_msgpack(bytes);
+		REQUIRE(back["blob"].is_binary() && back["blob"].get_binary().size() == 300 && back["blob"].get_binary()[299] == 0xab);
+		REQUIRE(back.value("n_params", 0u) == 70000u && back.value("lr", 0.0) == 0.1 && back.value("neg", 0) == -33);
+		REQUIRE(json::to_msgpack(back) == bytes);
+	}
 	std::printf("host checks ok\n");
 	return 0;
 }
@@ -103,6 +125,21 @@ static int gpu_checks() {
 	err /= p.size();
 	std::printf("mean abs error of inference vs target: %g\n", err);
 	REQUIRE(err < 0.1);
+
+	// trainer.h:275-315: snapshot object with binary values; a second trainer restored from it infers the same
+	{
+		const json snap = trainer->serialize(true);
+		REQUIRE(snap.value("n_params", 0u) == 708368u + 7168u && snap.value("params_type", "") == "__half");
+		REQUIRE(snap["params_binary"].is_binary() && snap["params_binary"].get_binary().size() == 2 * (708368u + 7168u));
+		REQUIRE(snap["optimizer"].value("current_step", 0u) == 100u && snap["optimizer"]["first_moments_binary"].get_binary().size() == 4 * (708368u + 7168u));
+		auto other = create_from_config(n_input_dims, n_output_dims, config);
+		other.trainer->deserialize(json::from_msgpack(json::to_msgpack(snap)));
+		GPUMatrix<float> again(n_output_dims, batch_size);
+		other.network->inference(nullptr, training_batch, again);
+		tcnn_stream_synchronize(nullptr);
+		REQUIRE(again.to_cpu_vector() == p);
+		REQUIRE(other.trainer->optimizer_step_count() == 100);
+	}
 
 	// row-major (SoA) matrices go through the same entry points
 	GPUMatrix<float, RM> soa_in(n_input_dims, 256), soa_out(n_output_dims, 256);

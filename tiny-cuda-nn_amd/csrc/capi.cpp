@@ -49,6 +49,7 @@ struct tcnn_trainer_s {
 	std::unique_ptr<Trainer> trainer;
 	std::string hyperparams_text;
 	std::string network_hyperparams_text;
+	std::vector<uint8_t> snapshot; // tcnn_trainer_serialize's result
 };
 
 struct tcnn_train_ctx_s {
@@ -310,5 +311,21 @@ const char* tcnn_trainer_network_hyperparams(tcnn_trainer_t t) {
 }
 
 uint32_t tcnn_trainer_optimizer_step_count(tcnn_trainer_t t) { return t->trainer->optimizer().step_count(); }
+
+int tcnn_trainer_serialize(tcnn_trainer_t t, int serialize_optimizer, const void** out_bytes, size_t* out_size) {
+	return guarded([&] {
+		CHECK_THROW(out_bytes != nullptr && out_size != nullptr);
+		t->snapshot = Json::to_msgpack(t->trainer->serialize(serialize_optimizer != 0));
+		*out_bytes = t->snapshot.data();
+		*out_size = t->snapshot.size();
+	});
+}
+
+int tcnn_trainer_deserialize(tcnn_trainer_t t, const void* bytes, size_t size) {
+	return guarded([&] {
+		CHECK_THROW(bytes != nullptr && size > 0);
+		t->trainer->deserialize(Json::from_msgpack((const uint8_t*)bytes, size));
+	});
+}
 
 } // extern "C"

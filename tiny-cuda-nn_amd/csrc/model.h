@@ -1140,6 +1140,40 @@ public:
 		for (const auto& ls : layer_sizes) m_n_matrix += (size_t)ls.first * ls.second;
 	}
 
+	// adam.h:278-299
+	Json serialize() const {
+		auto blob = [](const DeviceBuf& buf, size_t n_bytes) {
+			std::vector<uint8_t> host(n_bytes);
+			if (n_bytes) HIP_CHECK_THROW(hipMemcpy(host.data(), buf.data(), n_bytes, hipMemcpyDeviceToHost));
+			return Json::binary(std::move(host));
+		};
+		Json data = Json::object();
+		data["current_step"] = Json((uint32_t)m_current_step);
+		data["base_learning_rate"] = Json((float)m_h.learning_rate);
+		data["first_moments_binary"] = blob(m_first_moments, m_n_weights * sizeof(float));
+		data["second_moments_binary"] = blob(m_second_moments, m_n_weights * sizeof(float));
+		data["param_steps_binary"] = blob(m_param_steps, m_n_weights * sizeof(uint32_t));
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights, std::vector<uint8_t> (*binary_of)(const Json&)) {
+		auto load = [&](DeviceBuf& buf, const std::vector<uint8_t>& bytes, size_t elem) {
+			if (bytes.size() != n_weights * elem) throw std::runtime_error{"Adam: snapshot state has the wrong size."};
+			buf.resize(bytes.size());
+			if (!bytes.empty()) HIP_CHECK_THROW(hipMemcpy(buf.data(), bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+		};
+		m_n_weights = n_weights;
+		load(m_first_moments, binary_of(data["first_moments_binary"]), sizeof(float));
+		load(m_second_moments, binary_of(data["second_moments_binary"]), sizeof(float));
+		if (data.contains("param_steps_binary")) {
+			load(m_param_steps, binary_of(data["param_steps_binary"]), sizeof(uint32_t));
+		} else {
+			m_param_steps.resize(n_weights * sizeof(uint32_t));
+			m_param_steps.memset(0);
+		}
+		m_current_step = (uint32_t)data["current_step"].as_double();
+		m_h.learning_rate = (float)data["base_learning_rate"].as_double();
+	}
+
 	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) { // adam.h:150-188
 		++m_current_step;
 		ensure_debias_table(stream);
@@ -1357,6 +1391,50 @@ public:
 
 	void update_hyperparams(const Json& params) { // trainer.h:213-216
 		m_optimizer->update_hyperparams(params.value("optimizer", Json::object()));
+	}
+
+	// ---- snapshot wire format, trainer.h:275-315 (+ adam.h:278-299, gpu_memory_json.h:36-71): an object holding the half
+	// parameters as a binary blob and, optionally, the optimizer's state.  Callers store it as MessagePack (Json::to_msgpack).
+	static Json device_to_binary(const void* device, size_t n_bytes) {
+		std::vector<uint8_t> host(n_bytes);
+		if (n_bytes) HIP_CHECK_THROW(hipMemcpy(host.data(), device, n_bytes, hipMemcpyDeviceToHost));
+		return Json::binary(std::move(host));
+	}
+	// binary value, or nlohmann's text form of one: {"bytes": [...], "subtype": null} (gpu_memory_json.h:55-67)
+	static std::vector<uint8_t> binary_of(const Json& j) {
+		if (j.is_binary()) return j.get_binary();
+		if (j.is_object()) {
+			const Json& arr = j["bytes"];
+			std::vector<uint8_t> bytes(arr.size());
+			for (size_t i = 0; i < bytes.size(); ++i) bytes[i] = (uint8_t)arr.at(i).as_double();
+			return bytes;
+		}
+		throw std::runtime_error{"Invalid json type: must be either binary or object"};
+	}
+
+	Json serialize(bool serialize_optimizer) {
+		HIP_CHECK_THROW(hipDeviceSynchronize());
+		const size_t n = m_model->n_params();
+		Json data = Json::object();
+		data["n_params"] = Json((uint64_t)n);
+		data["params_type"] = "__half"; // type_to_string<__half>() of the reference: the name snapshots carry
+		data["params_binary"] = device_to_binary(m_params.data(), 2 * n);
+		if (serialize_optimizer) data["optimizer"] = m_optimizer->serialize();
+		return data;
+	}
+
+	void deserialize(const Json& data) {
+		const std::string type = data.value("params_type", "__half");
+		const std::vector<uint8_t> bytes = binary_of(data["params_binary"]);
+		if (type == "float") {
+			set_params_full_precision((const float*)bytes.data(), bytes.size() / sizeof(float), false);
+		} else if (type == "__half") {
+			set_params(bytes.data(), bytes.size() / 2, false);
+		} else {
+			throw std::runtime_error{"Trainer: snapshot parameters must be of type float of __half"};
+		}
+		if (data.contains("optimizer")) m_optimizer->deserialize(data["optimizer"], m_model->n_params(), binary_of);
+		HIP_CHECK_THROW(hipDeviceSynchronize());
 	}
 
 	Json hyperparams() const { // trainer.h:218-224

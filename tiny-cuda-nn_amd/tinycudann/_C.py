@@ -105,6 +105,8 @@ _SIGNATURES = {
     "tcnn_trainer_hyperparams": (_cp, [_vp]),
     "tcnn_trainer_network_hyperparams": (_cp, [_vp]),
     "tcnn_trainer_optimizer_step_count": (_u32, [_vp]),
+    "tcnn_trainer_serialize": (_int, [_vp, _int, _pp, C.POINTER(_sz)]),
+    "tcnn_trainer_deserialize": (_int, [_vp, _vp, _sz]),
 }
 
 for _name, (_res, _args) in _SIGNATURES.items():

@@ -153,6 +153,17 @@ class Trainer:
     def optimizer_step_count(self):
         return int(_C.lib.tcnn_trainer_optimizer_step_count(self._h))
 
+    def serialize(self, serialize_optimizer=False):
+        """trainer.h:275-291 as MessagePack bytes (what json::to_msgpack(trainer->serialize()) yields in the reference's callers)."""
+        ptr, size = _C.C.c_void_p(), _C.C.c_size_t()
+        _C.check(_C.lib.tcnn_trainer_serialize(self._h, int(bool(serialize_optimizer)), _C.C.byref(ptr), _C.C.byref(size)))
+        return _C.C.string_at(ptr, size.value)
+
+    def deserialize(self, data):
+        """trainer.h:293-315: MessagePack bytes of a snapshot object ("params_type" "__half" or "float")."""
+        data = bytes(data)
+        _C.check(_C.lib.tcnn_trainer_deserialize(self._h, data, len(data)))
+
 
 class TrainableModel:
     """config.h:46-51: {loss, optimizer, network, trainer}; here network and trainer are the same native object."""
