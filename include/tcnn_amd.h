@@ -98,7 +98,11 @@ int  tcnn_module_forward(tcnn_module_t m, tcnn_stream_t stream, uint32_t n_eleme
                          int prepare_input_gradients, tcnn_context_t* ctx_out);
 int  tcnn_module_backward(tcnn_module_t m, tcnn_stream_t stream, tcnn_context_t ctx, uint32_t n_elements, float* dL_dinput,
                           const void* dL_doutput, void* dL_dparams, const float* input, const void* output, const void* params);
-/* second-order input gradients (cpp_api.h:94): declared for ABI completeness, returns TCNN_ERROR ("not implemented") in this round */
+/* second-order input gradients (cpp_api.h:94, cpp_api.cu:111-127; grid.h:902-1026): dL_ddLdinput [n][n_input_dims] float is the
+ * gradient arriving at dL_dinput; optional results dL_dparams (Overwrite), dL_ddLdoutput [n][n_output_dims], dL_dinput [n][n_input_dims]
+ * (overwritten; the reference adds into a zeroed buffer).  The context must come from tcnn_module_forward(prepare_input_gradients = 1).
+ * Like in the reference only grid encodings implement it; other modules report "DifferentiableObject::backward_backward_input_impl:
+ * not implemented error" (object.h:288). */
 int  tcnn_module_backward_backward_input(tcnn_module_t m, tcnn_stream_t stream, tcnn_context_t ctx, uint32_t n_elements, const float* dL_ddLdinput,
                                          const float* input, const void* dL_doutput, void* dL_dparams, void* dL_ddLdoutput, float* dL_dinput, const void* params);
 void tcnn_context_destroy(tcnn_context_t ctx);

@@ -88,6 +88,7 @@ def lib():
             "orc_grid_forward": (None, [vp, u32, vp, vp, vp, u32, vp, vp]),
             "orc_grid_backward": (None, [vp, u32, vp, vp, u32, vp, vp]),
             "orc_grid_backward_input": (None, [vp, u32, vp, u32, vp, vp]),
+            "orc_grid_backward_backward_input": (None, [vp, u32, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp]),
             "orc_grid_backward_exact": (None, [vp, u32, vp, vp, u32, vp, C.c_int]),
             "orc_oneblob_forward": (None, [u32, u32, u32, vp, vp, u32]), "orc_oneblob_backward_input": (None, [u32, u32, u32, vp, vp, u32, vp]),
             "orc_identity_forward": (None, [u32, u32, f32, f32, vp, vp, u32]), "orc_identity_backward_input": (None, [u32, u32, f32, vp, u32, vp]),
@@ -275,6 +276,19 @@ class GridEncoding:
             lib().orc_grid_backward_input(C.byref(self.g), n, _p(dL_dy), dL_dy.shape[1], _p(ctx["dy_dx"]), _p(dL_dx))
             return dL_dx
         return None
+
+    def backward_backward_input(self, x, ctx, dL_ddLdx, dL_dy, params_half, grad_half=None, grad_f32=None, want_dL_ddLdy=False, want_dL_dx=False):
+        """grid.h:902-1026: second-order terms.  ctx must come from forward(want_dy_dx=True) when want_dL_ddLdy.
+        Returns (dL_ddLdy half bits or None, dL_dx float or None); grad_half / grad_f32 are accumulated in place."""
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dL_ddLdx = np.ascontiguousarray(dL_ddLdx, dtype=np.float32)
+        dL_dy = np.ascontiguousarray(dL_dy)
+        dL_ddLdy = np.empty_like(dL_dy) if want_dL_ddLdy else None
+        dL_dx = np.empty((n, self.n_in), dtype=np.float32) if want_dL_dx else None
+        lib().orc_grid_backward_backward_input(C.byref(self.g), n, _p(x), _p(dL_ddLdx), _p(dL_dy), dL_dy.shape[1], _p(np.ascontiguousarray(params_half)),
+                                               _p(ctx["dy_dx"] if ctx else None), _p(grad_half), _p(grad_f32), _p(dL_ddLdy), _p(dL_dx))
+        return dL_ddLdy, dL_dx
 
     def backward_exact(self, x, dL_dy, grad_half, accumulate=False):
         """Order-independent limit of the reference's fp16 atomic scatter: exact sum of the fp16 products, rounded once."""

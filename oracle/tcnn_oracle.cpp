@@ -620,6 +620,173 @@ void orc_grid_backward_input(const orc_grid_t* g, uint32_t n, const uint16_t* dL
 	}
 }
 
+// Second-order terms of dL/dx = sum_k dL_dy_k * dy_k/dx (GridEncodingTemplated::backward_backward_input_impl, grid.h:902-1026):
+// given dL/d(dL_dx), the gradients w.r.t. the grid (kernel_grid_backward_input_backward_grid, grid.h:352-454), w.r.t. dL_dy
+// (kernel_grid_backward_input_backward_dLdoutput, grid.h:626-650) and w.r.t. x (kernel_grid_backward_input_backward_input,
+// grid.h:456-624).  Operation order inside a (sample, level, feature pair) follows the kernels; across them the grid
+// gradient is accumulated in sample order (fp16 like the reference's atomics, and optionally fp32), dL_dx in
+// (level, feature pair) order per sample (the reference adds the per-thread partial sums with fp32 atomics in any order).
+void orc_grid_backward_backward_input(const orc_grid_t* g, uint32_t n, const float* x, const float* dL_ddLdx, const uint16_t* dL_dy, uint32_t dy_stride,
+                                      const uint16_t* grid, const float* dy_dx, uint16_t* grad, float* grad_f32, uint16_t* dL_ddLdy, float* dL_dx) {
+	const uint32_t D = g->n_pos_dims, F = g->n_features_per_level, L = g->n_levels;
+	const uint32_t FT = F < 2 ? F : 2; // N_FEATURES_PER_THREAD (grid.h:949)
+	const bool nearest = g->interpolation == ORC_INTERP_NEAREST, smooth = g->interpolation == ORC_INTERP_SMOOTHSTEP;
+
+	auto fractions = [&](uint32_t i, float scale, float* pos, float* d1, float* d2, uint32_t* cell) { // common_device.h:825-838
+		for (uint32_t dim = 0; dim < D; ++dim) {
+			float p = fmaf(scale, x[(size_t)i * D + dim], 0.5f);
+			const float tmp = floorf(p);
+			cell[dim] = (uint32_t)(int)tmp;
+			p -= tmp;
+			d2[dim] = smooth ? 6.0f - 12.0f * p : 0.0f;
+			d1[dim] = smooth ? smoothstep_derivative(p) : 1.0f;
+			pos[dim] = smooth ? smoothstep(p) : p;
+		}
+	};
+
+	if ((grad || grad_f32) && !nearest) { // grid.h:352-454; d(dy_dx)/dgrid is zero without interpolation (:420-423)
+		std::vector<float> scratch32;
+		if (F == 1 && !grad_f32) {
+			scratch32.assign(g->n_params, 0.0f);
+			grad_f32 = scratch32.data();
+		}
+		uint16_t* grad_half_atomic = F == 1 ? nullptr : grad;
+#pragma omp parallel for schedule(dynamic, 1)
+		for (uint32_t level = 0; level < L; ++level) {
+			uint16_t* lgrad = grad_half_atomic ? grad_half_atomic + (size_t)g->offsets[level] * F : nullptr;
+			float* lgrad32 = grad_f32 ? grad_f32 + (size_t)g->offsets[level] * F : nullptr;
+			const uint32_t hashmap_size = g->offsets[level + 1] - g->offsets[level];
+			const float scale = g->scales[level];
+			const uint32_t resolution = g->resolutions[level];
+			for (uint32_t i = 0; i < n; ++i) {
+				float pos[8], d1[8], d2[8];
+				uint32_t cell[8];
+				fractions(i, scale, pos, d1, d2, cell);
+				const uint16_t* gy = dL_dy + (size_t)i * dy_stride + level * F;
+				auto add = [&](const uint32_t* local, float weight) { // :393-396: (GRAD_T)weight * grad, atomic add
+					const uint32_t index = grid_index(D, g->hash_type, g->grid_type, hashmap_size, resolution, local);
+					const uint16_t wh = f2h(weight);
+					for (uint32_t f = 0; f < F; ++f) {
+						if (lgrad) lgrad[(size_t)index * F + f] = hadd(lgrad[(size_t)index * F + f], hmul(wh, gy[f]));
+						if (lgrad32) lgrad32[(size_t)index * F + f] += F == 1 ? weight * h2f(gy[f]) : h2f(hmul(wh, gy[f]));
+					}
+				};
+				for (uint32_t grad_dim = 0; grad_dim < D; ++grad_dim) {
+					const float grad_in = scale * dL_ddLdx[(size_t)i * D + grad_dim] * d1[grad_dim];
+					for (uint32_t idx = 0; idx < (1u << (D - 1)); ++idx) {
+						float weight = grad_in;
+						uint32_t local[8];
+						for (uint32_t ngd = 0; ngd < D - 1; ++ngd) {
+							const uint32_t dim = ngd >= grad_dim ? (ngd + 1) : ngd;
+							if ((idx & (1u << ngd)) == 0) {
+								weight *= 1 - pos[dim];
+								local[dim] = cell[dim];
+							} else {
+								weight *= pos[dim];
+								local[dim] = cell[dim] + 1;
+							}
+						}
+						local[grad_dim] = cell[grad_dim];
+						add(local, -weight);
+						local[grad_dim] = cell[grad_dim] + 1;
+						add(local, weight);
+					}
+				}
+			}
+		}
+		if (F == 1 && grad) for (size_t k = 0; k < g->n_params; ++k) grad[k] = f2h(grad_f32[k]);
+	}
+
+	if (dL_ddLdy) { // grid.h:626-650
+		const uint32_t NF = L * F;
+#pragma omp parallel for schedule(static)
+		for (uint32_t i = 0; i < n; ++i) {
+			for (uint32_t k = 0; k < dy_stride; ++k) {
+				float result = 0;
+				if (k < NF) for (uint32_t dim = 0; dim < D; ++dim) result += dy_dx[((size_t)i * NF + k) * D + dim] * dL_ddLdx[(size_t)i * D + dim];
+				dL_ddLdy[(size_t)i * dy_stride + k] = f2h(result);
+			}
+		}
+	}
+
+	if (dL_dx) { // grid.h:456-624
+#pragma omp parallel for schedule(static)
+		for (uint32_t i = 0; i < n; ++i) {
+			float out[8] = {0};
+			for (uint32_t level = 0; level < L && !nearest; ++level) {
+				const uint16_t* lgrid = grid + (size_t)g->offsets[level] * F;
+				const uint32_t hashmap_size = g->offsets[level + 1] - g->offsets[level];
+				const float scale = g->scales[level];
+				const uint32_t resolution = g->resolutions[level];
+				float pos[8], d1[8], d2[8];
+				uint32_t cell[8];
+				fractions(i, scale, pos, d1, d2, cell);
+				float diag[8], other[8];
+				for (uint32_t gd = 0; gd < D; ++gd) {
+					diag[gd] = scale * scale * dL_ddLdx[(size_t)i * D + gd] * d2[gd];
+					other[gd] = scale * scale * dL_ddLdx[(size_t)i * D + gd] * d1[gd];
+				}
+				for (uint32_t feature = 0; feature < F; feature += FT) {
+					const uint16_t* gy = dL_dy + (size_t)i * dy_stride + level * F + feature;
+					auto calc = [&](const uint32_t* local, float weight) { // :531-541
+						const size_t index = (size_t)grid_index(D, g->hash_type, g->grid_type, hashmap_size, resolution, local) * F + feature;
+						float v = 0;
+						for (uint32_t f = 0; f < FT; ++f) v += h2f(lgrid[index + f]) * h2f(gy[f]) * weight;
+						return v;
+					};
+					for (uint32_t grad_dim = 0; grad_dim < D; ++grad_dim) {
+						float grad_out = 0;
+						for (uint32_t idx = 0; idx < (1u << (D - 1)); ++idx) {
+							if (smooth) { // diagonal part of the Hessian (zero for linear interpolation)
+								float w = diag[grad_dim];
+								uint32_t local[8];
+								for (uint32_t ngd = 0; ngd < D - 1; ++ngd) {
+									const uint32_t dim = ngd >= grad_dim ? (ngd + 1) : ngd;
+									if ((idx & (1u << ngd)) == 0) {
+										w *= 1 - pos[dim];
+										local[dim] = cell[dim];
+									} else {
+										w *= pos[dim];
+										local[dim] = cell[dim] + 1;
+									}
+								}
+								local[grad_dim] = cell[grad_dim];
+								grad_out += calc(local, -w);
+								local[grad_dim] = cell[grad_dim] + 1;
+								grad_out += calc(local, w);
+							}
+							if (D > 1) { // mixed part: d(dy/d[other])/d[grad_dim]
+								for (uint32_t og = 0; og < D - 1; ++og) {
+									const uint32_t rog = og >= grad_dim ? (og + 1) : og;
+									float w = other[rog] * d1[grad_dim];
+									uint32_t local[8];
+									for (uint32_t ngd = 0; ngd < D - 1; ++ngd) {
+										const uint32_t dim = ngd >= rog ? (ngd + 1) : ngd;
+										if ((idx & (1u << ngd)) == 0) {
+											if (dim != grad_dim) w *= 1 - pos[dim];
+											else w *= -1;
+											local[dim] = cell[dim];
+										} else {
+											if (dim != grad_dim) w *= pos[dim];
+											local[dim] = cell[dim] + 1;
+										}
+									}
+									local[rog] = cell[rog];
+									grad_out += calc(local, -w);
+									local[rog] = cell[rog] + 1;
+									grad_out += calc(local, w);
+								}
+							}
+						}
+						out[grad_dim] += grad_out;
+					}
+				}
+			}
+			for (uint32_t d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = out[d];
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------
 void orc_oneblob_forward(uint32_t n, uint32_t n_dims, uint32_t n_bins, const float* x, uint16_t* out, uint32_t out_stride) {
 	uint32_t log2_bins = 0;

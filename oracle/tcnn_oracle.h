@@ -94,6 +94,12 @@ void orc_grid_backward(const orc_grid_t* g, uint32_t n, const float* x, const ui
 void orc_grid_backward_exact(const orc_grid_t* g, uint32_t n, const float* x, const uint16_t* dL_dy, uint32_t dy_stride, uint16_t* grad, int accumulate);
 /* grid.h:323-349 */
 void orc_grid_backward_input(const orc_grid_t* g, uint32_t n, const uint16_t* dL_dy, uint32_t dy_stride, const float* dy_dx, float* dL_dx);
+/* grid.h:352-650, 902-1026 (backward_backward_input): second-order terms of dL_dx = sum_k dL_dy_k dy_k/dx.
+ * dL_ddLdx [n][D] float = gradient arriving at dL_dx.  Optional outputs: grad half[n_params] / grad_f32 (accumulated in place like
+ * orc_grid_backward), dL_ddLdy half [n][dy_stride] (needs dy_dx [n][L*F][D] of the forward pass; padded columns 0),
+ * dL_dx float [n][D] (needs grid; overwritten). */
+void orc_grid_backward_backward_input(const orc_grid_t* g, uint32_t n, const float* x, const float* dL_ddLdx, const uint16_t* dL_dy, uint32_t dy_stride,
+                                      const uint16_t* grid, const float* dy_dx, uint16_t* grad, float* grad_f32, uint16_t* dL_ddLdy, float* dL_dx);
 
 /* ---- OneBlob (oneblob.h:47-164, definition form) and Identity (identity.h:46-85) ---- */
 void orc_oneblob_forward(uint32_t n, uint32_t n_dims, uint32_t n_bins, const float* x, uint16_t* out, uint32_t out_stride);

@@ -164,9 +164,17 @@ int tcnn_module_backward(tcnn_module_t m, tcnn_stream_t stream, tcnn_context_t c
 	});
 }
 
-int tcnn_module_backward_backward_input(tcnn_module_t, tcnn_stream_t, tcnn_context_t, uint32_t, const float*, const float*, const void*, void*, void*, float*, const void*) {
-	g_last_error = "backward_backward_input (second-order input gradients) is not implemented in this build";
-	return TCNN_ERROR;
+int tcnn_module_backward_backward_input(tcnn_module_t m, tcnn_stream_t stream, tcnn_context_t ctx, uint32_t n, const float* dL_ddLdinput, const float* input, const void* dL_doutput,
+                                        void* dL_dparams, void* dL_ddLdoutput, float* dL_dinput, const void* params) {
+	return guarded([&] { // cpp_api.cu:111-127
+		CHECK_THROW(m && m->model);
+		if (!ctx || !ctx->ctx) throw std::runtime_error{"Module::bwd_bwd_input: called with invalid context. fwd likely (mistakenly) ran in inference mode."};
+		CHECK_THROW(dL_ddLdinput != nullptr && input != nullptr);
+		const uint32_t w = m->model->input_width();
+		MatViewMut dx{dL_dinput, w, 1u};
+		m->model->backward_backward_input((hipStream_t)stream, *ctx->ctx, n, MatView{input, w, 1u}, MatView{dL_ddLdinput, w, 1u}, dL_doutput, dL_ddLdoutput, dL_dinput ? &dx : nullptr, params,
+		                                  dL_dparams, dL_dparams ? GradientMode::Overwrite : GradientMode::Ignore);
+	});
 }
 
 void tcnn_context_destroy(tcnn_context_t ctx) { delete ctx; }

@@ -227,6 +227,11 @@ public:
 	// dL_dy [n][padded] T; grads: T[n_params] or nullptr (Ignore)
 	// dy_planes: dL_dy is laid out as level planes [padded / F][n][F] (only if level_plane_features() allowed it), else AoS
 	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) = 0;
+	// second-order input gradients (object.h:278-288); only the grid encoding provides them (grid.h:902-1026)
+	virtual void backward_backward_input(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, MatView dL_ddLdx, const void* dL_dy, void* dL_ddLdy,
+	                                     MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) {
+		throw std::runtime_error{"DifferentiableObject::backward_backward_input_impl: not implemented error"};
+	}
 	// > 0: this encoding's backward prefers dL_dy in level planes with that many features per plane (see k_grid_bwd_lds)
 	virtual uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const { return 0; }
 	// true: the encoding is half(x * scale + offset) padded with ones -- cheap enough to apply inside the consumer's load
@@ -483,6 +488,32 @@ public:
 			CHECK_THROW(ctx.dy_dx);
 			CHECK_THROW(!dy_planes);
 			grid_backward_input(stream, m_meta, m_fp32, n, dL_dy, padded_output_width(), ctx.dy_dx.as<float>(), *dL_dx);
+		}
+	}
+
+	// grid.h:902-1026
+	void backward_backward_input(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, MatView dL_ddLdx, const void* dL_dy, void* dL_ddLdy,
+	                             MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) override {
+		if ((!dL_ddLdy && mode == GradientMode::Ignore && !dL_dx) || padded_output_width() == 0 || n == 0) return;
+		const size_t elem = m_fp32 ? 4 : 2;
+		if (dL_ddLdy) CHECK_THROW(ctx.dy_dx); // needs the forward pass to have run with prepare_input_gradients
+		const float* dy_dx = ctx.dy_dx.as<float>();
+		if (mode != GradientMode::Ignore) {
+			CHECK_THROW(grads != nullptr);
+			const bool scratch32 = !m_fp32 && m_meta.n_features_per_level == 1; // grid.h:660: F == 1 accumulates in fp32 and casts (:934-941, :971-975)
+			if (scratch32) {
+				ArenaBuf tmp{stream, n_params() * sizeof(float)};
+				if (mode == GradientMode::Overwrite) HIP_CHECK_THROW(hipMemsetAsync(tmp.data(), 0, n_params() * sizeof(float), stream));
+				else cast_half_to_float(stream, n_params(), grads, tmp.as<float>());
+				grid_backward_backward_input(stream, m_meta, dev_meta(), false, true, n, x, dL_ddLdx, dL_dy, padded_output_width(), params, dy_dx, tmp.data(), nullptr, nullptr);
+				cast_float_to_half(stream, n_params(), tmp.as<float>(), grads);
+			} else {
+				if (mode == GradientMode::Overwrite) HIP_CHECK_THROW(hipMemsetAsync(grads, 0, n_params() * elem, stream)); // grid.h:943-945
+				grid_backward_backward_input(stream, m_meta, dev_meta(), m_fp32, m_fp32, n, x, dL_ddLdx, dL_dy, padded_output_width(), params, dy_dx, grads, nullptr, nullptr);
+			}
+		}
+		if (dL_ddLdy || dL_dx) {
+			grid_backward_backward_input(stream, m_meta, dev_meta(), m_fp32, m_fp32, n, x, dL_ddLdx, dL_dy, padded_output_width(), params, dy_dx, nullptr, dL_ddLdy, dL_dx);
 		}
 	}
 
@@ -862,6 +893,12 @@ public:
 	virtual std::unique_ptr<ModelContext> forward(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params, bool prepare_input_gradients) = 0;
 	virtual void backward(hipStream_t stream, const ModelContext& ctx, uint32_t n, MatView input, const void* output, const void* dL_doutput,
 	                      MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) = 0;
+	// object.h:278-331: second-order input gradients.  dL_ddLdinput [n][input_width] float arrives at dL_dinput; optional
+	// results: dL_ddLdoutput [n][padded_output_width], dL_dinput (overwritten), parameter gradients per `mode`.
+	virtual void backward_backward_input(hipStream_t stream, const ModelContext& ctx, uint32_t n, MatView input, MatView dL_ddLdinput, const void* dL_doutput,
+	                                     void* dL_ddLdoutput, MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) {
+		throw std::runtime_error{"DifferentiableObject::backward_backward_input_impl: not implemented error"}; // object.h:288
+	}
 	virtual Json hyperparams() const = 0;
 	std::string name() const { return hyperparams().value("otype", "<Unknown>"); } // object.h:51-53
 
@@ -1100,6 +1137,12 @@ public:
 		check_batch(n);
 		const Ctx& ctx = dynamic_cast<const Ctx&>(mctx);
 		m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_doutput, dL_dinput, params, gradients, mode, false);
+	}
+	void backward_backward_input(hipStream_t stream, const ModelContext& mctx, uint32_t n, MatView input, MatView dL_ddLdinput, const void* dL_doutput,
+	                             void* dL_ddLdoutput, MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) override {
+		check_batch(n);
+		const Ctx& ctx = dynamic_cast<const Ctx&>(mctx);
+		m_encoding->backward_backward_input(stream, ctx.encoding_ctx, n, input, dL_ddLdinput, dL_doutput, dL_ddLdoutput, dL_dinput, params, gradients, mode);
 	}
 	Json hyperparams() const override { return m_encoding->hyperparams(); }
 private:

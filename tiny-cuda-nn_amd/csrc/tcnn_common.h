@@ -133,6 +133,10 @@ size_t grid_bin_workspace_bytes(const GridMeta& meta, uint32_t n);
 void grid_backward_binned(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, MatView x, const void* dL_dy, uint32_t dy_stride_sample,
                           uint32_t dy_stride_level, void* grad, bool accumulate, void* workspace);
 void grid_backward_input(hipStream_t stream, const GridMeta& meta, bool fp32, uint32_t n, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
+// second-order input gradients (k_grid_bwdbwd.hip; grid.h:352-650): each of grad (accumulated in place, GT = float if fp32_grad),
+// dL_ddLdy (T [n][dy_stride], needs dy_dx) and dL_dx (overwritten, needs grid) is optional
+void grid_backward_backward_input(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, bool fp32_grad, uint32_t n, MatView x, MatView dL_ddLdx, const void* dL_dy,
+                                  uint32_t dy_stride, const void* grid, const float* dy_dx, void* grad, void* dL_ddLdy, MatViewMut* dL_dx);
 
 // OneBlob / Identity (AoS output, T = half or float)
 void oneblob_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, uint32_t n_bins, MatView x, void* out, uint32_t out_stride);

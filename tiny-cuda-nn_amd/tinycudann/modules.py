@@ -121,6 +121,29 @@ class NativeModule:
                                                      _ptr(input), _ptr(output), _ptr(params)))
         return dL_dinput, dL_dparams
 
+    def bwd_bwd_input(self, ctx, input, params, dL_ddLdinput, dL_doutput):  # bindings.cpp:172-245
+        """from dL_ddLdinput to (dL_ddLdoutput, dL_dparams, dL_dinput); each is None unless its tensor requires grad."""
+        if ctx is None or not ctx._h:
+            raise RuntimeError("Module::bwd_bwd_input: called with invalid context. fwd likely (mistakenly) ran in inference mode.")
+        self._check_inputs(input, params)
+        if not (dL_ddLdinput.is_cuda and dL_ddLdinput.is_contiguous() and dL_ddLdinput.dtype == torch.float32 and dL_ddLdinput.shape == input.shape):
+            raise RuntimeError("tcnn: dL_ddLdinput must be a contiguous float32 device tensor shaped like input")
+        if not (dL_doutput.is_cuda and dL_doutput.is_contiguous()) or dL_doutput.dtype != _torch_precision(self.output_precision()):
+            raise RuntimeError("tcnn: dL_doutput must be a contiguous device tensor in output precision")
+        if dL_doutput.shape[0] != input.shape[0] or dL_doutput.shape[1] != self.n_output_dims():
+            raise RuntimeError("tcnn: wrong shape for dL_doutput")
+        with torch.cuda.device(input.device):
+            n = input.shape[0]
+            dL_ddLdoutput = torch.zeros((n, self.n_output_dims()), dtype=dL_doutput.dtype, device=input.device) if dL_doutput.requires_grad else None
+            dL_dparams = torch.zeros(self.n_params(), dtype=params.dtype, device=input.device) if params.requires_grad else None
+            dL_dinput = torch.zeros((n, input.shape[1]), dtype=torch.float32, device=input.device) if input.requires_grad else None
+            # The reference only makes the native call when dL_doutput or params require grad (bindings.cpp:224), which leaves
+            # dL_dinput all zero for a frozen grid; here the Hessian term is computed whenever the input asks for it.
+            if dL_doutput.requires_grad or params.requires_grad or input.requires_grad:
+                _C.check(_C.lib.tcnn_module_backward_backward_input(self._h, _stream(), ctx._h, n, _ptr(dL_ddLdinput), _ptr(input), _ptr(dL_doutput), _ptr(dL_dparams),
+                                                                    _ptr(dL_ddLdoutput), _ptr(dL_dinput), _ptr(params)))
+        return dL_ddLdoutput, dL_dparams, dL_dinput
+
 
 class NativeContext:
     def __init__(self, handle):
@@ -152,7 +175,6 @@ class _ModuleFunction(torch.autograd.Function):
         return output
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, doutput):
         if doutput is None:
             return None, None, None, None
@@ -160,16 +182,53 @@ class _ModuleFunction(torch.autograd.Function):
             warnings.warn("doutput must be a CUDA tensor, but isn't. This indicates suboptimal performance.")
             doutput = doutput.cuda()
         input, params, output = ctx.saved_tensors
-        # restore the requires_grad flags the native bwd keys on (saved tensors are detached)
-        input_g = input.detach().requires_grad_(ctx.needs_input_grad[1])
-        params_g = params.detach().requires_grad_(ctx.needs_input_grad[2])
-        scaled = (doutput * ctx.loss_scale).contiguous()
-        input_grad, params_grad = ctx.native.bwd(ctx.native_ctx, input_g, params_g, output, scaled)
-        if input_grad is not None:
-            input_grad = input_grad / ctx.loss_scale
-        if params_grad is not None:
-            params_grad = params_grad / ctx.loss_scale
-        return None, input_grad, params_grad, None
+        # the backward pass is itself a differentiable function (modules.py:107-118): second-order input gradients
+        input_grad, params_grad = _ModuleFunctionBackward.apply(ctx, doutput, input, params, output)
+        return None, _null_tensor_to_none(input_grad), _null_tensor_to_none(params_grad), None
+
+
+def _null_tensor_like(tensor):
+    return torch.empty([], dtype=tensor.dtype, device=tensor.device)
+
+
+def _null_tensor_to_none(tensor):
+    return None if len(tensor.shape) == 0 else tensor
+
+
+class _ModuleFunctionBackward(torch.autograd.Function):
+    """modules.py:120-160 of the reference.  Supported, like there: d(dL_dinput)/d(dL_doutput), d(dL_dinput)/d(params),
+    d(dL_dinput)/d(input); nothing flows back from dL_dparams."""
+
+    @staticmethod
+    def forward(ctx, ctx_fwd, doutput, input, params, output):
+        ctx.ctx_fwd = ctx_fwd
+        ctx.save_for_backward(input, params, doutput)
+        with torch.no_grad():
+            # the native bwd keys on requires_grad; inside a Function's forward the flags of the arguments are not reliable
+            input_g = input.detach().requires_grad_(ctx_fwd.needs_input_grad[1])
+            params_g = params.detach().requires_grad_(ctx_fwd.needs_input_grad[2])
+            scaled = (doutput * ctx_fwd.loss_scale).contiguous()
+            input_grad, params_grad = ctx_fwd.native.bwd(ctx_fwd.native_ctx, input_g, params_g, output, scaled)
+            input_grad = _null_tensor_like(input) if input_grad is None else (input_grad / ctx_fwd.loss_scale)
+            params_grad = _null_tensor_like(params) if params_grad is None else (params_grad / ctx_fwd.loss_scale)
+        return input_grad, params_grad
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dinput_grad, dparams_grad):
+        input, params, doutput = ctx.saved_tensors
+        fwd = ctx.ctx_fwd
+        if dinput_grad is None or len(dinput_grad.shape) == 0:
+            return None, None, None, None, None
+        need_doutput, need_input, need_params = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        scaled = (doutput.detach() * fwd.loss_scale).contiguous().requires_grad_(need_doutput)
+        input_g = input.detach().requires_grad_(need_input)
+        params_g = params.detach().requires_grad_(need_params)
+        doutput_grad, params_grad, input_grad = fwd.native.bwd_bwd_input(fwd.native_ctx, input_g, params_g, dinput_grad.contiguous().float(), scaled)
+        # loss scale bookkeeping (modules.py:150-156): doutput_grad is linear in dinput_grad only; the other two also in doutput
+        params_grad = None if params_grad is None else (params_grad / fwd.loss_scale)
+        input_grad = None if input_grad is None else (input_grad / fwd.loss_scale)
+        return None, doutput_grad, input_grad, params_grad, None
 
 
 class Module(torch.nn.Module):
