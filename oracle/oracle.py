@@ -92,6 +92,9 @@ def lib():
             "orc_grid_backward_exact": (None, [vp, u32, vp, vp, u32, vp, C.c_int]),
             "orc_oneblob_forward": (None, [u32, u32, u32, vp, vp, u32]), "orc_oneblob_backward_input": (None, [u32, u32, u32, vp, vp, u32, vp]),
             "orc_identity_forward": (None, [u32, u32, f32, f32, vp, vp, u32]), "orc_identity_backward_input": (None, [u32, u32, f32, vp, u32, vp]),
+            "orc_frequency_forward": (None, [u32, u32, u32, vp, vp, u32, vp]), "orc_trianglewave_forward": (None, [u32, u32, u32, vp, vp, u32, vp]),
+            "orc_periodic_backward_input": (None, [u32, u32, u32, vp, u32, vp, vp]),
+            "orc_sh_forward": (None, [u32, u32, vp, vp, u32]), "orc_sh_backward_input": (None, [u32, u32, vp, vp, u32, vp]),
             "orc_mlp_n_params": (sz, [vp]), "orc_mlp_init_params": (None, [vp, vp, vp, f32]),
             "orc_mlp_forward": (None, [vp, u32, vp, vp, vp, vp]),
             "orc_mlp_backward": (None, [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]),
@@ -386,6 +389,91 @@ class IdentityEncoding:
         return {"otype": "Identity", "scale": self.scale, "offset": self.offset}
 
 
+class PeriodicEncoding:
+    """encodings/frequency.h:104-220 (kind "frequency": 2 outputs per frequency) and encodings/triangle_wave.h:110-220"""
+
+    def __init__(self, n_in, cfg, kind):
+        self.kind = kind
+        self.n_frequencies = int(_ci(cfg, "n_frequencies", 12))
+        self.n_in = n_in
+        self.outputs_per_input = self.n_frequencies * (2 if kind == "frequency" else 1)
+        self.n_output_dims = n_in * self.outputs_per_input
+        self.n_to_pad = 0
+        self.n_params = 0
+        self.required_output_alignment = 1
+
+    padded_output_width = GridEncoding.padded_output_width
+    set_alignment = GridEncoding.set_alignment
+
+    def initialize_params(self, rng, scale=1.0):
+        return np.empty(0, dtype=np.float32)
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((n, self.padded_output_width), dtype=np.uint16)
+        dy_dx = np.empty((n, self.n_output_dims), dtype=np.float32) if want_dy_dx else None
+        fn = lib().orc_frequency_forward if self.kind == "frequency" else lib().orc_trianglewave_forward
+        fn(n, self.n_in, self.n_frequencies, _p(x), _p(out), out.shape[1], _p(dy_dx))
+        return out, {"dy_dx": dy_dx}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        if not want_dL_dx:
+            return None
+        n = x.shape[0]
+        dL_dy = np.ascontiguousarray(dL_dy)
+        dL_dx = np.empty((n, self.n_in), dtype=np.float32)
+        lib().orc_periodic_backward_input(n, self.n_in, self.outputs_per_input, _p(dL_dy), dL_dy.shape[1], _p(ctx["dy_dx"]), _p(dL_dx))
+        return dL_dx
+
+    def hyperparams(self):
+        return {"otype": "Frequency" if self.kind == "frequency" else "TriangleWave", "n_frequencies": self.n_frequencies}
+
+
+class SphericalHarmonicsEncoding:
+    """encodings/spherical_harmonics.h:110-230"""
+
+    def __init__(self, n_in, cfg):
+        self.degree = int(_ci(cfg, "degree", 4))
+        if n_in != 3:
+            raise RuntimeError("Can only encode 3D directions in spherical harmonics.")
+        if self.degree <= 0:
+            raise RuntimeError("Spherical harmonics must have positive degree.")
+        if self.degree > 8:
+            raise RuntimeError("Spherical harmonics are only implemented up to degree 8.")
+        self.n_in = n_in
+        self.n_output_dims = self.degree * self.degree
+        self.n_to_pad = 0
+        self.n_params = 0
+        self.required_output_alignment = 1
+
+    padded_output_width = GridEncoding.padded_output_width
+    set_alignment = GridEncoding.set_alignment
+
+    def initialize_params(self, rng, scale=1.0):
+        return np.empty(0, dtype=np.float32)
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((n, self.padded_output_width), dtype=np.uint16)
+        lib().orc_sh_forward(n, self.degree, _p(x), _p(out), out.shape[1])
+        return out, {}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        if not want_dL_dx:
+            return None
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dL_dy = np.ascontiguousarray(dL_dy)
+        dL_dx = np.empty((n, 3), dtype=np.float32)
+        lib().orc_sh_backward_input(n, self.degree, _p(x), _p(dL_dy), dL_dy.shape[1], _p(dL_dx))
+        return dL_dx
+
+    def hyperparams(self):
+        return {"otype": "SphericalHarmonics", "degree": self.degree}
+
+
 def create_encoding(n_in, cfg, alignment=8):
     """src/encoding.cu:144-158 (case-insensitive otype, default OneBlob)"""
     name = _norm(_ci(cfg, "otype", "OneBlob"))
@@ -395,6 +483,12 @@ def create_encoding(n_in, cfg, alignment=8):
         enc = OneBlobEncoding(n_in, cfg)
     elif name == "identity":
         enc = IdentityEncoding(n_in, cfg)
+    elif name == "frequency":
+        enc = PeriodicEncoding(n_in, cfg, "frequency")
+    elif name == "trianglewave":
+        enc = PeriodicEncoding(n_in, cfg, "trianglewave")
+    elif name == "sphericalharmonics":
+        enc = SphericalHarmonicsEncoding(n_in, cfg)
     else:
         raise RuntimeError(f"Encoding '{cfg.get('otype')}' not found")
     if alignment > 0:

@@ -851,6 +851,143 @@ void orc_identity_backward_input(uint32_t n, uint32_t n_dims, float scale, const
 	}
 }
 
+// ---- Frequency (encodings/frequency.h:44-101) and TriangleWave (encodings/triangle_wave.h:44-107): AoS output, pad dims = 1.
+// The reference evaluates __sinf / __cosf (hardware approximations); here sinf / cosf -- parity for Frequency is by tolerance.
+void orc_frequency_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const float* x, uint16_t* out, uint32_t out_stride, float* dy_dx) {
+	const uint32_t fan_out_encoded = n_dims * n_frequencies * 2;
+	const float PI = 3.14159265358979323846f;
+#pragma omp parallel for schedule(static)
+	for (uint32_t i = 0; i < n; ++i) {
+		for (uint32_t j = 0; j < out_stride; ++j) {
+			if (j >= fan_out_encoded) { out[(size_t)i * out_stride + j] = f2h(1.0f); continue; }
+			const uint32_t feature = j / (n_frequencies * 2);
+			const uint32_t log2_frequency = (j / 2) % n_frequencies;
+			const float phase_shift = (j % 2) * (PI / 2);
+			const float v = scalbnf(x[(size_t)i * n_dims + feature], (int)log2_frequency);
+			const float input = v * PI + phase_shift;
+			out[(size_t)i * out_stride + j] = f2h(sinf(input));
+			if (dy_dx) dy_dx[(size_t)i * fan_out_encoded + j] = scalbnf(1.0f, (int)log2_frequency) * PI * cosf(input);
+		}
+	}
+}
+
+void orc_trianglewave_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const float* x, uint16_t* out, uint32_t out_stride, float* dy_dx) {
+	const uint32_t fan_out_encoded = n_dims * n_frequencies;
+#pragma omp parallel for schedule(static)
+	for (uint32_t i = 0; i < n; ++i) {
+		for (uint32_t j = 0; j < out_stride; ++j) {
+			if (j >= fan_out_encoded) { out[(size_t)i * out_stride + j] = f2h(1.0f); continue; }
+			const uint32_t feature = j / n_frequencies;
+			const int log2_frequency = (int)(j - feature * n_frequencies);
+			const float v = scalbnf(x[(size_t)i * n_dims + feature], log2_frequency - 1);
+			const float val = v + log2_frequency * 0.25f; // small frequency-dependent phase shift (triangle_wave.h:71-72)
+			out[(size_t)i * out_stride + j] = f2h(fabsf(val - floorf(val) - 0.5f) * 4 - 1);
+			if (dy_dx) dy_dx[(size_t)i * fan_out_encoded + j] = scalbnf((int)floorf(val * 2.0f) % 2 == 0 ? -1.0f : 1.0f, log2_frequency + 1);
+		}
+	}
+}
+
+// frequency.h:82-101 / triangle_wave.h:83-107: dL_dx(j) = sum_k dL_dy(j * outputs_per_input + k) * dy_dx
+void orc_periodic_backward_input(uint32_t n, uint32_t n_dims, uint32_t outputs_per_input, const uint16_t* dL_dy, uint32_t dy_stride, const float* dy_dx, float* dL_dx) {
+#pragma omp parallel for schedule(static)
+	for (uint32_t i = 0; i < n; ++i) {
+		for (uint32_t j = 0; j < n_dims; ++j) {
+			float result = 0;
+			for (uint32_t k = 0; k < outputs_per_input; ++k)
+				result += h2f(dL_dy[(size_t)i * dy_stride + j * outputs_per_input + k]) * dy_dx[((size_t)i * n_dims + j) * outputs_per_input + k];
+			dL_dx[(size_t)i * n_dims + j] = result;
+		}
+	}
+}
+
+// ---- SphericalHarmonics (encodings/spherical_harmonics.h:44-108; common_device.h:339-420 sh_enc, :421-700 sh_enc_grad).
+// The reference hard-codes the 64 polynomials of degree <= 8 (generated from the recurrences of P.-P. Sloan, "Stupid Spherical
+// Harmonics Tricks", appendix A1).  This restatement evaluates the SAME polynomials through those recurrences:
+//   Y_l^m(x, y, z) = N_l^|m| * Q_l^|m|(z) * { Im (x + iy)^|m|  (m < 0),  1  (m = 0),  Re (x + iy)^m  (m > 0) }
+//   Q_m^m = (-1)^m (2m - 1)!!,  Q_{m+1}^m = (2m + 1) z Q_m^m,  Q_l^m = ((2l - 1) z Q_{l-1}^m - (l + m - 1) Q_{l-2}^m) / (l - m)
+//   N_l^m = sqrt((2l + 1) / (4 pi) * (l - m)! / (l + m)!) * (m ? sqrt 2 : 1)
+// -- polynomials in z times harmonic polynomials in (x, y), identical as functions (also off the unit sphere), summed in a
+// different floating-point order (differences ~1e-7 relative, below fp16 resolution).  Output index l^2 + l + m.
+static void sh_norms(uint32_t degree, float* norms /* [degree][degree] indexed [l][m] */) {
+	for (uint32_t l = 0; l < degree; ++l) {
+		for (uint32_t m = 0; m <= l; ++m) {
+			double ratio = 1.0; // (l - m)! / (l + m)!
+			for (uint32_t k = l - m + 1; k <= l + m; ++k) ratio /= (double)k;
+			norms[l * degree + m] = (float)(std::sqrt((2.0 * l + 1.0) / (4.0 * 3.14159265358979323846) * ratio) * (m ? std::sqrt(2.0) : 1.0));
+		}
+	}
+}
+
+// values (and optionally the gradient against dL_dy) of all degree^2 functions at one point
+static void sh_eval(uint32_t degree, const float* norms, float x, float y, float z, float* values, const uint16_t* dL_dy, float* grad3) {
+	float gx = 0, gy = 0, gz = 0;
+	float c = 1, s = 0, cp = 0, sp = 0; // Re / Im (x + iy)^m and ^(m-1)
+	float qmm = 1;                      // Q_m^m
+	for (uint32_t m = 0; m < degree; ++m) {
+		if (m > 0) {
+			cp = c;
+			sp = s;
+			c = x * cp - y * sp;
+			s = x * sp + y * cp;
+			qmm = -qmm * (float)(2 * m - 1);
+		}
+		float q2 = 0, q1 = 0, d2 = 0, d1 = 0; // Q_{l-2}^m, Q_{l-1}^m and their z derivatives
+		for (uint32_t l = m; l < degree; ++l) {
+			float q, dq;
+			if (l == m) { q = qmm; dq = 0; }
+			else if (l == m + 1) { q = (float)(2 * m + 1) * z * q1; dq = (float)(2 * m + 1) * q1; }
+			else {
+				q = ((float)(2 * l - 1) * z * q1 - (float)(l + m - 1) * q2) / (float)(l - m);
+				dq = ((float)(2 * l - 1) * (q1 + z * d1) - (float)(l + m - 1) * d2) / (float)(l - m);
+			}
+			q2 = q1; q1 = q; d2 = d1; d1 = dq;
+			const float nq = norms[l * degree + m] * q, ndq = norms[l * degree + m] * dq;
+			const uint32_t base = l * l + l;
+			if (m == 0) {
+				if (values) values[base] = nq;
+				if (dL_dy) gz += h2f(dL_dy[base]) * ndq;
+			} else {
+				if (values) { values[base + m] = nq * c; values[base - m] = nq * s; }
+				if (dL_dy) {
+					const float gp = h2f(dL_dy[base + m]), gm = h2f(dL_dy[base - m]);
+					// d/dx (x + iy)^m = m (x + iy)^(m-1), d/dy = i m (x + iy)^(m-1)
+					gx += gp * (nq * (float)m * cp) + gm * (nq * (float)m * sp);
+					gy += gp * (nq * -(float)m * sp) + gm * (nq * (float)m * cp);
+					gz += gp * (ndq * c) + gm * (ndq * s);
+				}
+			}
+		}
+	}
+	if (grad3) { grad3[0] = gx; grad3[1] = gy; grad3[2] = gz; }
+}
+
+// out: [n][out_stride] half; the padding columns come FIRST (spherical_harmonics.h:58-64), then the degree^2 values
+void orc_sh_forward(uint32_t n, uint32_t degree, const float* x, uint16_t* out, uint32_t out_stride) {
+	std::vector<float> norms(degree * degree);
+	sh_norms(degree, norms.data());
+	const uint32_t n_to_pad = out_stride - degree * degree;
+#pragma omp parallel for schedule(static)
+	for (uint32_t i = 0; i < n; ++i) {
+		float values[64];
+		sh_eval(degree, norms.data(), x[(size_t)i * 3] * 2.f - 1.f, x[(size_t)i * 3 + 1] * 2.f - 1.f, x[(size_t)i * 3 + 2] * 2.f - 1.f, values, nullptr, nullptr);
+		for (uint32_t j = 0; j < n_to_pad; ++j) out[(size_t)i * out_stride + j] = f2h(1.0f);
+		for (uint32_t j = 0; j < degree * degree; ++j) out[(size_t)i * out_stride + n_to_pad + j] = f2h(values[j]);
+	}
+}
+
+// spherical_harmonics.h:78-105: dL_dx = 2 * sum_k dL_dy_k dY_k/d(direction)
+void orc_sh_backward_input(uint32_t n, uint32_t degree, const float* x, const uint16_t* dL_dy, uint32_t dy_stride, float* dL_dx) {
+	std::vector<float> norms(degree * degree);
+	sh_norms(degree, norms.data());
+	const uint32_t n_to_pad = dy_stride - degree * degree;
+#pragma omp parallel for schedule(static)
+	for (uint32_t i = 0; i < n; ++i) {
+		float g[3];
+		sh_eval(degree, norms.data(), x[(size_t)i * 3] * 2.f - 1.f, x[(size_t)i * 3 + 1] * 2.f - 1.f, x[(size_t)i * 3 + 2] * 2.f - 1.f, nullptr, dL_dy + (size_t)i * dy_stride + n_to_pad, g);
+		for (uint32_t d = 0; d < 3; ++d) dL_dx[(size_t)i * 3 + d] = 2.0f * g[d];
+	}
+}
+
 // ---------------------------------------------------------------------------------------------------------
 size_t orc_mlp_n_params(const orc_mlp_t* m) { return mlp_layout(m).total; }
 

@@ -107,6 +107,16 @@ void orc_oneblob_backward_input(uint32_t n, uint32_t n_dims, uint32_t n_bins, co
 void orc_identity_forward(uint32_t n, uint32_t n_dims, float scale, float offset, const float* x, uint16_t* out, uint32_t out_stride);
 void orc_identity_backward_input(uint32_t n, uint32_t n_dims, float scale, const uint16_t* dL_dy, uint32_t dy_stride, float* dL_dx);
 
+/* ---- Frequency (frequency.h:44-101), TriangleWave (triangle_wave.h:44-107): out AoS [n][out_stride] half, pad dims = 1;
+ * dy_dx (optional) float [n][n_dims * outputs_per_input].  orc_periodic_backward_input serves both backward kernels. ---- */
+void orc_frequency_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const float* x, uint16_t* out, uint32_t out_stride, float* dy_dx);
+void orc_trianglewave_forward(uint32_t n, uint32_t n_dims, uint32_t n_frequencies, const float* x, uint16_t* out, uint32_t out_stride, float* dy_dx);
+void orc_periodic_backward_input(uint32_t n, uint32_t n_dims, uint32_t outputs_per_input, const uint16_t* dL_dy, uint32_t dy_stride, const float* dy_dx, float* dL_dx);
+/* ---- SphericalHarmonics (spherical_harmonics.h:44-108, common_device.h:339-700): x [n][3] in [0,1]^3 -> directions 2x-1;
+ * degree^2 outputs, the PADDING COLUMNS FIRST; degree <= 8. ---- */
+void orc_sh_forward(uint32_t n, uint32_t degree, const float* x, uint16_t* out, uint32_t out_stride);
+void orc_sh_backward_input(uint32_t n, uint32_t degree, const float* x, const uint16_t* dL_dy, uint32_t dy_stride, float* dL_dx);
+
 /* ---- MLP (fully_fused_mlp.cu:500-557,151-259,736-836; cutlass_mlp.cu:39-315) ---- */
 typedef struct {
 	uint32_t in_width;        /* padded input width */

@@ -1,0 +1,175 @@
+"""Frequency, TriangleWave and SphericalHarmonics encodings (encodings/frequency.h, triangle_wave.h,
+spherical_harmonics.h + common_device.h:339-700).  CPU: the oracle is pinned against independent mathematics (scipy's spherical
+harmonics, closed forms, numpy).  GPU: the HIP kernels against the oracle through the C ABI and the torch surface."""
+import numpy as np
+import pytest
+
+
+# ------------------------------------------------------------------------------------------------------------- oracle pins
+def test_sh_oracle_matches_scipy_and_closed_forms(oracle):
+    """All 64 functions of degree <= 8 against scipy on unit vectors, in the reference's sign convention (Condon-Shortley phase
+    kept: Y_1 = (-c y, c z, -c x)); the first nine against the published closed forms; off the unit sphere the functions are the
+    reference's polynomials (Y_2^0 = 0.946 z^2 - 0.315, not a homogeneous form)."""
+    scipy_special = pytest.importorskip("scipy.special")
+    sph = getattr(scipy_special, "sph_harm_y", None)
+    rs = np.random.RandomState(0)
+    d = rs.normal(size=(256, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x = ((d + 1) / 2).astype(np.float32)
+    enc = oracle.create_encoding(3, {"otype": "SphericalHarmonics", "degree": 8}, alignment=0)
+    assert enc.n_output_dims == 64
+    got = oracle.half_to_f32(enc.forward(x)[0])
+    dd = x.astype(np.float64) * 2 - 1
+    azimuth = np.arctan2(dd[:, 1], dd[:, 0])
+    polar = np.arccos(np.clip(dd[:, 2] / np.linalg.norm(dd, axis=1), -1, 1))
+    for l in range(8):
+        for m in range(-l, l + 1):
+            Y = sph(l, abs(m), polar, azimuth) if sph is not None else scipy_special.sph_harm(abs(m), l, azimuth, polar)
+            want = Y.real if m == 0 else np.sqrt(2) * (Y.real if m > 0 else Y.imag)
+            assert np.abs(got[:, l * l + l + m] - want).max() < 1e-3, (l, m)
+    X, Y_, Z = dd[:, 0], dd[:, 1], dd[:, 2]
+    closed = [0.28209479177387814 + 0 * X, -0.48860251190291987 * Y_, 0.48860251190291987 * Z, -0.48860251190291987 * X, 1.0925484305920792 * X * Y_,
+              -1.0925484305920792 * Y_ * Z, 0.94617469575755997 * Z * Z - 0.31539156525251999, -1.0925484305920792 * X * Z, 0.54627421529603959 * (X * X - Y_ * Y_)]
+    for k, f in enumerate(closed):
+        assert np.abs(got[:, k] - f).max() < 5e-4, k
+    x2 = rs.uniform(0, 1, (64, 3)).astype(np.float32)
+    o2 = oracle.half_to_f32(enc.forward(x2)[0])
+    z = x2[:, 2].astype(np.float64) * 2 - 1
+    assert np.abs(o2[:, 6] - (0.94617469575755997 * z * z - 0.31539156525251999)).max() < 5e-4
+
+
+def test_sh_oracle_padding_comes_first_and_gradient(oracle):
+    enc = oracle.create_encoding(3, {"otype": "SphericalHarmonics", "degree": 3}, alignment=16)  # 9 values, 7 padding columns
+    assert enc.padded_output_width == 16
+    rs = np.random.RandomState(1)
+    x = rs.uniform(0.1, 0.9, (32, 3)).astype(np.float32)
+    out = oracle.half_to_f32(enc.forward(x)[0])
+    assert np.all(out[:, :7] == 1.0) and np.allclose(out[:, 7], 0.28209479, atol=2e-4)  # spherical_harmonics.h:58-64
+    # gradient: central differences of the (fp16-rounded) outputs weighted by dL_dy; padded columns carry no gradient
+    dy = oracle.half_bits(rs.uniform(-1, 1, (32, 16)).astype(np.float32))
+    g = enc.backward(x, {}, dy, want_dL_dx=True)
+    w = oracle.half_to_f32(dy)[:, 7:].astype(np.float64)
+    full = oracle.create_encoding(3, {"otype": "SphericalHarmonics", "degree": 3}, alignment=0)
+    eps = 1e-2
+    for d in range(3):
+        xp, xm = x.copy(), x.copy()
+        xp[:, d] += eps
+        xm[:, d] -= eps
+        fd = ((oracle.half_to_f32(full.forward(xp)[0]).astype(np.float64) - oracle.half_to_f32(full.forward(xm)[0])) * w).sum(1) / (xp[:, d] - xm[:, d])
+        assert np.abs(fd - g[:, d]).max() < 0.08 * max(1.0, np.abs(g[:, d]).max())
+    with pytest.raises(RuntimeError, match="3D directions"):
+        oracle.create_encoding(2, {"otype": "SphericalHarmonics"}, alignment=0)
+    with pytest.raises(RuntimeError, match="up to degree 8"):
+        oracle.create_encoding(3, {"otype": "SphericalHarmonics", "degree": 9}, alignment=0)
+
+
+def test_periodic_oracles_match_numpy(oracle):
+    rs = np.random.RandomState(2)
+    x = rs.uniform(0, 1, (64, 3)).astype(np.float32)
+    f = oracle.create_encoding(3, {"otype": "Frequency", "n_frequencies": 6}, alignment=16)
+    assert f.n_output_dims == 36 and f.padded_output_width == 48
+    out, ctx = f.forward(x, want_dy_dx=True)
+    got = oracle.half_to_f32(out)
+    for j in range(36):
+        feature, k, phase = j // 12, (j // 2) % 6, (j % 2) * np.pi / 2
+        want = np.sin(x[:, feature].astype(np.float64) * 2.0 ** k * np.pi + phase)
+        assert np.abs(got[:, j] - want).max() < 2e-3, j
+        assert np.abs(ctx["dy_dx"][:, j] - 2.0 ** k * np.pi * np.cos(x[:, feature].astype(np.float64) * 2.0 ** k * np.pi + phase)).max() < 2e-3 * 2.0 ** k
+    assert np.all(got[:, 36:] == 1.0)
+    t = oracle.create_encoding(2, {"otype": "TriangleWave", "n_frequencies": 5}, alignment=0)
+    out, ctx = t.forward(x[:, :2], want_dy_dx=True)
+    got = oracle.half_to_f32(out)
+    for j in range(10):
+        feature, k = j // 5, j % 5
+        val = x[:, feature].astype(np.float64) * 2.0 ** (k - 1) + k * 0.25
+        want = np.abs(val - np.floor(val) - 0.5) * 4 - 1
+        assert np.abs(got[:, j] - want).max() < 2e-3, j
+    dy = oracle.half_bits(rs.uniform(-1, 1, (64, 10)).astype(np.float32))
+    g = t.backward(x[:, :2], ctx, dy, want_dL_dx=True)
+    want_g = (oracle.half_to_f32(dy).reshape(64, 2, 5) * ctx["dy_dx"].reshape(64, 2, 5)).sum(2)
+    assert np.allclose(g, want_g, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+CASES = [
+    (3, {"otype": "SphericalHarmonics", "degree": 4}, 1e-6),
+    (3, {"otype": "SphericalHarmonics", "degree": 8}, 1e-6),
+    (3, {"otype": "SphericalHarmonics", "degree": 1}, 0.0),
+    (3, {"otype": "Frequency", "n_frequencies": 10}, 2e-3),  # sinf of arguments up to 2^9 pi: libm vs device sinf
+    (2, {"otype": "TriangleWave", "n_frequencies": 12}, 0.0),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_in,cfg,tol", CASES)
+def test_encoding_forward_backward_match_oracle(tcnn, oracle, n_in, cfg, tol):
+    """tcnn.Encoding through the C ABI.  TriangleWave and degree-1 SH are exact arithmetic -> identical bits; SH: same recurrence
+    in the same order, within one fp16 ulp of the oracle (device vs host fp32 division); Frequency: by tolerance (sinf)."""
+    import torch
+
+    from test_gpu_parity import _bits, _f32, _t
+
+    n = 1024
+    enc = tcnn.Encoding(n_in, cfg)
+    ref = oracle.create_encoding(n_in, cfg, alignment=0)
+    assert enc.n_output_dims == ref.padded_output_width
+    x = oracle.Pcg32(42).uniform_strided(n * n_in).reshape(n, n_in)
+    want, ctx = ref.forward(x, want_dy_dx=True)
+    xt = _t(x).requires_grad_(True)
+    got = enc(xt)
+    if tol == 0.0:
+        assert np.array_equal(_bits(got), want)
+    else:
+        a, b = _f32(_bits(got)), _f32(want)
+        assert np.abs(a - b).max() <= max(tol, 2.0 ** -10 * np.abs(b).max())
+    dy = oracle.half_bits(oracle.Pcg32(5).uniform_strided(n * ref.padded_output_width, -1.0, 1.0).reshape(n, ref.padded_output_width))
+    want_dx = ref.backward(x, ctx, oracle.half_bits(oracle.half_to_f32(dy) * 128.0), want_dL_dx=True) / 128.0  # modules.py scales by loss_scale
+    got.backward(_t(dy.view(np.float16)))
+    got_dx = xt.grad.cpu().numpy()
+    assert np.abs(got_dx - want_dx).max() <= 2e-3 * max(1.0, np.abs(want_dx).max())
+
+
+@pytest.mark.gpu
+def test_fp32_encoding_and_errors(tcnn, oracle):
+    import torch
+
+    enc = tcnn.Encoding(3, {"otype": "SphericalHarmonics", "degree": 4}, dtype=torch.float32)
+    d = torch.nn.functional.normalize(torch.randn(512, 3, device="cuda"), dim=1)
+    y = enc((d + 1) / 2)
+    assert y.dtype == torch.float32 and y.shape == (512, 16)
+    # orthonormality over the sphere is a Monte Carlo statement; a cheap exact one: Y_0 is constant, sum_m Y_1m^2 = 3 / (4 pi)
+    assert torch.allclose(y[:, 0], torch.full((512,), 0.28209479, device="cuda"), atol=1e-6)
+    assert torch.allclose((y[:, 1:4] ** 2).sum(1), torch.full((512,), 3 / (4 * np.pi), device="cuda"), atol=1e-5)
+    assert torch.allclose((y[:, 4:9] ** 2).sum(1), torch.full((512,), 5 / (4 * np.pi), device="cuda"), atol=1e-5)  # addition theorem
+    with pytest.raises(RuntimeError, match="3D directions"):
+        tcnn.Encoding(2, {"otype": "SphericalHarmonics"})
+    with pytest.raises(RuntimeError, match="up to degree 8"):
+        tcnn.Encoding(3, {"otype": "SphericalHarmonics", "degree": 9})
+
+
+@pytest.mark.gpu
+def test_network_with_spherical_harmonics_trains(tcnn, oracle):
+    """NetworkWithInputEncoding(SphericalHarmonics degree 4 -> 64 x 2 FullyFusedMLP), the direction branch of NeRF-style models:
+    one training step against the oracle, and the loss falls over 50 steps."""
+    import torch
+
+    from test_gpu_parity import _bits, _f32, rel_err
+
+    cfg = {
+        "loss": {"otype": "L2"},
+        "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-8},
+        "encoding": {"otype": "SphericalHarmonics", "degree": 4},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2},
+    }
+    ref = oracle.Trainer(3, 3, cfg, seed=1337)
+    tr = tcnn.Trainer(3, 3, cfg, seed=1337)
+    x, t = oracle.synthetic_batch(1024, 3, 3, seed=42)
+    want = ref.training_step(x, t, run_optimizer=True)
+    ctx = tr.training_step(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda())
+    assert rel_err(_f32(_bits(ctx.output()))[:, :3], _f32(want["output"])[:, :3]) < 1e-2
+    assert abs(tr.loss(ctx) - want["loss"]) <= 2e-2 * abs(want["loss"])
+    first = tr.loss(ctx)
+    for s in range(50):
+        xs, ts = oracle.synthetic_batch(1024, 3, 3, seed=100 + s)
+        ctx = tr.training_step(torch.from_numpy(xs).cuda(), torch.from_numpy(ts).cuda())
+    assert tr.loss(ctx) < 0.7 * first

@@ -664,6 +664,64 @@ private:
 };
 
 // src/encoding.cu:144-158 (case-insensitive registry :48-54; default otype OneBlob)
+// encodings/frequency.h:104-220 (two outputs per frequency: sin, cos) and encodings/triangle_wave.h:110-220 (one)
+class PeriodicEncoding : public Encoding {
+public:
+	PeriodicEncoding(bool triangle, uint32_t n_frequencies, uint32_t n_dims_to_encode, bool fp32) : Encoding{fp32}, m_triangle{triangle}, m_n_frequencies{n_frequencies}, m_n_dims{n_dims_to_encode} {}
+	uint32_t input_width() const override { return m_n_dims; }
+	uint32_t outputs_per_input() const { return m_n_frequencies * (m_triangle ? 1u : 2u); }
+	uint32_t output_width() const override { return m_n_dims * outputs_per_input(); }
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
+		EncodingContext ctx;
+		if (!out || padded_output_width() == 0 || n == 0) return ctx;
+		if (prepare_input_gradients) ctx.dy_dx = ArenaBuf{stream, (size_t)n * output_width() * sizeof(float)};
+		periodic_forward(stream, m_triangle, m_fp32, n, m_n_dims, m_n_frequencies, x, out, padded_output_width(), ctx.dy_dx.as<float>());
+		return ctx;
+	}
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
+		if (!dL_dx || n == 0) return;
+		CHECK_THROW(ctx.dy_dx); // frequency.h:150-152: needs a forward pass with prepare_input_gradients
+		periodic_backward_input(stream, m_fp32, n, m_n_dims, outputs_per_input(), dL_dy, padded_output_width(), ctx.dy_dx.as<float>(), *dL_dx);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = m_triangle ? "TriangleWave" : "Frequency";
+		j["n_frequencies"] = m_n_frequencies;
+		return j;
+	}
+private:
+	bool m_triangle;
+	uint32_t m_n_frequencies, m_n_dims;
+};
+
+// encodings/spherical_harmonics.h:110-230
+class SphericalHarmonicsEncoding : public Encoding {
+public:
+	SphericalHarmonicsEncoding(uint32_t degree, uint32_t n_dims_to_encode, bool fp32) : Encoding{fp32}, m_degree{degree} {
+		if (n_dims_to_encode != 3) throw std::runtime_error{"Can only encode 3D directions in spherical harmonics."};
+		if (degree == 0) throw std::runtime_error{"Spherical harmonics must have positive degree."};
+		if (degree > 8) throw std::runtime_error{"Spherical harmonics are only implemented up to degree 8."};
+	}
+	uint32_t input_width() const override { return 3; }
+	uint32_t output_width() const override { return m_degree * m_degree; }
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
+		if (out && padded_output_width() > 0) sh_forward(stream, m_fp32, n, m_degree, x, out, padded_output_width());
+		return {};
+	}
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
+		if (!dL_dx) return;
+		sh_backward_input(stream, m_fp32, n, m_degree, x, dL_dy, padded_output_width(), *dL_dx);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "SphericalHarmonics";
+		j["degree"] = m_degree;
+		return j;
+	}
+private:
+	uint32_t m_degree;
+};
+
 inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, const Json& enc, uint32_t alignment, bool fp32) {
 	const std::string name = to_lower(enc.value("otype", "OneBlob"));
 	std::unique_ptr<Encoding> result;
@@ -673,8 +731,14 @@ inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, cons
 		result.reset(new OneBlobEncoding{enc.value("n_bins", 16u), n_dims_to_encode, fp32});
 	} else if (name == "identity") {
 		result.reset(new IdentityEncoding{n_dims_to_encode, enc.value("scale", 1.0f), enc.value("offset", 0.0f), fp32});
+	} else if (name == "frequency") {
+		result.reset(new PeriodicEncoding{false, enc.value("n_frequencies", 12u), n_dims_to_encode, fp32});
+	} else if (name == "trianglewave") {
+		result.reset(new PeriodicEncoding{true, enc.value("n_frequencies", 12u), n_dims_to_encode, fp32});
+	} else if (name == "sphericalharmonics") {
+		result.reset(new SphericalHarmonicsEncoding{enc.value("degree", 4u), n_dims_to_encode, fp32});
 	} else {
-		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity)"};
+		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity, Frequency, TriangleWave, SphericalHarmonics)"};
 	}
 	if (alignment > 0) result->set_alignment(alignment);
 	return result;

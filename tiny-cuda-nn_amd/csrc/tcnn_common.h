@@ -143,6 +143,12 @@ void oneblob_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims,
 void oneblob_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, uint32_t n_bins, MatView x, const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx);
 void identity_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, float scale, float offset, MatView x, void* out, uint32_t out_stride);
 void identity_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, float scale, const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx);
+// Frequency / TriangleWave (k_encodings.hip): dy_dx (optional) float [n][n_dims * outputs_per_input], consumed by the backward pass
+void periodic_forward(hipStream_t stream, bool triangle, bool fp32, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, MatView x, void* out, uint32_t out_stride, float* dy_dx);
+void periodic_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, uint32_t outputs_per_input, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
+// SphericalHarmonics: degree^2 outputs, the padding columns FIRST (spherical_harmonics.h:58-64)
+void sh_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t degree, MatView x, void* out, uint32_t out_stride);
+void sh_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t degree, MatView x, const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx);
 
 // ------------------------------------------------------------------------------------------------------------------
 // Fully fused MLP.  Weight matrices are row-major [fan_out][fan_in] half, contiguous (fully_fused_mlp.cu:656-671).
