@@ -150,7 +150,12 @@ class Loss {
 public:
 	explicit Loss(const json& params) : m_params(params) { // parentheses: braces would select json's initializer-list constructor
 		const std::string otype = params.value("otype", "RelativeL2");
-		if (otype != "L2" && otype != "RelativeL2" && otype != "l2" && otype != "relativel2") throw std::runtime_error{"Invalid loss type: " + otype}; // src/loss.cu:68
+		std::string lower;
+		for (char ch : otype) lower.push_back((char)((ch >= 'A' && ch <= 'Z') ? ch - 'A' + 'a' : ch));
+		static const char* known[] = {"l2", "relativel2", "relativel2luminance", "l1", "relativel1", "mape", "smape", "crossentropy", "variance"}; // src/loss.cu:57-65
+		bool ok = false;
+		for (const char* k : known) ok = ok || lower == k;
+		if (!ok) throw std::runtime_error{"Invalid loss type: " + otype}; // src/loss.cu:85-93
 	}
 	json hyperparams() const { return m_params; }
 

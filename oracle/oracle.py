@@ -25,7 +25,7 @@ ACT = {"none": 0, "relu": 1, "leakyrelu": 2, "exponential": 3, "sine": 4, "sigmo
 GRID_TYPE = {"hash": 0, "dense": 1, "tiled": 2}
 HASH_TYPE = {"prime": 0, "coherentprime": 1, "reversedprime": 2, "rng": 3}
 INTERP = {"nearest": 0, "linear": 1, "smoothstep": 2}
-LOSS = {"l2": 0, "relativel2": 1}
+LOSS = {"l2": 0, "relativel2": 1, "l1": 2, "relativel1": 3, "mape": 4, "smape": 5, "crossentropy": 6, "variance": 7, "relativel2luminance": 8}
 ACC_FP32, ACC_FP16 = 0, 1
 MAX_LEVELS = 128
 LOSS_SCALE = 128.0  # common.h:232 default_loss_scale<__half>

@@ -1111,18 +1111,57 @@ void orc_loss(uint32_t type, uint32_t n, uint32_t stride, uint32_t dims, float l
 		const uint32_t target_idx = inter * dims + intra;
 		const float prediction = h2f(pred[i]);
 		const float pdf = data_pdf ? data_pdf[target_idx] : 1;
-		const float difference = prediction - target[target_idx];
+		const float tgt = target[target_idx];
+		const float difference = prediction - tgt;
 		float value, gradient;
+		bool gradient_has_n_total = false;
 		if (type == ORC_LOSS_RELATIVE_L2) { // relative_l2.h:60-73
 			const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
 			value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
 			gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+		} else if (type == ORC_LOSS_RELATIVE_L2_LUMINANCE) { // relative_l2_luminance.h:60-84
+			const uint16_t* px = pred + (i - intra);
+			float r = h2f(px[0]), g = h2f(px[1]), b = h2f(px[2]);
+			if (dims >= 6) {
+				r += h2f(px[3]);
+				g += h2f(px[4]);
+				b += h2f(px[5]);
+			}
+			const float luminance = (0.299f * r + 0.587f * g + 0.114f * b);
+			const float prediction_sq_plus_epsilon = luminance * luminance + 0.01f;
+			value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
+			gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+		} else if (type == ORC_LOSS_L1) { // l1.h:60-69
+			value = fabsf(difference) / pdf / n_total;
+			gradient = copysignf(1.0f / pdf, difference);
+		} else if (type == ORC_LOSS_RELATIVE_L1) { // relative_l1.h:60-71
+			const float scale = 1.0f / (fabsf(prediction) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+		} else if (type == ORC_LOSS_MAPE) { // mape.h:60-72
+			const float scale = 1.0f / (fabsf(tgt) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+		} else if (type == ORC_LOSS_SMAPE) { // smape.h:60-72
+			const float scale = 1.0f / (0.5f * (fabsf(tgt) + fabsf(prediction)) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+		} else if (type == ORC_LOSS_CROSS_ENTROPY) { // cross_entropy.h:62-71
+			const float factor = -tgt / pdf / n_total;
+			value = factor * logf(prediction);
+			gradient = factor / prediction;
+			gradient_has_n_total = true;
+		} else if (type == ORC_LOSS_VARIANCE) { // variance_is.h:62-71
+			const float factor = tgt * tgt / pdf / n_total;
+			value = factor / prediction - factor / pdf;
+			gradient = -factor / (prediction * prediction);
+			gradient_has_n_total = true;
 		} else { // l2.h:60-72
 			value = difference * difference / pdf / n_total;
 			gradient = 2 * difference / pdf;
 		}
 		if (values) values[i] = value;
-		if (grads) grads[i] = f2h(loss_scale * gradient / n_total);
+		if (grads) grads[i] = gradient_has_n_total ? f2h(loss_scale * gradient) : f2h(loss_scale * gradient / n_total);
 	}
 }
 

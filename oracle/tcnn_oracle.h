@@ -29,7 +29,8 @@ enum { ORC_ACT_NONE = 0, ORC_ACT_RELU = 1, ORC_ACT_LEAKY_RELU = 2, ORC_ACT_EXPON
 enum { ORC_GRID_HASH = 0, ORC_GRID_DENSE = 1, ORC_GRID_TILED = 2 };
 enum { ORC_HASH_PRIME = 0, ORC_HASH_COHERENT_PRIME = 1, ORC_HASH_REVERSED_PRIME = 2, ORC_HASH_RNG = 3 };
 enum { ORC_INTERP_NEAREST = 0, ORC_INTERP_LINEAR = 1, ORC_INTERP_SMOOTHSTEP = 2 };
-enum { ORC_LOSS_L2 = 0, ORC_LOSS_RELATIVE_L2 = 1 };
+enum { ORC_LOSS_L2 = 0, ORC_LOSS_RELATIVE_L2 = 1, ORC_LOSS_L1 = 2, ORC_LOSS_RELATIVE_L1 = 3, ORC_LOSS_MAPE = 4, ORC_LOSS_SMAPE = 5, ORC_LOSS_CROSS_ENTROPY = 6,
+       ORC_LOSS_VARIANCE = 7, ORC_LOSS_RELATIVE_L2_LUMINANCE = 8 }; /* src/loss.cu:57-65 */
 enum { ORC_ACC_FP32 = 0, ORC_ACC_FP16 = 1 };
 
 #define ORC_MAX_LEVELS 128

@@ -118,15 +118,68 @@ __global__ void __launch_bounds__(256) k_loss(
 	const uint32_t n_total = n_elements / stride * dims;
 	const float prediction = (float)predictions[i];
 	const float pdf = data_pdf ? data_pdf[target_idx] : 1;
-	const float difference = prediction - targets[target_idx];
+	const float target = targets[target_idx];
+	const float difference = prediction - target;
 	float value, gradient;
-	if (type == (uint32_t)LossType::RelativeL2) {
-		const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-		value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
-		gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
-	} else {
-		value = difference * difference / pdf / n_total;
-		gradient = 2 * difference / pdf;
+	switch ((LossType)type) {
+		case LossType::RelativeL2: { // relative_l2.h:60-73
+			const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
+			value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
+			gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+			break;
+		}
+		case LossType::RelativeL2Luminance: { // relative_l2_luminance.h:40-85: the divisor is the squared luminance of the pixel
+			const half_t* px = predictions + (i - intra);
+			float r = (float)px[0], g = (float)px[1], b = (float)px[2];
+			if (dims >= 6) {
+				r += (float)px[3];
+				g += (float)px[4];
+				b += (float)px[5];
+			}
+			const float luminance = (0.299f * r + 0.587f * g + 0.114f * b);
+			const float prediction_sq_plus_epsilon = luminance * luminance + 0.01f;
+			value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
+			gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+			break;
+		}
+		case LossType::L1: // l1.h:40-70
+			value = fabsf(difference) / pdf / n_total;
+			gradient = copysignf(1.0f / pdf, difference);
+			break;
+		case LossType::RelativeL1: { // relative_l1.h:40-72
+			const float scale = 1.0f / (fabsf(prediction) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+			break;
+		}
+		case LossType::Mape: { // mape.h:40-73
+			const float scale = 1.0f / (fabsf(target) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+			break;
+		}
+		case LossType::Smape: { // smape.h:40-73
+			const float scale = 1.0f / (0.5f * (fabsf(target) + fabsf(prediction)) + 1e-2f) / pdf;
+			value = fabsf(difference) * scale / n_total;
+			gradient = copysignf(scale, difference);
+			break;
+		}
+		case LossType::CrossEntropy: { // cross_entropy.h:40-72: the gradient already carries 1 / n_total
+			const float factor = -target / pdf / n_total;
+			values[i] = factor * logf(prediction);
+			gradients[i] = (half_t)(loss_scale * (factor / prediction));
+			return;
+		}
+		case LossType::Variance: { // variance_is.h:40-72
+			const float factor = target * target / pdf / n_total;
+			values[i] = factor / prediction - factor / pdf;
+			gradients[i] = (half_t)(loss_scale * (-factor / (prediction * prediction)));
+			return;
+		}
+		default: // L2, l2.h:60-72
+			value = difference * difference / pdf / n_total;
+			gradient = 2 * difference / pdf;
+			break;
 	}
 	values[i] = value;
 	gradients[i] = (half_t)(loss_scale * gradient / n_total);

@@ -1219,11 +1219,18 @@ private:
 // ------------------------------------------------------------------------------------------------------------------
 inline LossType create_loss(const Json& loss) {
 	const std::string otype = loss.value("otype", "RelativeL2");
-	if (equals_case_insensitive(otype, "L2")) return LossType::L2;
-	if (equals_case_insensitive(otype, "RelativeL2")) return LossType::RelativeL2;
-	throw std::runtime_error{"Invalid loss type: " + otype + " (this build provides L2 and RelativeL2)"};
+	static const std::pair<const char*, LossType> table[] = { // src/loss.cu:57-65
+		{"L2", LossType::L2}, {"RelativeL2", LossType::RelativeL2}, {"RelativeL2Luminance", LossType::RelativeL2Luminance}, {"L1", LossType::L1},
+		{"RelativeL1", LossType::RelativeL1}, {"Mape", LossType::Mape}, {"Smape", LossType::Smape}, {"CrossEntropy", LossType::CrossEntropy}, {"Variance", LossType::Variance}};
+	for (const auto& kv : table) if (equals_case_insensitive(otype, kv.first)) return kv.second;
+	throw std::runtime_error{"Invalid loss type: " + otype};
 }
-inline const char* to_string(LossType t) { return t == LossType::L2 ? "L2" : "RelativeL2"; }
+inline const char* to_string(LossType t) {
+	static const char* names[] = {"L2", "RelativeL2", "L1", "RelativeL1", "Mape", "Smape", "CrossEntropy", "Variance", "RelativeL2Luminance"};
+	return names[(uint32_t)t];
+}
+// the fused training kernel evaluates these two inside its loss stage; the others go forward -> k_loss -> backward
+inline bool loss_in_fused_kernel(LossType t) { return t == LossType::L2 || t == LossType::RelativeL2; }
 
 class AdamOptimizer {
 public:
@@ -1441,7 +1448,7 @@ public:
 	                                            MatViewMut* dL_dinput, bool use_inference_params, GradientMode mode, const void* external_dL_dy) { // trainer.h:163-190
 		const float loss_scale = LOSS_SCALE_FP16;
 		std::unique_ptr<TrainContext> ctx;
-		if (m_model->fused_step_supported(n)) {
+		if (m_model->fused_step_supported(n) && (external_dL_dy || loss_in_fused_kernel(m_loss))) {
 			// MI355X path: encoding -> ONE fused MLP kernel (forward + loss + backward + weight gradients) -> grid scatter
 			ctx = std::make_unique<TrainContext>();
 			ctx->n = n;

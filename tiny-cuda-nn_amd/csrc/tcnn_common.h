@@ -18,7 +18,7 @@ enum class Activation : uint32_t { None = 0, ReLU = 1, LeakyReLU = 2, Exponentia
 enum class GridType : uint32_t { Hash = 0, Dense = 1, Tiled = 2 };
 enum class HashType : uint32_t { Prime = 0, CoherentPrime = 1, ReversedPrime = 2, Rng = 3 };
 enum class InterpolationType : uint32_t { Nearest = 0, Linear = 1, Smoothstep = 2 };
-enum class LossType : uint32_t { L2 = 0, RelativeL2 = 1 };
+enum class LossType : uint32_t { L2 = 0, RelativeL2 = 1, L1 = 2, RelativeL1 = 3, Mape = 4, Smape = 5, CrossEntropy = 6, Variance = 7, RelativeL2Luminance = 8 }; // src/loss.cu:57-65
 enum class Precision : uint32_t { Fp32 = 0, Fp16 = 1 };      // cpp_api.h:69-72
 enum class GradientMode : uint32_t { Ignore = 0, Overwrite = 1, Accumulate = 2 }; // common.h GradientMode
 
