@@ -673,6 +673,143 @@ class Adam:
         lib().orc_adam_step(C.byref(self.a), self.n, self.n_matrix, loss_scale, self.current_step, _p(w_fp), _p(w_half), _p(g_half),
                             _p(self.m1), _p(self.m2), _p(self.steps))
 
+    # the small interface the wrapping optimizers use (optimizer.h:44-95)
+    def learning_rate(self):
+        return float(self.a.learning_rate)
+
+    def set_learning_rate(self, v):
+        self.a.learning_rate = float(np.float32(v))
+
+    def step_count(self):
+        return self.current_step
+
+    def custom_weights(self):
+        return None
+
+
+class Sgd:
+    """optimizers/sgd.h:44-150, float32 arithmetic in the kernel's order"""
+
+    def __init__(self, cfg):
+        self.lr = np.float32(_ci(cfg, "learning_rate", 1e-3))
+        self.l2_reg = np.float32(_ci(cfg, "l2_reg", 1e-8))
+        self.current_step = 0
+
+    def allocate(self, n, layer_sizes):
+        self.n = n
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        self.current_step += 1
+        gradient = half_to_f32(g_half) / np.float32(loss_scale)
+        gradient = gradient + self.l2_reg * w_fp
+        w_fp[:] = w_fp - self.lr * gradient
+        w_half[:] = half_bits(w_fp)
+
+    def learning_rate(self):
+        return float(self.lr)
+
+    def set_learning_rate(self, v):
+        self.lr = np.float32(v)
+
+    def step_count(self):
+        return self.current_step
+
+    def custom_weights(self):
+        return None
+
+
+class ExponentialDecay:
+    """optimizers/exponential_decay.h:45-160"""
+
+    def __init__(self, cfg):
+        self.nested = create_optimizer(_ci(cfg, "nested", {}))
+        self.decay_base = np.float32(_ci(cfg, "decay_base", 0.1))
+        self.decay_interval = int(_ci(cfg, "decay_interval", 10000))
+        self.decay_start = int(_ci(cfg, "decay_start", 10000))
+        self.decay_end = int(_ci(cfg, "decay_end", 10000000))
+        self.factor = np.float32(1.0)
+        self.base_lr = np.float32(self.nested.learning_rate())
+
+    def allocate(self, n, layer_sizes):
+        self.nested.allocate(n, layer_sizes)
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        s = self.step_count()
+        if s == 0:
+            self.factor = np.float32(1.0)
+        if s >= self.decay_start and (s - self.decay_start) % self.decay_interval == 0 and s <= self.decay_end:
+            self.factor = np.float32(self.factor * self.decay_base)
+        self.nested.set_learning_rate(np.float32(self.base_lr * self.factor))
+        self.nested.step(loss_scale, w_fp, w_half, g_half)
+
+    def learning_rate(self):
+        return float(np.float32(self.base_lr * self.factor))
+
+    def set_learning_rate(self, v):
+        self.base_lr = np.float32(np.float32(v) / self.factor)
+        self.nested.set_learning_rate(np.float32(self.base_lr * self.factor))
+
+    def step_count(self):
+        return self.nested.step_count()
+
+    def custom_weights(self):
+        return self.nested.custom_weights()
+
+
+class Ema:
+    """optimizers/ema.h:44-230 (half_precision and full_precision forms)"""
+
+    def __init__(self, cfg):
+        self.nested = create_optimizer(_ci(cfg, "nested", {}))
+        self.decay = np.float32(_ci(cfg, "decay", 0.99))
+        self.full_precision = bool(_ci(cfg, "full_precision", False))
+
+    def allocate(self, n, layer_sizes):
+        self.nested.allocate(n, layer_sizes)
+        self.weights_ema = np.zeros(n, dtype=np.uint16)
+        self.tmp = np.zeros(n, dtype=np.float32) if self.full_precision else None
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        self.nested.step(loss_scale, w_fp, w_half, g_half)
+        s = self.nested.step_count()
+        # ema.h:103-104: float(std::pow(float, uint32_t)) -- evaluated in double, rounded to float
+        debias_old = np.float32(1) - np.float32(float(self.decay) ** (s - 1))
+        debias_new = np.float32(1.0) / (np.float32(1) - np.float32(float(self.decay) ** s))
+        weights = self.nested.custom_weights()
+        weights = w_half if weights is None else weights
+        previous = self.tmp if self.full_precision else half_to_f32(self.weights_ema)
+        filtered = (previous * self.decay * debias_old + half_to_f32(weights) * (np.float32(1) - self.decay)) * debias_new
+        filtered = filtered.astype(np.float32)
+        if self.full_precision:
+            self.tmp[:] = filtered
+        self.weights_ema[:] = half_bits(filtered)
+
+    def learning_rate(self):
+        return self.nested.learning_rate()
+
+    def set_learning_rate(self, v):
+        self.nested.set_learning_rate(v)
+
+    def step_count(self):
+        return self.nested.step_count()
+
+    def custom_weights(self):
+        return self.weights_ema
+
+
+def create_optimizer(cfg):
+    """src/optimizer.cu:50-82 (the subset this build provides)"""
+    name = _norm(_ci(cfg, "otype", "Adam"))
+    if name == "adam":
+        return Adam(cfg)
+    if name == "sgd":
+        return Sgd(cfg)
+    if name == "exponentialdecay":
+        return ExponentialDecay(cfg)
+    if name == "ema":
+        return Ema(cfg)
+    raise RuntimeError(f"Invalid optimizer type: {cfg.get('otype')}")
+
 
 class Trainer:
     """trainer.h:48-363 + config.h:46-63 (create_from_config)"""
@@ -685,9 +822,7 @@ class Trainer:
         self.loss_type = _ci(loss_cfg, "otype", "RelativeL2")
         if _norm(self.loss_type) not in LOSS:
             raise RuntimeError(f"Invalid loss type: {self.loss_type}")
-        if _norm(_ci(opt_cfg, "otype", "Adam")) != "adam":
-            raise RuntimeError(f"Invalid optimizer type: {opt_cfg.get('otype')}")
-        self.optimizer = Adam(opt_cfg)
+        self.optimizer = create_optimizer(opt_cfg)
         self.model = NetworkWithInputEncoding(n_in, n_out, _ci(config, "encoding", {}), _ci(config, "network", {}), acc_mode)
         self.rng = Pcg32.trainer(seed)
         self.initialize_params()
@@ -712,5 +847,10 @@ class Trainer:
         return {"output": out, "L": values, "dL_doutput": dL_dout, "dL_dinput": dL_dx, "dL_dnetwork_input": dnet_in, "ctx": ctx,
                 "loss": float(lib().orc_reduce_sum(values.size, _p(values)))}
 
+    def params_inference(self):
+        """trainer.h:329-333: the optimizer's own weights (EMA) if it keeps any"""
+        custom = self.optimizer.custom_weights()
+        return self.params if custom is None else custom
+
     def inference(self, x):
-        return self.model.inference(np.ascontiguousarray(x, dtype=np.float32), self.params)
+        return self.model.inference(np.ascontiguousarray(x, dtype=np.float32), self.params_inference())

@@ -1,0 +1,124 @@
+"""Optimizers beside Adam (src/optimizer.cu:50-82): SGD (optimizers/sgd.h), ExponentialDecay
+(exponential_decay.h) and Ema (ema.h) -- the nesting instant-ngp style configs use: Ema -> ExponentialDecay -> Adam.
+Identical gradients are copied into the trainer so that only the optimizer is compared with the oracle's restatement."""
+import numpy as np
+import pytest
+
+NESTED = {
+    "otype": "Ema", "decay": 0.9,
+    "nested": {"otype": "ExponentialDecay", "decay_start": 2, "decay_interval": 1, "decay_base": 0.5,
+               "nested": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6}},
+}
+
+
+def test_oracle_optimizer_factory_and_schedule(oracle):
+    opt = oracle.create_optimizer(NESTED)
+    assert type(opt).__name__ == "Ema" and type(opt.nested).__name__ == "ExponentialDecay" and type(opt.nested.nested).__name__ == "Adam"
+    n = 64
+    opt.allocate(n, [(8, 8)])
+    w_fp = np.linspace(-1, 1, n).astype(np.float32)
+    w_h = oracle.half_bits(w_fp)
+    g = oracle.half_bits(np.full(n, 128.0, dtype=np.float32))  # gradient 1 after unscaling
+    rates = []
+    for _ in range(5):
+        opt.step(128.0, w_fp, w_h, g)
+        rates.append(opt.learning_rate())
+    # exponential_decay.h:60-68: the factor is applied when step() >= decay_start, BEFORE the nested step of that call
+    assert np.allclose(rates, [1e-2, 1e-2, 5e-3, 2.5e-3, 1.25e-3], rtol=1e-6)
+    assert opt.step_count() == 5 and opt.custom_weights() is opt.weights_ema
+    # debiased EMA of a weight sequence: within the span of the weights seen so far, and moving
+    ema = oracle.half_to_f32(opt.weights_ema)
+    assert np.all(np.abs(ema - oracle.half_to_f32(w_h)) < 0.1) and not np.array_equal(opt.weights_ema, w_h)
+    with pytest.raises(RuntimeError, match="Invalid optimizer type"):
+        oracle.create_optimizer({"otype": "Shampoo"})
+
+
+def _drive(tcnn, oracle, opt_cfg, steps=4):
+    """Same gradients into both trainers' optimizers."""
+    from tinycudann import _C
+
+    from test_gpu_parity import CONFIG_C3B, _t
+
+    cfg = {**CONFIG_C3B, "optimizer": opt_cfg}
+    ref = oracle.Trainer(2, 3, cfg, seed=1337)
+    tr = tcnn.Trainer(2, 3, cfg, seed=1337)
+    n = ref.model.n_params
+    n_net = ref.model.network.n_params
+    p0 = ref.params_fp.copy()
+    for step in range(steps):
+        g = oracle.Pcg32(11 + step).uniform_strided(n, -4.0, 4.0)
+        g[n_net + step::3] = 0.0
+        g_h = oracle.half_bits(g)
+        ref.grads[:] = g_h
+        ref.optimizer.step(128.0, ref.params_fp, ref.params, ref.grads)
+        gt = _t(g_h.view(np.float16))
+        _C.memcpy_dtod(_C.lib.tcnn_trainer_param_gradients(tr._h), gt.data_ptr(), n * 2)
+        tr.optimizer_step()
+    return ref, tr, p0
+
+
+@pytest.mark.gpu
+def test_sgd_matches_oracle_bitwise(tcnn, oracle):
+    ref, tr, _ = _drive(tcnn, oracle, {"otype": "SGD", "learning_rate": 1e-2, "l2_reg": 1e-4})
+    assert np.array_equal(tr.params_full_precision().cpu().numpy().view(np.uint32), ref.params_fp.view(np.uint32))
+    assert np.array_equal(tr.params().cpu().numpy().view(np.uint16), ref.params)
+    assert tr.optimizer_step_count() == 4 and tr.hyperparams()["optimizer"]["otype"] == "SGD"
+
+
+@pytest.mark.gpu
+def test_nested_ema_exponential_decay_adam(tcnn, oracle):
+    from test_gpu_parity import _bits, _f32
+
+    ref, tr, p0 = _drive(tcnn, oracle, NESTED, steps=5)
+    hp = tr.hyperparams()["optimizer"]
+    assert hp["otype"] == "EMA" and hp["nested"]["otype"] == "ExponentialDecay" and hp["nested"]["nested"]["otype"] == "Adam"
+    # Adam under the decayed learning rates (adam parity bar: 1e-5 of the update size)
+    got = tr.params_full_precision().cpu().numpy()
+    upd = np.abs(ref.params_fp - p0)
+    assert np.max(np.abs(got - ref.params_fp)) <= 1e-5 * np.max(upd) + 1e-9
+    assert tr.optimizer_step_count() == 5
+    # the EMA weights are the inference parameters (trainer.h:329-333); half values may differ where Adam's last bit did
+    ema = _bits(tr.params_inference())
+    assert np.mean(ema == ref.optimizer.weights_ema) > 0.999
+    assert np.max(np.abs(_f32(ema) - _f32(ref.optimizer.weights_ema))) <= 2.0 ** -9 * max(1.0, float(np.max(np.abs(_f32(ema)))))
+    assert not np.array_equal(ema, _bits(tr.params()))
+
+
+@pytest.mark.gpu
+def test_inference_and_snapshot_use_ema_weights(tcnn, oracle):
+    import torch
+
+    msgpack = pytest.importorskip("msgpack")
+    from test_gpu_parity import CONFIG_C3B, _bits
+
+    cfg = {**CONFIG_C3B, "optimizer": NESTED}
+    tr = tcnn.Trainer(2, 3, cfg, seed=1337)
+    for s in range(5):
+        x, t = oracle.synthetic_batch(1024, 2, 3, seed=100 + s)
+        tr.training_step(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda())
+    x, _ = oracle.synthetic_batch(1024, 2, 3, seed=7)
+    xt = torch.from_numpy(x).cuda()
+    y_ema = tr.inference(xt)
+    # the same network evaluated with the training weights answers differently; with the EMA weights set as both, identically
+    other = tcnn.Trainer(2, 3, {**CONFIG_C3B}, seed=1)
+    other.set_params(tr.params_inference())
+    assert torch.equal(other.inference(xt), y_ema)
+    other.set_params(tr.params())
+    assert not torch.equal(other.inference(xt), y_ema)
+    snap = msgpack.unpackb(tr.serialize(serialize_optimizer=True), raw=False)
+    assert np.array_equal(np.frombuffer(snap["params_binary"], dtype=np.uint16), _bits(tr.params_inference()))  # trainer.h:281
+    opt = snap["optimizer"]
+    assert set(opt) == {"nested", "weights_ema_binary"} and set(opt["nested"]) == {"nested", "learning_rate", "learning_rate_factor"}
+    assert opt["nested"]["nested"]["current_step"] == 5 and abs(opt["nested"]["learning_rate_factor"] - 0.5 ** 3) < 1e-7
+    # restore into a fresh trainer: same inference, same next step
+    b = tcnn.Trainer(2, 3, cfg, seed=3)
+    b.deserialize(tr.serialize(serialize_optimizer=True))
+    assert torch.equal(b.inference(xt), y_ema) and b.optimizer_step_count() == 5
+
+
+@pytest.mark.gpu
+def test_unknown_optimizer_is_reported(tcnn):
+    from test_gpu_parity import CONFIG_C3B
+
+    with pytest.raises(RuntimeError, match="Invalid optimizer type: Shampoo"):
+        tcnn.Trainer(2, 3, {**CONFIG_C3B, "optimizer": {"otype": "Shampoo"}})

@@ -511,6 +511,42 @@ void adam_fill_debias_table(hipStream_t stream, float beta1, float beta2, uint32
 }
 
 namespace {
+// optimizers/sgd.h:44-72
+__global__ void __launch_bounds__(256) k_sgd(const size_t n, const float loss_scale, const float learning_rate, const float l2_reg, float* __restrict__ w_fp, half_t* __restrict__ w,
+                                             const half_t* __restrict__ g) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float weight_fp = w_fp[i];
+	float gradient = (float)g[i] / loss_scale;
+	gradient += l2_reg * weight_fp;
+	const float new_weight = weight_fp - learning_rate * gradient;
+	w_fp[i] = new_weight;
+	w[i] = (half_t)new_weight;
+}
+
+// optimizers/ema.h:44-78: tmp != nullptr keeps the average in fp32 (full_precision), else it lives in the half weights themselves
+__global__ void __launch_bounds__(256) k_ema(const size_t n, const float decay, const float debias_old, const float debias_new, const half_t* __restrict__ weights, half_t* __restrict__ weights_ema,
+                                             float* __restrict__ tmp) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float previous = tmp ? tmp[i] : (float)weights_ema[i];
+	const float filtered = (previous * decay * debias_old + (float)weights[i] * (1 - decay)) * debias_new;
+	if (tmp) tmp[i] = filtered;
+	weights_ema[i] = (half_t)filtered;
+}
+} // namespace
+
+void sgd_step(hipStream_t stream, size_t n, float loss_scale, float learning_rate, float l2_reg, float* weights_full_precision, void* weights, const void* gradients) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_sgd, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, loss_scale, learning_rate, l2_reg, weights_full_precision, (half_t*)weights, (const half_t*)gradients);
+}
+
+void ema_step(hipStream_t stream, size_t n, float decay, float debias_old, float debias_new, const void* weights, void* weights_ema, float* tmp) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_ema, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, decay, debias_old, debias_new, (const half_t*)weights, (half_t*)weights_ema, tmp);
+}
+
+namespace {
 void pcg32_advance_host(uint64_t* st, uint64_t delta) {
 	const uint64_t MULT = 0x5851f42d4c957f2dULL;
 	uint64_t cur_mult = MULT, cur_plus = st[1], acc_mult = 1u, acc_plus = 0u;

@@ -1232,15 +1232,50 @@ inline const char* to_string(LossType t) {
 // the fused training kernel evaluates these two inside its loss stage; the others go forward -> k_loss -> backward
 inline bool loss_in_fused_kernel(LossType t) { return t == LossType::L2 || t == LossType::RelativeL2; }
 
-class AdamOptimizer {
-public:
-	explicit AdamOptimizer(const Json& params) {
-		const std::string otype = params.value("otype", "Adam");
-		if (!equals_case_insensitive(otype, "Adam")) throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam)"};
-		update_hyperparams(params);
+// snapshot helpers (gpu_memory_json.h:36-71): device memory <-> json binary value
+inline Json device_to_binary(const void* device, size_t n_bytes) {
+	std::vector<uint8_t> host(n_bytes);
+	if (n_bytes) HIP_CHECK_THROW(hipMemcpy(host.data(), device, n_bytes, hipMemcpyDeviceToHost));
+	return Json::binary(std::move(host));
+}
+// binary value, or nlohmann's text form of one: {"bytes": [...], "subtype": null} (gpu_memory_json.h:55-67)
+inline std::vector<uint8_t> binary_of(const Json& j) {
+	if (j.is_binary()) return j.get_binary();
+	if (j.is_object()) {
+		const Json& arr = j["bytes"];
+		std::vector<uint8_t> bytes(arr.size());
+		for (size_t i = 0; i < bytes.size(); ++i) bytes[i] = (uint8_t)arr.at(i).as_double();
+		return bytes;
 	}
+	throw std::runtime_error{"Invalid json type: must be either binary or object"};
+}
 
-	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) { // adam.h:128-148
+// optimizer.h:44-95
+class Optimizer {
+public:
+	virtual ~Optimizer() {}
+	virtual void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) = 0;
+	virtual void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) = 0;
+	virtual float learning_rate() const = 0;
+	virtual void set_learning_rate(float val) = 0;
+	virtual uint32_t step_count() const = 0;
+	virtual size_t n_weights() const = 0;
+	virtual void* custom_weights() const { return nullptr; } // half weights the trainer uses for inference instead of its own (EMA)
+	virtual void update_hyperparams(const Json& params) = 0;
+	virtual Json hyperparams() const = 0;
+	virtual Json serialize() const = 0;
+	virtual void deserialize(const Json& data, size_t n_weights) = 0;
+};
+inline std::unique_ptr<Optimizer> create_optimizer(const Json& params);
+
+class AdamOptimizer : public Optimizer {
+public:
+	explicit AdamOptimizer(const Json& params) { update_hyperparams(params); }
+	float learning_rate() const override { return m_h.learning_rate; }
+	void set_learning_rate(float val) override { m_h.learning_rate = val; }
+	size_t n_weights() const override { return m_n_weights; }
+
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) override { // adam.h:128-148
 		m_n_weights = n_weights;
 		if (n_weights * sizeof(float) > m_first_moments.bytes()) {
 			m_first_moments.resize(n_weights * sizeof(float));
@@ -1255,12 +1290,8 @@ public:
 	}
 
 	// adam.h:278-299
-	Json serialize() const {
-		auto blob = [](const DeviceBuf& buf, size_t n_bytes) {
-			std::vector<uint8_t> host(n_bytes);
-			if (n_bytes) HIP_CHECK_THROW(hipMemcpy(host.data(), buf.data(), n_bytes, hipMemcpyDeviceToHost));
-			return Json::binary(std::move(host));
-		};
+	Json serialize() const override {
+		auto blob = [](const DeviceBuf& buf, size_t n_bytes) { return device_to_binary(buf.data(), n_bytes); };
 		Json data = Json::object();
 		data["current_step"] = Json((uint32_t)m_current_step);
 		data["base_learning_rate"] = Json((float)m_h.learning_rate);
@@ -1269,7 +1300,7 @@ public:
 		data["param_steps_binary"] = blob(m_param_steps, m_n_weights * sizeof(uint32_t));
 		return data;
 	}
-	void deserialize(const Json& data, size_t n_weights, std::vector<uint8_t> (*binary_of)(const Json&)) {
+	void deserialize(const Json& data, size_t n_weights) override {
 		auto load = [&](DeviceBuf& buf, const std::vector<uint8_t>& bytes, size_t elem) {
 			if (bytes.size() != n_weights * elem) throw std::runtime_error{"Adam: snapshot state has the wrong size."};
 			buf.resize(bytes.size());
@@ -1288,7 +1319,7 @@ public:
 		m_h.learning_rate = (float)data["base_learning_rate"].as_double();
 	}
 
-	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) { // adam.h:150-188
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override { // adam.h:150-188
 		++m_current_step;
 		ensure_debias_table(stream);
 		adam_step(stream, m_h, m_n_weights, m_n_matrix, loss_scale, m_current_step, weights_full_precision, weights, gradients,
@@ -1312,7 +1343,7 @@ public:
 		m_debias_beta2 = m_h.beta2;
 	}
 
-	void update_hyperparams(const Json& p) { // adam.h:210-258
+	void update_hyperparams(const Json& p) override { // adam.h:210-258
 		if (!p.is_object()) return;
 		if (p.contains("beta1")) m_h.beta1 = (float)p["beta1"].as_double();
 		if (p.contains("beta2")) m_h.beta2 = (float)p["beta2"].as_double();
@@ -1328,7 +1359,7 @@ public:
 		if (p.contains("optimize_non_matrix_params")) m_h.optimize_non_matrix_params = p["optimize_non_matrix_params"].as_bool();
 	}
 
-	Json hyperparams() const { // adam.h:260-276
+	Json hyperparams() const override { // adam.h:260-276
 		Json j = Json::object();
 		j["otype"] = "Adam";
 		j["beta1"] = m_h.beta1;
@@ -1346,7 +1377,7 @@ public:
 		return j;
 	}
 
-	uint32_t step_count() const { return m_current_step; }
+	uint32_t step_count() const override { return m_current_step; }
 	const AdamHyper& hyper() const { return m_h; }
 	float* first_moments() const { return m_first_moments.as<float>(); }
 	float* second_moments() const { return m_second_moments.as<float>(); }
@@ -1361,6 +1392,188 @@ private:
 	float m_debias_beta1 = -1.0f, m_debias_beta2 = -1.0f;
 	uint32_t m_current_step = 0;
 };
+
+// optimizers/sgd.h:44-150
+class SgdOptimizer : public Optimizer {
+public:
+	explicit SgdOptimizer(const Json& params) { update_hyperparams(params); }
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>&) override { m_n_weights = n_weights; }
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override {
+		++m_current_step;
+		sgd_step(stream, m_n_weights, loss_scale, m_learning_rate, m_l2_reg, weights_full_precision, weights, gradients);
+	}
+	float learning_rate() const override { return m_learning_rate; }
+	void set_learning_rate(float val) override { m_learning_rate = val; }
+	uint32_t step_count() const override { return m_current_step; }
+	size_t n_weights() const override { return m_n_weights; }
+	void update_hyperparams(const Json& p) override {
+		if (!p.is_object()) return;
+		if (p.contains("learning_rate")) m_learning_rate = (float)p["learning_rate"].as_double();
+		if (p.contains("l2_reg")) m_l2_reg = (float)p["l2_reg"].as_double();
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "SGD";
+		j["learning_rate"] = m_learning_rate;
+		j["l2_reg"] = m_l2_reg;
+		return j;
+	}
+	Json serialize() const override {
+		Json data = Json::object();
+		data["current_step"] = Json((uint32_t)m_current_step);
+		data["learning_rate"] = Json(m_learning_rate);
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights) override {
+		m_n_weights = n_weights;
+		m_current_step = (uint32_t)data["current_step"].as_double();
+		m_learning_rate = (float)data["learning_rate"].as_double();
+	}
+private:
+	size_t m_n_weights = 0;
+	uint32_t m_current_step = 0;
+	float m_learning_rate = 1e-3f, m_l2_reg = 1e-8f; // sgd.h:151-152
+};
+
+// optimizers/exponential_decay.h:45-160: scales the nested optimizer's learning rate by decay_base every decay_interval steps
+class ExponentialDecayOptimizer : public Optimizer {
+public:
+	explicit ExponentialDecayOptimizer(const Json& params) {
+		m_nested = create_optimizer(params.value("nested", Json::object()));
+		update_hyperparams(params);
+		m_learning_rate_factor = 1.0f;
+		m_base_learning_rate = m_nested->learning_rate();
+	}
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) override { m_nested->allocate(n_weights, layer_sizes); }
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override { // :60-71
+		if (step_count() == 0) m_learning_rate_factor = 1.0f;
+		if (step_count() >= m_decay_start && (step_count() - m_decay_start) % m_decay_interval == 0 && step_count() <= m_decay_end) m_learning_rate_factor *= m_decay_base;
+		m_nested->set_learning_rate(m_base_learning_rate * m_learning_rate_factor);
+		m_nested->step(stream, loss_scale, weights_full_precision, weights, gradients);
+	}
+	float learning_rate() const override { return m_base_learning_rate * m_learning_rate_factor; }
+	void set_learning_rate(float val) override {
+		m_base_learning_rate = val / m_learning_rate_factor;
+		m_nested->set_learning_rate(m_base_learning_rate * m_learning_rate_factor);
+	}
+	uint32_t step_count() const override { return m_nested->step_count(); }
+	size_t n_weights() const override { return m_nested->n_weights(); }
+	void* custom_weights() const override { return m_nested->custom_weights(); }
+	void update_hyperparams(const Json& p) override {
+		if (!p.is_object()) return;
+		if (p.contains("decay_base")) m_decay_base = (float)p["decay_base"].as_double();
+		if (p.contains("decay_interval")) m_decay_interval = std::max(1u, (uint32_t)p["decay_interval"].as_double());
+		if (p.contains("decay_start")) m_decay_start = (uint32_t)p["decay_start"].as_double();
+		if (p.contains("decay_end")) m_decay_end = (uint32_t)p["decay_end"].as_double();
+		if (p.contains("nested")) m_nested->update_hyperparams(p["nested"]);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "ExponentialDecay";
+		j["nested"] = m_nested->hyperparams();
+		j["decay_base"] = m_decay_base;
+		j["decay_interval"] = m_decay_interval;
+		j["decay_start"] = m_decay_start;
+		j["decay_end"] = m_decay_end;
+		return j;
+	}
+	Json serialize() const override {
+		Json data = Json::object();
+		data["nested"] = m_nested->serialize();
+		data["learning_rate"] = Json(m_base_learning_rate);
+		data["learning_rate_factor"] = Json(m_learning_rate_factor);
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights) override {
+		m_base_learning_rate = (float)data["learning_rate"].as_double();
+		m_learning_rate_factor = data.value("learning_rate_factor", 1.0f);
+		m_nested->deserialize(data["nested"], n_weights);
+	}
+private:
+	std::unique_ptr<Optimizer> m_nested;
+	float m_learning_rate_factor = 1.0f, m_base_learning_rate = 0.0f;
+	float m_decay_base = 0.1f;
+	uint32_t m_decay_interval = 10000, m_decay_start = 10000, m_decay_end = 10000000;
+};
+
+// optimizers/ema.h:44-230: debiased exponential moving average of the nested optimizer's weights, used for inference
+class EmaOptimizer : public Optimizer {
+public:
+	explicit EmaOptimizer(const Json& params) {
+		m_nested = create_optimizer(params.value("nested", Json::object()));
+		update_hyperparams(params);
+	}
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) override {
+		m_nested->allocate(n_weights, layer_sizes);
+		if (n_weights * 2 <= m_weights_ema.bytes()) return;
+		m_weights_ema.resize(n_weights * 2);
+		m_weights_ema.memset(0);
+		if (m_full_precision) {
+			m_tmp.resize(n_weights * sizeof(float));
+			m_tmp.memset(0);
+		}
+	}
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override { // :98-132
+		m_nested->step(stream, loss_scale, weights_full_precision, weights, gradients);
+		const uint32_t current_step = m_nested->step_count();
+		const float ema_debias_old = 1 - (float)std::pow(m_ema_decay, current_step - 1);
+		const float ema_debias_new = 1.0f / (1 - (float)std::pow(m_ema_decay, current_step));
+		if (void* nested_custom = m_nested->custom_weights()) weights = nested_custom;
+		ema_step(stream, n_weights(), m_ema_decay, ema_debias_old, ema_debias_new, weights, m_weights_ema.data(), m_full_precision ? m_tmp.as<float>() : nullptr);
+	}
+	float learning_rate() const override { return m_nested->learning_rate(); }
+	void set_learning_rate(float val) override { m_nested->set_learning_rate(val); }
+	uint32_t step_count() const override { return m_nested->step_count(); }
+	size_t n_weights() const override { return m_nested->n_weights(); }
+	void* custom_weights() const override { return m_weights_ema.data(); }
+	void update_hyperparams(const Json& p) override {
+		if (!p.is_object()) return;
+		if (p.contains("decay")) m_ema_decay = (float)p["decay"].as_double();
+		if (p.contains("full_precision")) m_full_precision = p["full_precision"].as_bool();
+		if (p.contains("nested")) m_nested->update_hyperparams(p["nested"]);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "EMA";
+		j["nested"] = m_nested->hyperparams();
+		j["decay"] = m_ema_decay;
+		j["full_precision"] = m_full_precision;
+		return j;
+	}
+	Json serialize() const override {
+		Json data = Json::object();
+		data["nested"] = m_nested->serialize();
+		data["weights_ema_binary"] = device_to_binary(m_weights_ema.data(), n_weights() * 2);
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights) override {
+		const std::vector<uint8_t> bytes = binary_of(data["weights_ema_binary"]);
+		if (bytes.size() != n_weights * 2) throw std::runtime_error{"EMA: snapshot state has the wrong size."};
+		m_weights_ema.resize(bytes.size());
+		HIP_CHECK_THROW(hipMemcpy(m_weights_ema.data(), bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+		if (m_full_precision) {
+			m_tmp.resize(n_weights * sizeof(float));
+			cast_half_to_float(nullptr, n_weights, m_weights_ema.data(), m_tmp.as<float>());
+			HIP_CHECK_THROW(hipDeviceSynchronize());
+		}
+		m_nested->deserialize(data["nested"], n_weights);
+	}
+private:
+	float m_ema_decay = 0.99f;
+	bool m_full_precision = false;
+	std::unique_ptr<Optimizer> m_nested;
+	DeviceBuf m_weights_ema, m_tmp;
+};
+
+// src/optimizer.cu:50-82
+inline std::unique_ptr<Optimizer> create_optimizer(const Json& params) {
+	const std::string otype = params.value("otype", "Adam");
+	if (equals_case_insensitive(otype, "Adam")) return std::unique_ptr<Optimizer>{new AdamOptimizer{params}};
+	if (equals_case_insensitive(otype, "SGD")) return std::unique_ptr<Optimizer>{new SgdOptimizer{params}};
+	if (equals_case_insensitive(otype, "ExponentialDecay")) return std::unique_ptr<Optimizer>{new ExponentialDecayOptimizer{params}};
+	if (equals_case_insensitive(otype, "Ema")) return std::unique_ptr<Optimizer>{new EmaOptimizer{params}};
+	throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam, SGD, ExponentialDecay, Ema)"};
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Trainer (trainer.h:48-363) + create_from_config (config.h:53-63)
@@ -1390,7 +1603,7 @@ public:
 		const Json optimizer = config.value("optimizer", Json::object());
 		const Json network = config.value("network", Json::object());
 		m_loss = create_loss(loss);
-		m_optimizer.reset(new AdamOptimizer{optimizer});
+		m_optimizer = create_optimizer(optimizer);
 		m_model.reset(new NetworkWithInputEncoding{n_input_dims, n_output_dims, encoding, network});
 		// trainer.h:52-55
 		std::seed_seq seq{seed};
@@ -1421,7 +1634,7 @@ public:
 		ctx->n = n;
 		const uint32_t pw = m_model->padded_output_width();
 		ctx->output = ArenaBuf{stream, (size_t)n * pw * 2};
-		ctx->model_ctx = m_model->forward(stream, n, input, ctx->output.data(), m_params.data(), prepare_input_gradients);
+		ctx->model_ctx = m_model->forward(stream, n, input, ctx->output.data(), use_inference_params ? params_inference() : m_params.data(), prepare_input_gradients);
 		ctx->L = ArenaBuf{stream, (size_t)n * pw * sizeof(float)};
 		if (external_dL_dy) {
 			ctx->dL_doutput_ptr = external_dL_dy;
@@ -1437,7 +1650,7 @@ public:
 	}
 
 	void backward(hipStream_t stream, const TrainContext& ctx, uint32_t n, MatView input, MatViewMut* dL_dinput, bool use_inference_params, GradientMode mode) { // trainer.h:147-149
-		m_model->backward(stream, *ctx.model_ctx, n, input, ctx.output.data(), ctx.dL_doutput_ptr, dL_dinput, m_params.data(), m_grads.data(), mode);
+		m_model->backward(stream, *ctx.model_ctx, n, input, ctx.output.data(), ctx.dL_doutput_ptr, dL_dinput, use_inference_params ? params_inference() : m_params.data(), m_grads.data(), mode);
 	}
 
 	void optimizer_step(hipStream_t stream, float loss_scale) { // trainer.h:155-157
@@ -1448,7 +1661,8 @@ public:
 	                                            MatViewMut* dL_dinput, bool use_inference_params, GradientMode mode, const void* external_dL_dy) { // trainer.h:163-190
 		const float loss_scale = LOSS_SCALE_FP16;
 		std::unique_ptr<TrainContext> ctx;
-		if (m_model->fused_step_supported(n) && (external_dL_dy || loss_in_fused_kernel(m_loss))) {
+		const bool other_weights = use_inference_params && params_inference() != m_params.data(); // EMA weights requested for this step
+		if (m_model->fused_step_supported(n) && (external_dL_dy || loss_in_fused_kernel(m_loss)) && !other_weights) {
 			// MI355X path: encoding -> ONE fused MLP kernel (forward + loss + backward + weight gradients) -> grid scatter
 			ctx = std::make_unique<TrainContext>();
 			ctx->n = n;
@@ -1486,13 +1700,14 @@ public:
 	void inference(hipStream_t stream, uint32_t n, MatView input, MatViewMut output, bool use_inference_params) { // object.h:147-176
 		Model::check_batch(n);
 		if (n == 0) return;
-		m_model->inference_f32(stream, n, input, output, m_params.data());
+		m_model->inference_f32(stream, n, input, output, use_inference_params ? params_inference() : m_params.data());
 	}
 
 	void set_params_full_precision(const float* params, size_t n_params, bool device_ptr) { // trainer.h:242-254
 		if (n_params != m_model->n_params()) throw std::runtime_error{"Can't set fp params because buffer has the wrong size."};
 		HIP_CHECK_THROW(hipMemcpy(m_params_fp.data(), params, sizeof(float) * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 		cast_float_to_half(nullptr, n_params, m_params_fp.as<float>(), m_params.data());
+		if (params_inference() != m_params.data()) HIP_CHECK_THROW(hipMemcpy(params_inference(), m_params.data(), 2 * n_params, hipMemcpyDeviceToDevice));
 		HIP_CHECK_THROW(hipDeviceSynchronize());
 	}
 
@@ -1500,6 +1715,7 @@ public:
 		if (n_params != m_model->n_params()) throw std::runtime_error{"Can't set params because buffer has the wrong size."};
 		HIP_CHECK_THROW(hipMemcpy(m_params.data(), params, 2 * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 		cast_half_to_float(nullptr, n_params, m_params.data(), m_params_fp.as<float>());
+		if (params_inference() != m_params.data()) HIP_CHECK_THROW(hipMemcpy(params_inference(), m_params.data(), 2 * n_params, hipMemcpyDeviceToDevice));
 		HIP_CHECK_THROW(hipDeviceSynchronize());
 	}
 
@@ -1509,30 +1725,13 @@ public:
 
 	// ---- snapshot wire format, trainer.h:275-315 (+ adam.h:278-299, gpu_memory_json.h:36-71): an object holding the half
 	// parameters as a binary blob and, optionally, the optimizer's state.  Callers store it as MessagePack (Json::to_msgpack).
-	static Json device_to_binary(const void* device, size_t n_bytes) {
-		std::vector<uint8_t> host(n_bytes);
-		if (n_bytes) HIP_CHECK_THROW(hipMemcpy(host.data(), device, n_bytes, hipMemcpyDeviceToHost));
-		return Json::binary(std::move(host));
-	}
-	// binary value, or nlohmann's text form of one: {"bytes": [...], "subtype": null} (gpu_memory_json.h:55-67)
-	static std::vector<uint8_t> binary_of(const Json& j) {
-		if (j.is_binary()) return j.get_binary();
-		if (j.is_object()) {
-			const Json& arr = j["bytes"];
-			std::vector<uint8_t> bytes(arr.size());
-			for (size_t i = 0; i < bytes.size(); ++i) bytes[i] = (uint8_t)arr.at(i).as_double();
-			return bytes;
-		}
-		throw std::runtime_error{"Invalid json type: must be either binary or object"};
-	}
-
 	Json serialize(bool serialize_optimizer) {
 		HIP_CHECK_THROW(hipDeviceSynchronize());
 		const size_t n = m_model->n_params();
 		Json data = Json::object();
 		data["n_params"] = Json((uint64_t)n);
 		data["params_type"] = "__half"; // type_to_string<__half>() of the reference: the name snapshots carry
-		data["params_binary"] = device_to_binary(m_params.data(), 2 * n);
+		data["params_binary"] = device_to_binary(params_inference(), 2 * n); // trainer.h:281: the inference parameters (EMA weights if there are any)
 		if (serialize_optimizer) data["optimizer"] = m_optimizer->serialize();
 		return data;
 	}
@@ -1547,7 +1746,7 @@ public:
 		} else {
 			throw std::runtime_error{"Trainer: snapshot parameters must be of type float of __half"};
 		}
-		if (data.contains("optimizer")) m_optimizer->deserialize(data["optimizer"], m_model->n_params(), binary_of);
+		if (data.contains("optimizer")) m_optimizer->deserialize(data["optimizer"], m_model->n_params());
 		HIP_CHECK_THROW(hipDeviceSynchronize());
 	}
 
@@ -1562,7 +1761,9 @@ public:
 	}
 
 	NetworkWithInputEncoding& model() { return *m_model; }
-	AdamOptimizer& optimizer() { return *m_optimizer; }
+	Optimizer& optimizer() { return *m_optimizer; }
+	// trainer.h:329-333: the optimizer's own weights (EMA) if it keeps any, else the training parameters
+	void* params_inference() const { void* custom = m_optimizer->custom_weights(); return custom ? custom : m_params.data(); }
 	size_t n_params() const { return m_model->n_params(); }
 	float* params_full_precision() const { return m_params_fp.as<float>(); }
 	void* params() const { return m_params.data(); }
@@ -1570,7 +1771,7 @@ public:
 
 private:
 	std::unique_ptr<NetworkWithInputEncoding> m_model;
-	std::unique_ptr<AdamOptimizer> m_optimizer;
+	std::unique_ptr<Optimizer> m_optimizer;
 	LossType m_loss;
 	Pcg32 m_rng;
 	DeviceBuf m_params_fp, m_params, m_grads, m_scalar;

@@ -234,6 +234,9 @@ void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix
                float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps, const float* debias_table);
 // debias_table[t] = sqrtf(1 - powf(beta2, t)) / (1 - powf(beta1, t)) (adam.h:97-98), evaluated on the device, for t in [from, to)
 void adam_fill_debias_table(hipStream_t stream, float beta1, float beta2, uint32_t from, uint32_t to, float* table);
+// optimizers/sgd.h:44-72 and optimizers/ema.h:44-78 (half parameters)
+void sgd_step(hipStream_t stream, size_t n, float loss_scale, float learning_rate, float l2_reg, float* weights_full_precision, void* weights, const void* gradients);
+void ema_step(hipStream_t stream, size_t n, float decay, float debias_old, float debias_new, const void* weights, void* weights_ema, float* tmp);
 
 // random.h:40-70: strided uniform fill from a pcg32 state; advances (state, inc) on the host copy by n
 void generate_random_uniform(hipStream_t stream, uint64_t* state_inc_host, size_t n, float* out, float lower, float upper);

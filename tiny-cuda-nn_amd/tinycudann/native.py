@@ -130,6 +130,10 @@ class Trainer:
     def params(self):
         return self._copy_out(_C.lib.tcnn_trainer_params(self._h), torch.half, 2)
 
+    def params_inference(self):
+        """trainer.h:234: the parameters inference runs with (the optimizer's EMA weights if it keeps any)."""
+        return self._copy_out(_C.lib.tcnn_trainer_params_inference(self._h), torch.half, 2)
+
     def param_gradients(self):
         return self._copy_out(_C.lib.tcnn_trainer_param_gradients(self._h), torch.half, 2)
 
