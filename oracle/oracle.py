@@ -474,6 +474,108 @@ class SphericalHarmonicsEncoding:
         return {"otype": "SphericalHarmonics", "degree": self.degree}
 
 
+class CompositeEncoding:
+    """encodings/composite.h:126-420, reduction Concatenation: nested encodings over slices of the input dims; padded nested
+    outputs side by side (each padded so that the next starts at a multiple of its required alignment, :189-200; the last one
+    absorbs the composite's own padding, :375-385); parameters one after the other (:422-428)."""
+
+    def __init__(self, n_in, cfg):
+        nested = _ci(cfg, "nested", None)
+        if not isinstance(nested, list):
+            raise RuntimeError("Must provide an array of nested encodings to CompositeEncoding.")
+        if _norm(_ci(cfg, "reduction", "Concatenation")) != "concatenation":
+            raise RuntimeError("CompositeEncoding: only Concatenation is restated")
+        total = 0
+        for c in nested:
+            total += int(c.get("n_dims_to_encode", 0))
+            if "dims_to_encode_begin" in c:
+                total = None
+                break
+        if total is not None and total > n_in:
+            raise RuntimeError(f"CompositeEncoding: nested encodings must not encode more dims {total} than composite {n_in}")
+        unspecified = None if total is None else n_in - total
+        offset = 0
+        self.nested, self.begin = [], []
+        for c in nested:
+            if "n_dims_to_encode" in c:
+                if "dims_to_encode_begin" in c:
+                    offset = int(c["dims_to_encode_begin"])
+                dims = int(c["n_dims_to_encode"])
+            else:
+                if unspecified is None:
+                    raise RuntimeError("CompositeEncoding: may only leave 'n_dims_to_encode' unspecified for a single nested encoding")
+                dims, unspecified = unspecified, None
+            if dims > 0:
+                self.nested.append(create_encoding(dims, c, alignment=1))
+                self.begin.append(offset)
+            offset += dims
+        so_far = 0
+        for i in range(len(self.nested) - 1):
+            desired = self.nested[i + 1].required_output_alignment
+            e = self.nested[i]
+            e.n_to_pad = next_multiple(so_far + e.n_output_dims, desired) - so_far - e.n_output_dims
+            so_far += e.padded_output_width
+        self.n_in = n_in
+        self.n_to_pad = 0
+        self.n_params = sum(e.n_params for e in self.nested)
+        self.required_output_alignment = int(np.lcm.reduce([e.required_output_alignment for e in self.nested]))
+
+    @property
+    def n_output_dims(self):
+        return sum(e.padded_output_width for e in self.nested)
+
+    @property
+    def padded_output_width(self):
+        return self.n_output_dims
+
+    def set_alignment(self, alignment):
+        a = int(np.lcm(alignment, self.required_output_alignment))
+        last = self.nested[-1]
+        prev = self.n_output_dims - last.padded_output_width
+        last.n_to_pad = next_multiple(self.n_output_dims, a) - prev - last.n_output_dims
+
+    def initialize_params(self, rng, scale=1.0):
+        parts = [e.initialize_params(rng, scale) for e in self.nested]
+        return np.concatenate(parts).astype(np.float32) if parts else np.empty(0, dtype=np.float32)
+
+    def _param_slices(self):
+        off = 0
+        for e in self.nested:
+            yield e, slice(off, off + e.n_params)
+            off += e.n_params
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((n, self.padded_output_width), dtype=np.uint16)
+        ctxs, col = [], 0
+        for (e, sl), b in zip(self._param_slices(), self.begin):
+            p = None if params_half is None or e.n_params == 0 else np.ascontiguousarray(params_half[sl])
+            o, c = e.forward(np.ascontiguousarray(x[:, b:b + e.n_in]), p, want_dy_dx=want_dy_dx)
+            out[:, col:col + e.padded_output_width] = o
+            ctxs.append(c)
+            col += e.padded_output_width
+        return out, {"nested": ctxs}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        n = x.shape[0]
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        dL_dx = np.zeros((n, self.n_in), dtype=np.float32) if want_dL_dx else None
+        col = 0
+        for (e, sl), b, c in zip(self._param_slices(), self.begin, ctx["nested"]):
+            dy = np.ascontiguousarray(dL_dy[:, col:col + e.padded_output_width])
+            gh = None if grad_half is None or e.n_params == 0 else grad_half[sl]
+            g32 = None if grad_f32 is None or e.n_params == 0 else grad_f32[sl]
+            d = e.backward(np.ascontiguousarray(x[:, b:b + e.n_in]), c, dy, gh, want_dL_dx, g32)
+            if want_dL_dx and d is not None:
+                dL_dx[:, b:b + e.n_in] = d
+            col += e.padded_output_width
+        return dL_dx
+
+    def hyperparams(self):
+        return {"otype": "Composite", "reduction": "Concatenation", "nested": [e.hyperparams() for e in self.nested]}
+
+
 def create_encoding(n_in, cfg, alignment=8):
     """src/encoding.cu:144-158 (case-insensitive otype, default OneBlob)"""
     name = _norm(_ci(cfg, "otype", "OneBlob"))
@@ -489,6 +591,8 @@ def create_encoding(n_in, cfg, alignment=8):
         enc = PeriodicEncoding(n_in, cfg, "trianglewave")
     elif name == "sphericalharmonics":
         enc = SphericalHarmonicsEncoding(n_in, cfg)
+    elif name == "composite":
+        enc = CompositeEncoding(n_in, cfg)
     else:
         raise RuntimeError(f"Encoding '{cfg.get('otype')}' not found")
     if alignment > 0:

@@ -536,6 +536,27 @@ __global__ void __launch_bounds__(256) k_ema(const size_t n, const float decay, 
 }
 } // namespace
 
+namespace {
+// dst[i][dst_col + j] = src[i][src_col + j], j < width (Composite encoding: nested AoS blocks <-> column ranges of the composite row)
+template <typename T>
+__global__ void __launch_bounds__(256) k_copy_columns(const uint32_t n_elements, const uint32_t width, const T* __restrict__ src, const uint32_t src_stride, const uint32_t src_col,
+                                                      T* __restrict__ dst, const uint32_t dst_stride, const uint32_t dst_col) {
+	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n_elements) return;
+	const uint32_t i = e / width, j = e - i * width;
+	dst[(size_t)i * dst_stride + dst_col + j] = src[(size_t)i * src_stride + src_col + j];
+}
+} // namespace
+
+void copy_columns(hipStream_t stream, size_t elem_bytes, uint32_t n, const void* src, uint32_t src_stride, uint32_t src_col, void* dst, uint32_t dst_stride, uint32_t dst_col, uint32_t width) {
+	const uint64_t total = (uint64_t)n * width;
+	if (total == 0) return;
+	CHECK_THROW(total < (1ull << 32) && (elem_bytes == 2 || elem_bytes == 4));
+	const dim3 blocks((uint32_t)((total + 255) / 256));
+	if (elem_bytes == 2) hipLaunchKernelGGL((k_copy_columns<uint16_t>), blocks, dim3(256), 0, stream, (uint32_t)total, width, (const uint16_t*)src, src_stride, src_col, (uint16_t*)dst, dst_stride, dst_col);
+	else hipLaunchKernelGGL((k_copy_columns<uint32_t>), blocks, dim3(256), 0, stream, (uint32_t)total, width, (const uint32_t*)src, src_stride, src_col, (uint32_t*)dst, dst_stride, dst_col);
+}
+
 void sgd_step(hipStream_t stream, size_t n, float loss_scale, float learning_rate, float l2_reg, float* weights_full_precision, void* weights, const void* gradients) {
 	if (n == 0) return;
 	hipLaunchKernelGGL(k_sgd, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, loss_scale, learning_rate, l2_reg, weights_full_precision, (half_t*)weights, (const half_t*)gradients);

@@ -206,6 +206,7 @@ struct EncodingContext {
 	ArenaBuf chunk_mask;  // grid only: uint64 [L][32][n/64] bit planes, which samples touch which scatter chunk (filter for the LDS scatter)
 	uint32_t n = 0;
 	mutable bool dy_records = false; // the level planes handed to backward() hold 16-byte scatter records {coordinates, gradients} (mlp_train_fused); set by the caller of backward()
+	std::vector<EncodingContext> nested; // Composite: one context per nested encoding
 };
 
 class Encoding {
@@ -215,9 +216,13 @@ public:
 	virtual uint32_t output_width() const = 0; // unpadded
 	uint32_t padded_output_width() const { return output_width() + m_n_to_pad; }
 	virtual uint32_t required_output_alignment() const { return 1; }
+	virtual void set_padded_output_width(uint32_t padded) { // encoding.h: each encoding pads its own output with ones
+		CHECK_THROW(padded >= output_width());
+		m_n_to_pad = padded - output_width();
+	}
 	void set_alignment(uint32_t alignment) { // encoding.h:70-72
 		const uint32_t a = std::lcm(alignment, required_output_alignment());
-		m_n_to_pad = next_multiple(output_width(), a) - output_width();
+		set_padded_output_width(next_multiple(output_width(), a));
 	}
 	virtual size_t n_params() const { return 0; }
 	virtual void initialize_params(Pcg32& rng, float* params_full_precision, float scale) {}
@@ -722,6 +727,139 @@ private:
 	uint32_t m_degree;
 };
 
+inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, const Json& enc, uint32_t alignment, bool fp32);
+
+// encodings/composite.h:126-420, reduction "Concatenation": nested encodings over slices of the input dims, their (padded)
+// outputs side by side, their parameters one after the other.  Every nested encoding writes its own AoS block, which is then
+// copied into its column range of the composite row (and dL_dy copied out the same way): a few extra bytes per sample instead
+// of a width / stride distinction in every encoding kernel.
+class CompositeEncoding : public Encoding {
+public:
+	CompositeEncoding(uint32_t n_dims_to_encode, const Json& params, bool fp32) : Encoding{fp32}, m_n_dims{n_dims_to_encode} {
+		if (!params.contains("nested") || !params["nested"].is_array()) throw std::runtime_error{"Must provide an array of nested encodings to CompositeEncoding."};
+		const std::string reduction = params.value("reduction", "Concatenation");
+		if (!equals_case_insensitive(reduction, "Concatenation")) throw std::runtime_error{"CompositeEncoding: reduction '" + reduction + "' is not provided by this build (Concatenation only)"};
+		const Json& nested = params["nested"];
+		m_config = params;
+		uint32_t total = 0;
+		for (size_t i = 0; i < nested.size(); ++i) { // composite.h:147-158
+			total += nested.at(i).value("n_dims_to_encode", 0u);
+			if (nested.at(i).contains("dims_to_encode_begin")) { total = 0xFFFFFFFFu; break; }
+		}
+		if (total != 0xFFFFFFFFu && total > n_dims_to_encode) throw std::runtime_error{"CompositeEncoding: nested encodings must not encode more dims " + std::to_string(total) + " than composite " + std::to_string(n_dims_to_encode)};
+		uint32_t unspecified = total == 0xFFFFFFFFu ? 0xFFFFFFFFu : (n_dims_to_encode - total);
+		uint32_t offset = 0;
+		for (size_t i = 0; i < nested.size(); ++i) { // composite.h:163-187
+			const Json& cfg = nested.at(i);
+			uint32_t dims;
+			if (cfg.contains("n_dims_to_encode")) {
+				if (cfg.contains("dims_to_encode_begin")) offset = cfg.value("dims_to_encode_begin", 0u);
+				dims = cfg.value("n_dims_to_encode", 0u);
+			} else {
+				if (unspecified == 0xFFFFFFFFu) throw std::runtime_error{"CompositeEncoding: may only leave 'n_dims_to_encode' unspecified for a single nested encoding"};
+				dims = unspecified;
+				unspecified = 0xFFFFFFFFu;
+			}
+			if (dims > 0) {
+				if (offset + dims > n_dims_to_encode) throw std::runtime_error{"CompositeEncoding: nested encoding reaches past the input dims"};
+				m_nested.emplace_back(create_encoding(dims, cfg, 1, fp32));
+				m_begin.push_back(offset);
+			}
+			offset += dims;
+		}
+		if (m_nested.empty()) throw std::runtime_error{"CompositeEncoding: no nested encoding encodes anything"};
+		// composite.h:189-200: pad each nested output so that the next one starts at a multiple of ITS required alignment
+		uint32_t so_far = 0;
+		for (size_t i = 0; i + 1 < m_nested.size(); ++i) {
+			const uint32_t desired = m_nested[i + 1]->required_output_alignment();
+			m_nested[i]->set_padded_output_width(next_multiple(so_far + m_nested[i]->output_width(), desired) - so_far);
+			so_far += m_nested[i]->padded_output_width();
+		}
+	}
+	uint32_t input_width() const override { return m_n_dims; }
+	uint32_t output_width() const override { // composite.h:352-366: the sum of the nested PADDED widths
+		uint32_t total = 0;
+		for (const auto& e : m_nested) total += e->padded_output_width();
+		return total;
+	}
+	uint32_t required_output_alignment() const override {
+		uint32_t a = 1;
+		for (const auto& e : m_nested) a = std::lcm(a, e->required_output_alignment());
+		return a;
+	}
+	void set_padded_output_width(uint32_t padded) override { // composite.h:375-385: the last nested encoding absorbs the padding
+		const uint32_t prev = output_width() - m_nested.back()->padded_output_width();
+		CHECK_THROW(padded >= prev + m_nested.back()->output_width());
+		m_nested.back()->set_padded_output_width(padded - prev);
+	}
+	size_t n_params() const override {
+		size_t n = 0;
+		for (const auto& e : m_nested) n += e->n_params();
+		return n;
+	}
+	void initialize_params(Pcg32& rng, float* params_full_precision, float scale) override { // composite.h:422-428
+		size_t offset = 0;
+		for (auto& e : m_nested) {
+			e->initialize_params(rng, params_full_precision + offset, scale);
+			offset += e->n_params();
+		}
+	}
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
+		EncodingContext ctx;
+		if (!out || n == 0) return ctx;
+		const size_t elem = m_fp32 ? 4 : 2;
+		ctx.nested.resize(m_nested.size());
+		uint32_t col = 0;
+		size_t p_off = 0;
+		for (size_t i = 0; i < m_nested.size(); ++i) {
+			Encoding& e = *m_nested[i];
+			const uint32_t w = e.padded_output_width();
+			ArenaBuf block{stream, (size_t)n * w * elem};
+			const MatView xs{x.data + (size_t)m_begin[i] * x.stride_dim, x.stride_sample, x.stride_dim};
+			ctx.nested[i] = e.forward(stream, n, xs, (const char*)params + p_off * elem, block.data(), prepare_input_gradients, prepare_param_gradients);
+			copy_columns(stream, elem, n, block.data(), w, 0, out, padded_output_width(), col, w);
+			col += w;
+			p_off += e.n_params();
+		}
+		return ctx;
+	}
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
+		if (n == 0) return;
+		CHECK_THROW(!dy_planes && ctx.nested.size() == m_nested.size());
+		const size_t elem = m_fp32 ? 4 : 2;
+		// input dims no nested encoding looks at have zero gradient
+		if (dL_dx && dL_dx->stride_dim == 1 && dL_dx->stride_sample == m_n_dims) HIP_CHECK_THROW(hipMemsetAsync(dL_dx->data, 0, (size_t)n * m_n_dims * sizeof(float), stream));
+		uint32_t col = 0;
+		size_t p_off = 0;
+		for (size_t i = 0; i < m_nested.size(); ++i) {
+			Encoding& e = *m_nested[i];
+			const uint32_t w = e.padded_output_width();
+			ArenaBuf block{stream, (size_t)n * w * elem};
+			copy_columns(stream, elem, n, dL_dy, padded_output_width(), col, block.data(), w, 0, w);
+			const MatView xs{x.data + (size_t)m_begin[i] * x.stride_dim, x.stride_sample, x.stride_dim};
+			MatViewMut dxs{};
+			if (dL_dx) dxs = MatViewMut{dL_dx->data + (size_t)m_begin[i] * dL_dx->stride_dim, dL_dx->stride_sample, dL_dx->stride_dim};
+			e.backward(stream, ctx.nested[i], n, xs, block.data(), dL_dx ? &dxs : nullptr, (const char*)params + p_off * elem, grads ? (char*)grads + p_off * elem : nullptr, mode, false);
+			col += w;
+			p_off += e.n_params();
+		}
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "Composite";
+		j["reduction"] = "Concatenation";
+		Json nested = Json::array();
+		for (const auto& e : m_nested) nested.push_back(e->hyperparams());
+		j["nested"] = nested;
+		return j;
+	}
+private:
+	uint32_t m_n_dims;
+	Json m_config;
+	std::vector<std::unique_ptr<Encoding>> m_nested;
+	std::vector<uint32_t> m_begin;
+};
+
 inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, const Json& enc, uint32_t alignment, bool fp32) {
 	const std::string name = to_lower(enc.value("otype", "OneBlob"));
 	std::unique_ptr<Encoding> result;
@@ -737,8 +875,10 @@ inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, cons
 		result.reset(new PeriodicEncoding{true, enc.value("n_frequencies", 12u), n_dims_to_encode, fp32});
 	} else if (name == "sphericalharmonics") {
 		result.reset(new SphericalHarmonicsEncoding{enc.value("degree", 4u), n_dims_to_encode, fp32});
+	} else if (name == "composite") {
+		result.reset(new CompositeEncoding{n_dims_to_encode, enc, fp32});
 	} else {
-		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity, Frequency, TriangleWave, SphericalHarmonics)"};
+		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity, Frequency, TriangleWave, SphericalHarmonics, Composite)"};
 	}
 	if (alignment > 0) result->set_alignment(alignment);
 	return result;

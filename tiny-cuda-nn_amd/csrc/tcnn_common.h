@@ -234,6 +234,8 @@ void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix
                float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps, const float* debias_table);
 // debias_table[t] = sqrtf(1 - powf(beta2, t)) / (1 - powf(beta1, t)) (adam.h:97-98), evaluated on the device, for t in [from, to)
 void adam_fill_debias_table(hipStream_t stream, float beta1, float beta2, uint32_t from, uint32_t to, float* table);
+// dst[i][dst_col + j] = src[i][src_col + j] for j < width; elements of 2 or 4 bytes (Composite encoding)
+void copy_columns(hipStream_t stream, size_t elem_bytes, uint32_t n, const void* src, uint32_t src_stride, uint32_t src_col, void* dst, uint32_t dst_stride, uint32_t dst_col, uint32_t width);
 // optimizers/sgd.h:44-72 and optimizers/ema.h:44-78 (half parameters)
 void sgd_step(hipStream_t stream, size_t n, float loss_scale, float learning_rate, float l2_reg, float* weights_full_precision, void* weights, const void* gradients);
 void ema_step(hipStream_t stream, size_t n, float decay, float debias_old, float debias_new, const void* weights, void* weights_ema, float* tmp);
