@@ -282,6 +282,8 @@ MLP_CASES = [
     (32, 3, {"otype": "FullyFusedMLP", "activation": "Squareplus", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 1}),
     (32, 3, {"otype": "FullyFusedMLP", "activation": "Softplus", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 1}),
     (32, 3, {"otype": "FullyFusedMLP", "activation": "None", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}),
+    (32, 3, {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 256, "n_hidden_layers": 2}),  # wider than FullyFusedMLP allows
+    (16, 4, {"otype": "CutlassMLP", "activation": "Sigmoid", "output_activation": "None", "n_neurons": 256, "n_hidden_layers": 1}),
 ]
 
 

@@ -542,7 +542,7 @@ void launch_bwd_act(hipStream_t stream, const MlpDesc& d, const BwdArgs& a, uint
 }
 
 // column blocks (of 16 samples) a wave processes per iteration
-constexpr int nb_for_width(int W) { return W >= 128 ? 2 : 4; }
+constexpr int nb_for_width(int W) { return W >= 256 ? 1 : (W >= 128 ? 2 : 4); }
 
 inline uint32_t mlp_grid(uint32_t n, int nb) {
 	const uint32_t n_iters = n / (16 * nb);
@@ -597,6 +597,7 @@ void mlp_forward_io(hipStream_t stream, const MlpDesc& d, const void* image, uin
 		case 32: return launch_fwd_act<32, nb_for_width(32)>(stream, d, a, mlp_grid(n, nb_for_width(32)));
 		case 64: return launch_fwd_act<64, nb_for_width(64)>(stream, d, a, mlp_grid(n, nb_for_width(64)));
 		case 128: return launch_fwd_act<128, nb_for_width(128)>(stream, d, a, mlp_grid(n, nb_for_width(128)));
+		case 256: return launch_fwd_act<256, nb_for_width(256)>(stream, d, a, mlp_grid(n, nb_for_width(256))); // CutlassMLP configs only
 		default: throw std::runtime_error{"FullyFusedMLP only supports 16, 32, 64, and 128 neurons."};
 	}
 }
@@ -613,6 +614,7 @@ void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint3
 		case 32: return launch_bwd_act<32, nb_for_width(32)>(stream, d, a, mlp_grid(n, nb_for_width(32)));
 		case 64: return launch_bwd_act<64, nb_for_width(64)>(stream, d, a, mlp_grid(n, nb_for_width(64)));
 		case 128: return launch_bwd_act<128, nb_for_width(128)>(stream, d, a, mlp_grid(n, nb_for_width(128)));
+		case 256: return launch_bwd_act<256, nb_for_width(256)>(stream, d, a, mlp_grid(n, nb_for_width(256)));
 		default: throw std::runtime_error{"FullyFusedMLP only supports 16, 32, 64, and 128 neurons."};
 	}
 }

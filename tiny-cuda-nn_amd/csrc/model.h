@@ -920,8 +920,10 @@ public:
 		m_n_hidden = net.value("n_hidden_layers", 5u);
 		m_activation = string_to_activation(net.value("activation", "ReLU"));
 		m_output_activation = string_to_activation(net.value("output_activation", "None"));
-		if (m_width != 16 && m_width != 32 && m_width != 64 && m_width != 128) {
-			throw std::runtime_error{"FullyFusedMLP only supports 16, 32, 64, and 128 neurons, but got " + std::to_string(m_width) + ". (CutlassMLP widths outside that set are not provided by this build.)"};
+		// fully_fused_mlp.cu:869-881 restricts FullyFusedMLP to these widths; CutlassMLP (cutlass_mlp.cu:39-92) takes any -- here: 256 as well
+		const bool width_ok = m_width == 16 || m_width == 32 || m_width == 64 || m_width == 128 || (cutlass && m_width == 256);
+		if (!width_ok) {
+			throw std::runtime_error{"FullyFusedMLP only supports 16, 32, 64, and 128 neurons, but got " + std::to_string(m_width) + ". (CutlassMLP: also 256; other widths are not provided by this build.)"};
 		}
 		if (m_n_hidden <= 0) throw std::runtime_error{"FullyFusedMLP requires at least 1 hidden layer (3 layers in total)."};
 		if (m_n_hidden + 1 > MAX_MLP_LAYERS) throw std::runtime_error{"MLP: too many layers for this build"};
