@@ -219,14 +219,19 @@ __global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdA
 		// ---- hidden layers 1 .. n_hidden-1: chained in registers
 		for (uint32_t l = 1; l < d.n_hidden; ++l) {
 			const uint32_t img = d.layers[l].fwd_off;
+			// Software pipeline over the KS * T weight fragments of the layer: fragment i + 1 is requested before the NB MFMAs of
+			// fragment i are issued, in a second register set.  Written out in this order the compiler waits with lgkmcnt(1); as a
+			// plain "load, use" loop it reused ONE register quad and exposed the whole LDS latency before every group of MFMAs
+			// (measured on C4: the MFMA pipe 36 % busy).
+			h8 af_cur = frag(img);
 #pragma unroll
-			for (int s = 0; s < KS; ++s) {
+			for (int i = 0; i < KS * T; ++i) {
+				const int s = i / T, t = i % T;
+				h8 af_next = af_cur;
+				if (i + 1 < KS * T) af_next = frag(img + ((i + 1) % T) * KS + (i + 1) / T);
 #pragma unroll
-				for (int t = 0; t < T; ++t) {
-					const h8 af = frag(img + t * KS + s);
-#pragma unroll
-					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], s == 0 ? f4{0, 0, 0, 0} : acc[t][b]); // first k-step: C = inline 0, no register clearing
-				}
+				for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af_cur, hf[s][b], s == 0 ? f4{0, 0, 0, 0} : acc[t][b]); // first k-step: C = inline 0, no register clearing
+				af_cur = af_next;
 			}
 			activate_pack<T, KS, NB, ACT>(acc, hf, d.activation);
 			store_hidden(l);
