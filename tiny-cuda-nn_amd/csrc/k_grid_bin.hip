@@ -29,7 +29,7 @@ namespace {
 constexpr uint32_t BIN_TILE_CONTRIBS = 8192; // contributions sorted per workgroup (LDS: 4 + 2F bytes each)
 constexpr uint32_t BIN_MAX_CHUNKS = 4096;    // chunks per level (LDS: three uint32 tables)
 constexpr uint32_t BIN_COUNT_THREADS = 256;
-constexpr uint32_t BIN_FILL_THREADS = 512;
+constexpr uint32_t BIN_FILL_THREADS = 1024;
 constexpr uint32_t BIN_ACC_THREADS = 1024;
 constexpr uint32_t BIN_ACC_BYTES_MAX = 128 * 1024;
 
