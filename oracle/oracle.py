@@ -593,6 +593,11 @@ def create_encoding(n_in, cfg, alignment=8):
         enc = SphericalHarmonicsEncoding(n_in, cfg)
     elif name == "composite":
         enc = CompositeEncoding(n_in, cfg)
+    elif name in ("oneblobfrequency", "nrc"):  # src/encoding.cu:96-119
+        enc = CompositeEncoding(n_in, {"otype": "Composite", "nested": [
+            {"n_dims_to_encode": 3, "otype": "TriangleWave", "n_frequencies": _ci(cfg, "n_frequencies", 12)},
+            {"n_dims_to_encode": 5, "otype": "OneBlob", "n_bins": _ci(cfg, "n_bins", 4)},
+            {"otype": "Identity"}]})
     else:
         raise RuntimeError(f"Encoding '{cfg.get('otype')}' not found")
     if alignment > 0:

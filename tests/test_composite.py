@@ -67,6 +67,22 @@ def test_composite_encoding_matches_oracle(tcnn, oracle):
 
 
 @pytest.mark.gpu
+def test_nrc_alias_matches_oracle(tcnn, oracle):
+    """src/encoding.cu:96-119: "NRC" / "OneBlobFrequency" = Composite(TriangleWave x3, OneBlob x5, Identity on the rest)."""
+    from test_gpu_parity import _bits, _t
+
+    for name in ("NRC", "OneBlobFrequency"):
+        cfg = {"otype": name, "n_frequencies": 6, "n_bins": 4}
+        enc = tcnn.Encoding(10, cfg)
+        ref = oracle.create_encoding(10, cfg, alignment=0)
+        assert [type(e).__name__ for e in ref.nested] == ["PeriodicEncoding", "OneBlobEncoding", "IdentityEncoding"]
+        assert enc.n_output_dims == ref.padded_output_width == 3 * 6 + 5 * 4 + 2
+        x = oracle.Pcg32(42).uniform_strided(512 * 10).reshape(512, 10)
+        want, _ = ref.forward(x)
+        assert np.array_equal(_bits(enc(_t(x))), want)  # all three parts are exact arithmetic
+
+
+@pytest.mark.gpu
 def test_trainer_with_composite_encoding(tcnn, oracle):
     """create_from_config with a NeRF-shaped config: Composite(HashGrid + SphericalHarmonics) -> 64 x 2 FullyFusedMLP, nested
     optimizers.  First step against the oracle, then the loss falls."""

@@ -877,6 +877,25 @@ inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, cons
 		result.reset(new SphericalHarmonicsEncoding{enc.value("degree", 4u), n_dims_to_encode, fp32});
 	} else if (name == "composite") {
 		result.reset(new CompositeEncoding{n_dims_to_encode, enc, fp32});
+	} else if (name == "oneblobfrequency" || name == "nrc") {
+		// src/encoding.cu:96-119: the neural radiance caching input layer = TriangleWave on 3 position dims, OneBlob on the next 5,
+		// Identity on whatever is left
+		Json tri = Json::object(), blob = Json::object(), rest = Json::object();
+		tri["n_dims_to_encode"] = 3u;
+		tri["otype"] = "TriangleWave";
+		tri["n_frequencies"] = enc.value("n_frequencies", 12u);
+		blob["n_dims_to_encode"] = 5u;
+		blob["otype"] = "OneBlob";
+		blob["n_bins"] = enc.value("n_bins", 4u);
+		rest["otype"] = "Identity";
+		Json nested = Json::array();
+		nested.push_back(tri);
+		nested.push_back(blob);
+		nested.push_back(rest);
+		Json composite = Json::object();
+		composite["otype"] = "Composite";
+		composite["nested"] = nested;
+		result.reset(new CompositeEncoding{n_dims_to_encode, composite, fp32});
 	} else {
 		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity, Frequency, TriangleWave, SphericalHarmonics, Composite)"};
 	}
