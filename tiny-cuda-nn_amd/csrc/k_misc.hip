@@ -61,6 +61,39 @@ __global__ void __launch_bounds__(256) k_oneblob_fwd(const uint32_t n, const uin
 	out[gid] = (T)(r - l);
 }
 
+// The same, 8 consecutive bins per thread (n_bins and out_stride multiples of 8): the 9 bin edges are evaluated once each --
+// the right edge of bin k IS the left edge of bin k + 1, bit for bit -- and the 8 results leave in one store.  27 cdf evaluations
+// for 8 outputs instead of 48: the element-per-thread form took 26 of C2's 84 us per step, ALU-bound.
+template <typename T>
+__global__ void __launch_bounds__(256) k_oneblob_fwd8(const uint32_t n, const uint32_t n_dims, const uint32_t log2_bins, const MatView x, T* __restrict__ out, const uint32_t out_stride) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t chunks = out_stride / 8;
+	const uint32_t i = gid / chunks;
+	if (i >= n) return;
+	const uint32_t j0 = (gid - i * chunks) * 8;
+	const uint32_t n_bins = 1u << log2_bins;
+	typedef T vec8 __attribute__((ext_vector_type(8)));
+	vec8 v;
+	if (j0 >= n_dims * n_bins) { // oneblob.h:207-209
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = (T)1.0f;
+	} else {
+		const uint32_t dim = j0 >> log2_bins, b0 = j0 & (n_bins - 1);
+		const float xv = x.data[(size_t)i * x.stride_sample + (size_t)dim * x.stride_dim];
+		const float nb = (float)n_bins;
+		float edge[9];
+#pragma unroll
+		for (int k = 0; k < 9; ++k) {
+			const float lb = scalbnf((float)((b0 + k) & (n_bins - 1)), -(int)log2_bins);
+			edge[k] = quartic_cdf(lb - xv, nb) + quartic_cdf(lb - xv - 1.0f, nb) + quartic_cdf(lb - xv + 1.0f, nb);
+		}
+		if (b0 + 8 == n_bins) edge[8] += 1; // the last bin's right edge is bin 0's left edge + 1
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = (T)(edge[k + 1] - edge[k]);
+	}
+	*(vec8*)(out + (size_t)i * out_stride + j0) = v;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(128) k_oneblob_bwd_input(const uint32_t n, const uint32_t n_dims, const uint32_t log2_bins, const MatView x, const T* __restrict__ dL_dy, const uint32_t dy_stride, const MatViewMut dL_dx) {
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,6 +463,12 @@ void oneblob_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims,
 	if (total == 0) return;
 	CHECK_THROW(total < (1ull << 32));
 	const uint32_t lb = log2_exact(n_bins);
+	if (n_bins % 8 == 0 && out_stride % 8 == 0) {
+		const uint64_t threads = total / 8;
+		if (fp32) hipLaunchKernelGGL(k_oneblob_fwd8<float>, dim3(blocks_for(threads, 256)), dim3(256), 0, stream, n, n_dims, lb, x, (float*)out, out_stride);
+		else hipLaunchKernelGGL(k_oneblob_fwd8<half_t>, dim3(blocks_for(threads, 256)), dim3(256), 0, stream, n, n_dims, lb, x, (half_t*)out, out_stride);
+		return;
+	}
 	if (fp32) hipLaunchKernelGGL(k_oneblob_fwd<float>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, n_dims, lb, x, (float*)out, out_stride);
 	else hipLaunchKernelGGL(k_oneblob_fwd<half_t>, dim3(blocks_for(total, 256)), dim3(256), 0, stream, n, n_dims, lb, x, (half_t*)out, out_stride);
 }
