@@ -1267,6 +1267,9 @@ public:
 	                                         void* gradients, GradientMode mode) {
 		check_batch(n);
 		auto ctx = std::make_unique<Ctx>();
+		// Everything in order on the caller's stream.  Running the two small kernels around the MLP kernel (k_mlp_prep, k_wgrad_reduce,
+		// ~5 us each, independent of the encoding kernels) on a side stream was measured and lost 13-15 us per step on every
+		// workload: a cross-stream event dependency costs more here than the kernels it hides (the same happened with Adam).
 		fused_encode(stream, *ctx, n, input, params, dL_dinput != nullptr, mode != GradientMode::Ignore);
 		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, dL_dinput, params, gradients, mode);
 		return ctx;
