@@ -906,6 +906,65 @@ class Ema:
         return self.weights_ema
 
 
+def slice_layer_sizes(layer_sizes, offset):
+    """optimizers/composite.h:44-74 (slice_weights) as it is meant: the layers that start at or after `offset`; a cut inside a
+    layer is an error.  (The reference's loop advances the layer index BEFORE adding that layer's size, so it skips layer 0
+    and indexes one past the end for any offset > 0 -- undefined behaviour there, the intended slice here.)"""
+    out, pos = [], 0
+    for r, c in layer_sizes:
+        if pos < offset < pos + r * c:
+            raise RuntimeError("Invalid slice. Can't slice within a layer.")
+        if pos >= offset:
+            out.append((r, c))
+        pos += r * c
+    return out
+
+
+class CompositeOptimizer:
+    """optimizers/composite.h:76-173: nested[i] owns the next n_params_to_optimize weights; custom weights are gathered"""
+
+    def __init__(self, cfg):
+        nested = _ci(cfg, "nested", None)
+        if not isinstance(nested, list) or not nested:
+            raise RuntimeError("Must provide an array of nested encodings to CompositeOptimizer.")
+        self.offsets, self.nested = [0], []
+        for c in nested:
+            self.nested.append(create_optimizer(c))
+            self.offsets.append(self.offsets[-1] + int(_ci(c, "n_params_to_optimize", 0)))
+        self.base_learning_rates = [o.learning_rate() for o in self.nested]
+        self.learning_rate_factor = np.float32(1.0)
+        self.custom = None
+
+    def allocate(self, n, layer_sizes):
+        for i, o in enumerate(self.nested):
+            o.allocate(self.offsets[i + 1] - self.offsets[i], slice_layer_sizes(layer_sizes, self.offsets[i]))
+        if any(o.custom_weights() is not None for o in self.nested):
+            self.custom = np.zeros(n, dtype=np.uint16)  # the whole vector: weights past the last nested optimizer are carried over
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        for i, o in enumerate(self.nested):
+            a, b = self.offsets[i], self.offsets[i + 1]
+            o.step(loss_scale, w_fp[a:b], w_half[a:b], g_half[a:b])
+            if self.custom is not None:
+                self.custom[a:b] = w_half[a:b] if o.custom_weights() is None else o.custom_weights()
+        if self.custom is not None:
+            self.custom[self.offsets[-1]:] = w_half[self.offsets[-1]:]
+
+    def learning_rate(self):
+        return self.learning_rate_factor
+
+    def set_learning_rate(self, v):
+        self.learning_rate_factor = np.float32(v)
+        for o, base in zip(self.nested, self.base_learning_rates):
+            o.set_learning_rate(np.float32(base) * self.learning_rate_factor)
+
+    def step_count(self):
+        return self.nested[0].step_count()
+
+    def custom_weights(self):
+        return self.custom
+
+
 def create_optimizer(cfg):
     """src/optimizer.cu:50-82 (the subset this build provides)"""
     name = _norm(_ci(cfg, "otype", "Adam"))
@@ -917,6 +976,8 @@ def create_optimizer(cfg):
         return ExponentialDecay(cfg)
     if name == "ema":
         return Ema(cfg)
+    if name == "composite":
+        return CompositeOptimizer(cfg)
     raise RuntimeError(f"Invalid optimizer type: {cfg.get('otype')}")
 
 

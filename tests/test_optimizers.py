@@ -1,5 +1,6 @@
 """Optimizers beside Adam (src/optimizer.cu:50-82): SGD (optimizers/sgd.h), ExponentialDecay
-(exponential_decay.h) and Ema (ema.h) -- the nesting instant-ngp style configs use: Ema -> ExponentialDecay -> Adam.
+(exponential_decay.h), Ema (ema.h) -- the nesting instant-ngp style configs use: Ema -> ExponentialDecay -> Adam -- and
+Composite (composite.h: one nested optimizer per slice of the parameter vector).
 Identical gradients are copied into the trainer so that only the optimizer is compared with the oracle's restatement."""
 import numpy as np
 import pytest
@@ -114,6 +115,74 @@ def test_inference_and_snapshot_use_ema_weights(tcnn, oracle):
     b = tcnn.Trainer(2, 3, cfg, seed=3)
     b.deserialize(tr.serialize(serialize_optimizer=True))
     assert torch.equal(b.inference(xt), y_ema) and b.optimizer_step_count() == 5
+
+
+def _composite(n_net, n_grid):
+    """optimizers/composite.h: SGD on the network's matrices, Ema -> Adam on the grid's entries"""
+    return {"otype": "Composite", "nested": [
+        {"otype": "SGD", "learning_rate": 1e-2, "l2_reg": 1e-4, "n_params_to_optimize": n_net},
+        {"otype": "Ema", "decay": 0.9, "n_params_to_optimize": n_grid,
+         "nested": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6}},
+    ]}
+
+
+def test_oracle_composite_optimizer(oracle):
+    layers = [(4, 8), (4, 4)]
+    assert oracle.slice_layer_sizes(layers, 0) == layers and oracle.slice_layer_sizes(layers, 32) == [(4, 4)] and oracle.slice_layer_sizes(layers, 48) == []
+    with pytest.raises(RuntimeError, match="Can't slice within a layer"):
+        oracle.slice_layer_sizes(layers, 40)
+    with pytest.raises(RuntimeError, match="Must provide an array"):
+        oracle.create_optimizer({"otype": "Composite", "nested": []})
+    opt = oracle.create_optimizer(_composite(48, 16))
+    n = 72  # 8 weights past the last nested optimizer: never touched, carried into the custom weights
+    opt.allocate(n, layers)
+    assert opt.offsets == [0, 48, 64] and opt.nested[1].nested.n_matrix == 0  # the grid part has no matrix weights: no l2_reg there
+    w_fp = np.linspace(-1, 1, n).astype(np.float32)
+    w_h = oracle.half_bits(w_fp)
+    before = w_fp.copy()
+    g = oracle.half_bits(np.full(n, 128.0, dtype=np.float32))
+    opt.step(128.0, w_fp, w_h, g)
+    assert np.allclose(w_fp[:48], before[:48] - 1e-2 * (1 + 1e-4 * before[:48]), atol=1e-7)  # SGD
+    assert np.allclose(w_fp[48:64], before[48:64] - 1e-2, atol=1e-6)  # Adam's first step = lr * sign(g)
+    assert np.array_equal(w_fp[64:], before[64:])
+    cw = opt.custom_weights()
+    assert np.array_equal(cw[:48], w_h[:48]) and np.array_equal(cw[48:64], opt.nested[1].weights_ema) and np.array_equal(cw[64:], w_h[64:])
+    assert opt.step_count() == 1 and opt.learning_rate() == 1.0
+    opt.set_learning_rate(0.5)  # composite.h:104-109: a FACTOR on the nested base rates
+    assert np.isclose(opt.nested[0].learning_rate(), 5e-3) and np.isclose(opt.nested[1].learning_rate(), 5e-3)
+
+
+@pytest.mark.gpu
+def test_composite_optimizer_matches_oracle(tcnn, oracle):
+    import torch
+
+    msgpack = pytest.importorskip("msgpack")
+    from test_gpu_parity import CONFIG_C3B, _bits
+
+    sizes = oracle.Trainer(2, 3, CONFIG_C3B, seed=1337).model
+    n_net, n = sizes.network.n_params, sizes.n_params
+    cfg = _composite(n_net, n - n_net)
+    ref, tr, p0 = _drive(tcnn, oracle, cfg, steps=4)
+    hp = tr.hyperparams()["optimizer"]
+    assert hp["otype"] == "Composite" and [h["otype"] for h in hp["nested"]] == ["SGD", "EMA"]
+    got = tr.params_full_precision().cpu().numpy()
+    assert np.array_equal(got[:n_net].view(np.uint32), ref.params_fp[:n_net].view(np.uint32))  # the SGD part: bit-exact
+    upd = np.abs(ref.params_fp[n_net:] - p0[n_net:])
+    assert np.max(np.abs(got[n_net:] - ref.params_fp[n_net:])) <= 1e-5 * np.max(upd) + 1e-9  # the Adam part: the Adam bar
+    # inference weights: the network's training weights next to the grid's EMA
+    inf = _bits(tr.params_inference())
+    want = ref.optimizer.custom_weights()
+    assert np.array_equal(inf[:n_net], ref.params[:n_net]) and np.mean(inf[n_net:] == want[n_net:]) > 0.999
+    assert tr.optimizer_step_count() == 4
+    # snapshot: composite.h:140-152
+    snap = msgpack.unpackb(tr.serialize(serialize_optimizer=True), raw=False)["optimizer"]
+    assert set(snap) == {"nested", "base_learning_rates", "learning_rate_factor"} and len(snap["nested"]) == 2
+    assert np.allclose(snap["base_learning_rates"], [1e-2, 1e-2]) and snap["learning_rate_factor"] == 1.0
+    b = tcnn.Trainer(2, 3, {**CONFIG_C3B, "optimizer": cfg}, seed=3)
+    b.deserialize(tr.serialize(serialize_optimizer=True))
+    assert b.optimizer_step_count() == 4 and torch.equal(b.params_inference(), tr.params_inference())
+    with pytest.raises(RuntimeError, match="Can't slice within a layer"):
+        tcnn.Trainer(2, 3, {**CONFIG_C3B, "optimizer": _composite(n_net - 8, n - n_net + 8)})
 
 
 @pytest.mark.gpu

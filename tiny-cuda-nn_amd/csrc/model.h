@@ -1429,6 +1429,8 @@ public:
 	virtual Json hyperparams() const = 0;
 	virtual Json serialize() const = 0;
 	virtual void deserialize(const Json& data, size_t n_weights) = 0;
+	// after a snapshot was loaded into `weights`: optimizers that assemble custom weights from several sources rebuild them
+	virtual void weights_restored(hipStream_t stream, const void* weights) {}
 };
 inline std::unique_ptr<Optimizer> create_optimizer(const Json& params);
 
@@ -1729,6 +1731,120 @@ private:
 	DeviceBuf m_weights_ema, m_tmp;
 };
 
+// optimizers/composite.h:44-74 (slice_weights) as it is meant: the layers that start at or after `offset`; a cut inside a layer
+// is an error.  (The reference's loop advances the layer index before adding that layer's size: it skips layer 0 and runs one
+// past the end of the list for any offset > 0 -- undefined behaviour there, the intended slice here.)
+inline std::vector<std::pair<uint32_t, uint32_t>> slice_layer_sizes(const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes, size_t offset) {
+	std::vector<std::pair<uint32_t, uint32_t>> out;
+	size_t pos = 0;
+	for (const auto& ls : layer_sizes) {
+		const size_t size = (size_t)ls.first * ls.second;
+		if (pos < offset && offset < pos + size) throw std::runtime_error{"Invalid slice. Can't slice within a layer."};
+		if (pos >= offset) out.push_back(ls);
+		pos += size;
+	}
+	return out;
+}
+
+// optimizers/composite.h:76-173: nested[i] optimizes the next "n_params_to_optimize" weights of the parameter vector
+class CompositeOptimizer : public Optimizer {
+public:
+	explicit CompositeOptimizer(const Json& params) {
+		if (!params.contains("nested") || !params["nested"].is_array() || params["nested"].size() == 0) {
+			throw std::runtime_error{"Must provide an array of nested encodings to CompositeOptimizer."};
+		}
+		m_offsets.push_back(0);
+		for (size_t i = 0; i < params["nested"].size(); ++i) {
+			const Json& nested = params["nested"].at(i);
+			m_offsets.push_back(m_offsets.back() + (size_t)nested.value("n_params_to_optimize", 0));
+			m_nested.emplace_back(create_optimizer(nested));
+			m_base_learning_rates.push_back(m_nested.back()->learning_rate());
+		}
+		update_hyperparams(params);
+	}
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) override {
+		CHECK_THROW(n_weights >= m_offsets.back()); // weights past the last nested optimizer stay as they are
+		m_need_custom_weights = false;
+		for (size_t i = 0; i < m_nested.size(); ++i) {
+			m_nested[i]->allocate(m_offsets[i + 1] - m_offsets[i], slice_layer_sizes(layer_sizes, m_offsets[i]));
+			m_need_custom_weights |= m_nested[i]->custom_weights() != nullptr;
+		}
+		m_n_total = n_weights;
+		if (m_need_custom_weights) { // sized for the whole vector: the trainer runs inference from it (the reference sizes it to the optimized part only)
+			m_custom_weights.resize(n_weights * 2);
+			m_custom_weights.memset(0);
+		}
+	}
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override {
+		for (size_t i = 0; i < m_nested.size(); ++i) {
+			const size_t offset = m_offsets[i];
+			m_nested[i]->step(stream, loss_scale, weights_full_precision + offset, (_Float16*)weights + offset, (const _Float16*)gradients + offset);
+		}
+		weights_restored(stream, weights);
+	}
+	// composite.h:86-93: the custom weights are the nested optimizers' custom weights where they have any, else the weights
+	void weights_restored(hipStream_t stream, const void* weights) override {
+		if (!m_need_custom_weights) return;
+		for (size_t i = 0; i < m_nested.size(); ++i) {
+			const size_t offset = m_offsets[i];
+			m_nested[i]->weights_restored(stream, (const _Float16*)weights + offset);
+			const void* src = m_nested[i]->custom_weights() ? m_nested[i]->custom_weights() : (const void*)((const _Float16*)weights + offset);
+			HIP_CHECK_THROW(hipMemcpyAsync((_Float16*)m_custom_weights.data() + offset, src, m_nested[i]->n_weights() * 2, hipMemcpyDeviceToDevice, stream));
+		}
+		if (m_n_total > m_offsets.back()) {
+			const size_t done = m_offsets.back();
+			HIP_CHECK_THROW(hipMemcpyAsync((_Float16*)m_custom_weights.data() + done, (const _Float16*)weights + done, (m_n_total - done) * 2, hipMemcpyDeviceToDevice, stream));
+		}
+	}
+	float learning_rate() const override { return m_learning_rate_factor; }
+	void set_learning_rate(float val) override {
+		m_learning_rate_factor = val;
+		for (size_t i = 0; i < m_nested.size(); ++i) m_nested[i]->set_learning_rate(m_base_learning_rates[i] * m_learning_rate_factor);
+	}
+	uint32_t step_count() const override { return m_nested[0]->step_count(); }
+	size_t n_weights() const override { return m_offsets.back(); }
+	void* custom_weights() const override { return m_need_custom_weights ? m_custom_weights.data() : nullptr; }
+	void update_hyperparams(const Json& p) override {
+		if (!p.is_object() || !p.contains("nested") || !p["nested"].is_array()) return;
+		for (size_t i = 0; i < m_nested.size() && i < p["nested"].size(); ++i) m_nested[i]->update_hyperparams(p["nested"].at(i));
+	}
+	Json hyperparams() const override {
+		Json nested = Json::array();
+		for (const auto& n : m_nested) nested.push_back(n->hyperparams());
+		Json j = Json::object();
+		j["otype"] = "Composite";
+		j["nested"] = nested;
+		return j;
+	}
+	Json serialize() const override {
+		Json nested = Json::array(), rates = Json::array();
+		for (const auto& n : m_nested) nested.push_back(n->serialize());
+		for (float r : m_base_learning_rates) rates.push_back(Json(r));
+		Json data = Json::object();
+		data["nested"] = nested;
+		data["base_learning_rates"] = rates;
+		data["learning_rate_factor"] = m_learning_rate_factor;
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights) override {
+		CHECK_THROW(n_weights >= m_offsets.back());
+		const Json& nested = data["nested"];
+		for (size_t i = 0; i < m_nested.size(); ++i) m_nested[i]->deserialize(nested.at(i), m_offsets[i + 1] - m_offsets[i]);
+		const Json& rates = data["base_learning_rates"];
+		m_base_learning_rates.clear();
+		for (size_t i = 0; i < rates.size(); ++i) m_base_learning_rates.push_back((float)rates.at(i).as_double());
+		set_learning_rate((float)data["learning_rate_factor"].as_double());
+	}
+private:
+	std::vector<std::unique_ptr<Optimizer>> m_nested;
+	std::vector<float> m_base_learning_rates;
+	std::vector<size_t> m_offsets;
+	size_t m_n_total = 0;
+	float m_learning_rate_factor = 1.0f;
+	bool m_need_custom_weights = false;
+	DeviceBuf m_custom_weights;
+};
+
 // src/optimizer.cu:50-82
 inline std::unique_ptr<Optimizer> create_optimizer(const Json& params) {
 	const std::string otype = params.value("otype", "Adam");
@@ -1736,7 +1852,8 @@ inline std::unique_ptr<Optimizer> create_optimizer(const Json& params) {
 	if (equals_case_insensitive(otype, "SGD")) return std::unique_ptr<Optimizer>{new SgdOptimizer{params}};
 	if (equals_case_insensitive(otype, "ExponentialDecay")) return std::unique_ptr<Optimizer>{new ExponentialDecayOptimizer{params}};
 	if (equals_case_insensitive(otype, "Ema")) return std::unique_ptr<Optimizer>{new EmaOptimizer{params}};
-	throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam, SGD, ExponentialDecay, Ema)"};
+	if (equals_case_insensitive(otype, "Composite")) return std::unique_ptr<Optimizer>{new CompositeOptimizer{params}};
+	throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam, SGD, ExponentialDecay, Ema, Composite)"};
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1910,7 +2027,10 @@ public:
 		} else {
 			throw std::runtime_error{"Trainer: snapshot parameters must be of type float of __half"};
 		}
-		if (data.contains("optimizer")) m_optimizer->deserialize(data["optimizer"], m_model->n_params());
+		if (data.contains("optimizer")) {
+			m_optimizer->deserialize(data["optimizer"], m_model->n_params());
+			m_optimizer->weights_restored(nullptr, m_params.data());
+		}
 		HIP_CHECK_THROW(hipDeviceSynchronize());
 	}
 
