@@ -739,11 +739,13 @@ void dispatch_train(hipStream_t stream, const MlpDesc& d, const TrainArgs& a, co
 } // namespace
 
 bool mlp_train_fused_supported(const MlpDesc& d, uint32_t n) {
+	if (mlp_train_regs_supported(d, n)) return true;
 	const TrainConfig cfg = pick_config(d);
 	return cfg.ok && n % cfg.s == 0 && n > 0;
 }
 
 uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n) {
+	if (mlp_train_regs_supported(d, n)) return mlp_train_regs_grid(d, n);
 	const TrainConfig cfg = pick_config(d);
 	if (!cfg.ok) return 0;
 	const uint32_t trips = n / cfg.s;
@@ -755,6 +757,10 @@ uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n) {
 void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
                      uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params) {
+	if (mlp_train_regs_supported(d, n)) {
+		return mlp_train_regs(stream, d, image, n, x, x_plane_features, target, data_pdf, external_dL_dy, dims, loss, loss_scale, out, dL_dout, L, nullptr, dL_dx, dx_plane_features,
+		                      dx_record_x, dx_record_dims, slabs, n_params);
+	}
 	const TrainConfig cfg = pick_config(d);
 	CHECK_THROW(cfg.ok && n % cfg.s == 0);
 	TrainArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)dL_dout, L, (half_t*)dL_dx, slabs, (const h8*)image,

@@ -208,6 +208,14 @@ uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n); // workgroups = num
 void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
                      uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params);
+// ---- the same step for (16 | 32) -> 64 -> [64 ->] 16 networks with everything in registers (k_train_regs.hip): no LDS images, no
+// barriers, transposes on the matrix cores.  mlp_train_fused* dispatch to it when it applies (TCNN_AMD_MLP_REGS=0: never).
+// loss_sums (optional): float[grid], the sum of the workgroup's loss values (lets callers skip the [n][16] float matrix L).
+bool mlp_train_regs_supported(const MlpDesc& d, uint32_t n);
+uint32_t mlp_train_regs_grid(const MlpDesc& d, uint32_t n);
+void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
+                    const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, float* loss_sums, void* dL_dx,
+                    uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params);
 // grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once
 void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate);
 // fully_fused_mlp.cu:757-762: result = dL_dout * act'(out), elementwise over n_elems halfs
