@@ -137,10 +137,12 @@ int  tcnn_trainer_backward(tcnn_trainer_t t, tcnn_stream_t stream, tcnn_train_ct
                            float* dL_dinput, int use_inference_params, int gradient_mode);
 int  tcnn_trainer_optimizer_step(tcnn_trainer_t t, tcnn_stream_t stream, float loss_scale);
 void tcnn_train_ctx_destroy(tcnn_train_ctx_t ctx);
-/* ForwardContext members (trainer.h:89-95): device pointers valid until the context is destroyed */
+/* ForwardContext members (trainer.h:89-95): device pointers valid until the context is destroyed.
+ * The fused training step keeps dL_doutput and L as dense [n][n_output_dims] matrices (the padding columns are zeros) and forms
+ * the padded ones on the FIRST call of their accessor, on the step's stream. */
 const void*  tcnn_train_ctx_output(tcnn_train_ctx_t ctx);      /* half  [n][padded_out] */
-const void*  tcnn_train_ctx_dL_doutput(tcnn_train_ctx_t ctx);  /* half  [n][padded_out] */
-const float* tcnn_train_ctx_L(tcnn_train_ctx_t ctx);           /* float [n][padded_out] */
+const void*  tcnn_train_ctx_dL_doutput(tcnn_train_ctx_t ctx);  /* half  [n][padded_out]; NULL + tcnn_last_error() on failure */
+const float* tcnn_train_ctx_L(tcnn_train_ctx_t ctx);           /* float [n][padded_out]; NULL + tcnn_last_error() on failure */
 
 /* network->inference(stream, input, output) (object.h:147-176): float in, float out [n_output_dims x n] in output_layout */
 int  tcnn_trainer_inference(tcnn_trainer_t t, tcnn_stream_t stream, uint32_t n_elements, const float* input, int input_layout,

@@ -523,3 +523,66 @@ def test_wide_inference_forms_agree(tcnn, oracle, monkeypatch):
     ref = oracle.Trainer(32, 16, cfg, seed=1337)
     want = ref.inference(x[:1024])
     assert rel_err(y_lds[:1024], want) < 1e-2
+
+
+def test_compact_training_context(tcnn, oracle):
+    """The register-resident fused kernel keeps dL_doutput / L as [n][dims] matrices and pads them on access (model.h
+    TrainContext::compact): same bits as the kernels that write the padded matrices during the step (TCNN_AMD_MLP_REGS=0),
+    whatever happens to the caller's target tensor in between."""
+    import os
+
+    import torch
+
+    n = 2048
+    x, t = oracle.synthetic_batch(n, 2, 3, seed=42)
+    results = []
+    for regs in ("1", "0"):
+        os.environ["TCNN_AMD_MLP_REGS"] = regs
+        try:
+            tr = tcnn.Trainer(2, 3, CONFIG_C3B, seed=1337)
+            tt = _t(t)
+            ctx = tr.training_step(_t(x), tt, run_optimizer=False)
+            tt.fill_(7.0)  # the context must not depend on the caller's buffers after the step
+            del tt
+            junk = torch.full((n, 3), 3.0, device="cuda")
+            loss = tr.loss(ctx)
+            results.append((loss, _bits(ctx.output()), ctx.L().cpu().numpy(), _bits(ctx.dL_doutput()), tr.loss(ctx)))
+            del junk
+        finally:
+            os.environ.pop("TCNN_AMD_MLP_REGS", None)
+    (l0, o0, L0, g0, l0b), (l1, o1, L1, g1, l1b) = results
+    assert np.array_equal(o0, o1)
+    assert np.array_equal(L0.view(np.uint32), L1.view(np.uint32)) and np.array_equal(g0, g1)
+    assert np.all(L0[:, 3:] == 0) and np.all(g0[:, 3:] == 0)
+    assert abs(l0 - l1) <= 1e-5 * abs(l1) and abs(l0b - l1) <= 1e-5 * abs(l1)  # sums of the same values in two orders
+
+
+@pytest.mark.parametrize("n", [256 * 384, 1 << 18])
+def test_fused_mlp_kernel_forms_agree_at_full_batch(tcnn, oracle, monkeypatch, n):
+    """BASELINE batch sizes, where every wave of the register-resident fused kernel (k_train_regs.hip) takes several trips
+    (3 and 8) and its input prefetch / counted waits are live: the compile-time form (FAST), the general form and the LDS-image
+    kernels of k_train.hip compute the same forward pass and the same dL/d(encoding) -- bit-identical outputs, loss matrices
+    and grid gradients -- and MLP weight gradients that differ by fp32 summation order only."""
+    x, t = oracle.synthetic_batch(n, 2, 3, seed=11)
+    n_net = oracle.Trainer(2, 3, CONFIG_C3A, seed=1337).model.network.n_params
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, CONFIG_C3A, seed=1337)
+        for _ in range(2):  # same parameters both times (the MLP weight gradients differ in the last bits between the forms)
+            ctx = tr.training_step(_t(x), _t(t), run_optimizer=False)
+        res = (_bits(tr.param_gradients()), _bits(ctx.output()), ctx.L().cpu().numpy().view(np.uint32), _bits(ctx.dL_doutput()), tr.loss(ctx))
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
+
+    g0, o0, L0, d0, l0 = run({})
+    assert np.isfinite(l0) and np.any(g0[n_net:] != 0)
+    for env in ({"TCNN_AMD_MLP_FAST": "0"}, {"TCNN_AMD_MLP_REGS": "0"}):
+        g, o, L, d, l = run(env)
+        assert np.array_equal(o, o0) and np.array_equal(L, L0) and np.array_equal(d, d0), env
+        assert np.array_equal(g[n_net:], g0[n_net:]), env
+        a, b = _f32(g[:n_net]), _f32(g0[:n_net])
+        assert float(np.linalg.norm(a - b)) <= 2e-3 * float(np.linalg.norm(b)), env
+        assert abs(l - l0) <= 1e-5 * abs(l0), env

@@ -273,8 +273,15 @@ int tcnn_trainer_optimizer_step(tcnn_trainer_t t, tcnn_stream_t stream, float lo
 
 void tcnn_train_ctx_destroy(tcnn_train_ctx_t ctx) { delete ctx; }
 const void* tcnn_train_ctx_output(tcnn_train_ctx_t ctx) { return ctx->ctx->output.data(); }
-const void* tcnn_train_ctx_dL_doutput(tcnn_train_ctx_t ctx) { return ctx->ctx->dL_doutput_ptr; }
-const float* tcnn_train_ctx_L(tcnn_train_ctx_t ctx) { return ctx->ctx->L.as<float>(); }
+// compact contexts (model.h TrainContext::compact) produce the two padded matrices on first access
+const void* tcnn_train_ctx_dL_doutput(tcnn_train_ctx_t ctx) {
+	if (guarded([&] { ctx->ctx->materialize(); }) != 0) return nullptr;
+	return ctx->ctx->dL_doutput_ptr;
+}
+const float* tcnn_train_ctx_L(tcnn_train_ctx_t ctx) {
+	if (guarded([&] { ctx->ctx->materialize(); }) != 0) return nullptr;
+	return ctx->ctx->L.as<float>();
+}
 
 int tcnn_trainer_inference(tcnn_trainer_t t, tcnn_stream_t stream, uint32_t n, const float* input, int input_layout, float* output, int output_layout, int use_inference_params) {
 	return guarded([&] {

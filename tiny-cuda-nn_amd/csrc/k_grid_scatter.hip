@@ -41,8 +41,8 @@ constexpr uint32_t SCATTER_QUEUE_IDS = 64 * SCATTER_SUB_BATCHES + 64; // wave-pr
 constexpr uint32_t SCATTER_LDS_BYTES = SCATTER_ACC_BYTES + SCATTER_WAVES * SCATTER_QUEUE_IDS * 4;
 constexpr uint32_t SCATTER_MAX_CHUNKS = 64;        // bit planes per level (the forward mask is a uint64); levels cut finer are binned (k_grid_bin.hip)
 
-// REC: dL_dy holds 16-byte records float4 [level][n] = {D coordinates, F gradient halves} written by the fused MLP kernel
-// (mlp_device.h store_dx_record): one gather per hit instead of two -- gathers cost ~2 clk per lane per CU whatever their width.
+// REC: dL_dy holds 16-byte records {D coordinates, gradient halves} written by the fused MLP kernel
+// (mlp_device.h store_dx_record; float4 [level][n], or [level / 2][n] where two levels fit one record): one gather per hit instead of two -- gathers cost ~2 clk per lane per CU whatever their width.
 template <int D, int F, bool REC>
 __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	const GridMeta* __restrict__ meta, const GridScatterTask* __restrict__ tasks, const uint32_t n, const MatView x,
@@ -87,14 +87,18 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	typedef typename VecOf<half_t, F>::type vecF;
 
 	// issue the loads of one sample (coordinates + its dL/dy of this level)
-	const uint4* recs = (const uint4*)dL_dy + (size_t)task.level * n;
+	// records (mlp_device.h store_dx_record): one per level, except D = 2 with F = 2 where two levels share one
+	constexpr bool PAIRED = REC && D == 2 && F == 2;
+	const uint4* recs = (const uint4*)dL_dy + (size_t)(PAIRED ? task.level / 2 : task.level) * n;
 	auto fetch = [&](const uint32_t i, float (&xin)[D], vecF& gv) {
 		if constexpr (REC) {
 			const uint4 r = recs[i];
 			const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
 			for (int d = 0; d < D; ++d) xin[d] = __builtin_bit_cast(float, w[d]);
-			if constexpr (F == 2) {
+			if constexpr (PAIRED) {
+				gv = __builtin_bit_cast(vecF, (task.level & 1u) ? w[3] : w[2]);
+			} else if constexpr (F == 2) {
 				gv = __builtin_bit_cast(vecF, w[D]);
 			} else {
 				typedef uint32_t u2 __attribute__((ext_vector_type(2)));
@@ -459,6 +463,10 @@ void dispatch_scatter(hipStream_t s, uint32_t F, const GridMeta* dm, const GridS
 } // namespace
 
 uint32_t grid_scatter_max_chunks() { return SCATTER_MAX_CHUNKS; }
+
+uint32_t grid_scatter_record_planes(const GridMeta& meta) {
+	return (meta.n_pos_dims == 2 && meta.n_features_per_level == 2) ? (meta.n_levels + 1) / 2 : meta.n_levels;
+}
 
 bool grid_scatter_records_supported(const GridMeta& meta) {
 	const uint32_t D = meta.n_pos_dims, F = meta.n_features_per_level;

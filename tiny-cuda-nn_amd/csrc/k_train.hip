@@ -755,12 +755,14 @@ uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n) {
 }
 
 void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
-                     const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
+                     const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, void* dL_dx,
                      uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params) {
-	if (mlp_train_regs_supported(d, n)) {
-		return mlp_train_regs(stream, d, image, n, x, x_plane_features, target, data_pdf, external_dL_dy, dims, loss, loss_scale, out, dL_dout, L, nullptr, dL_dx, dx_plane_features,
+	if (mlp_train_regs_supported(d, n) && slabs != nullptr) { // without weight gradients (GradientMode::Ignore): the kernels below
+		CHECK_THROW(compact_context || external_dL_dy);
+		return mlp_train_regs(stream, d, image, n, x, x_plane_features, target, data_pdf, external_dL_dy, dims, loss, loss_scale, out, dL_dout, L, dL_dx, dx_plane_features,
 		                      dx_record_x, dx_record_dims, slabs, n_params);
 	}
+	CHECK_THROW(!compact_context); // compact context matrices are a feature of k_train_regs.hip
 	const TrainConfig cfg = pick_config(d);
 	CHECK_THROW(cfg.ok && n % cfg.s == 0);
 	TrainArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)dL_dout, L, (half_t*)dL_dx, slabs, (const h8*)image,

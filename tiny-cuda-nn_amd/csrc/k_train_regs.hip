@@ -20,6 +20,11 @@
 // MFMA work per 16 samples: 30 (chain) + 19 (transposes) + 28 (k = 16 weight-gradient products) issue slots of 16 clocks.
 #include "mlp_device.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 namespace tcnn_amd {
 namespace {
 
@@ -29,9 +34,8 @@ struct RegsArgs {
 	const float* data_pdf;  // optional [n][dims]
 	const half_t* ext_dy;   // external dL/doutput [n][16] (LOSS == 0)
 	half_t* out;            // optional [n][16]
-	half_t* dL_dout;        // optional [n][16]
-	float* L;               // optional [n][16]
-	float* loss_sums;       // optional [gridDim.x]: sum of the loss values of the workgroup's samples
+	half_t* dL_dout;        // [n][dims]: the live columns of the reference's [n][16] matrix, dense ("compact"; mlp_expand_context pads them)
+	float* L;               // [n][dims], likewise
 	half_t* dL_dx;          // optional: AoS, level planes or scatter records
 	float* slabs;           // optional [gridDim.x][n_params]
 	const h8* image;        // k_mlp_prep's fragment images, forward then backward
@@ -39,6 +43,7 @@ struct RegsArgs {
 	uint32_t n, dims, rec_dims;
 	uint32_t x_plane_f, dx_plane_f, n_params;
 	float loss_scale;
+	unsigned long long* dbg; // development aid (TCNN_AMD_MLP_TIMING): per workgroup, wave 0's clock at kernel start / first trip / last trip done / end
 };
 
 constexpr int REGS_NW = 8; // waves per workgroup
@@ -59,11 +64,43 @@ template <int IN_T, int NH> struct RegsLayout {
 	static constexpr int n_tiles = T * IN_T + (NH - 1) * T * T + T;  // weight-gradient tiles
 };
 
-// f32 accumulator tile -> 4 halves (round to nearest even, like the reference's fp16 accumulators are read)
-__device__ inline h4 to_h4(const f4 v) { return h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
+// f32 accumulator tile -> 4 halves (round to nearest even, like the reference's fp16 accumulators are read); as a vector
+// conversion so that it becomes two v_cvt_pk_f16_f32
+__device__ inline h4 to_h4(const f4 v) { return __builtin_convertvector(v, h4); }
 __device__ inline h8 join(const h4 lo, const h4 hi) { return h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
 
-template <int IN_T, int NH, int ACT, int LOSS>
+// hidden activation on a tile, packed (v_pk_max_f16): ReLU(half) = max(x, 0) (common_device.h:92-98); ACT None: identity
+template <int ACT> __device__ inline h4 act_fwd_tile(const h4 v) {
+	if constexpr (ACT == (int)Activation::ReLU) return __builtin_elementwise_max(v, h4{0, 0, 0, 0});
+	else return v;
+}
+// ... and its derivative from the forward output (common_device.h:241-297): ReLU keeps the gradient where the output is
+// positive.  Outputs of a ReLU are +0 or positive, so "positive" is "any bit set": min(bits, 1) = 0 / 1 -> 0 - that = all
+// zeros / all ones, packed 16-bit integer ops.  (A masked gradient becomes +0 where the reference forms g * 0 = +-0.)
+template <int ACT> __device__ inline h4 act_bwd_tile(const h4 g, const h4 fwd) {
+	if constexpr (ACT == (int)Activation::ReLU) {
+		// inline assembly: written as vector code the compiler turns min(x, 1) back into per-element compares and selects
+		const uint2 f = __builtin_bit_cast(uint2, fwd), gb = __builtin_bit_cast(uint2, g);
+		uint2 m;
+		asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_sub_u16 %0, 0, %0 op_sel_hi:[0,1]" : "=&v"(m.x) : "v"(f.x));
+		asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]\n\tv_pk_sub_u16 %0, 0, %0 op_sel_hi:[0,1]" : "=&v"(m.y) : "v"(f.y));
+		return __builtin_bit_cast(h4, (uint2{gb.x & m.x, gb.y & m.y}));
+	} else {
+		return g;
+	}
+}
+// loads / stores at 32-bit byte offsets from wave-uniform bases (saddr + voffset addressing; mlp_train_regs_supported caps n)
+template <typename V> __device__ inline V ld32(const void* base, const uint32_t byte_off) { return *(const V*)((const char*)base + byte_off); }
+template <typename V> __device__ inline void st32(void* base, const uint32_t byte_off, const V v) { *(V*)((char*)base + byte_off) = v; }
+
+// FAST: the common case with every format decision made at compile time -- input as level planes of 2 features, at most 4 outputs,
+// no data_pdf, `out` and scatter records {x, y, two levels} written.  Not for speed of the decisions themselves: vmcnt retires in
+// issue order and counts stores too, and with branches between a trip's loads and its stores the compiler's wait for the
+// prefetched inputs at the top of the next trip is vmcnt(0) -- every trip then also sat out the write acknowledgements of the
+// stores it had just issued (measured: a third of the trip time).  Without those branches it counts: vmcnt(8) leaves the 8
+// stores of the trip in flight.
+// PHASES: development build (TCNN_AMD_MLP_TIMING=2) that sums wave 0's clocks per phase of the trip into a.dbg's tail.
+template <int IN_T, int NH, int ACT, int LOSS, bool FAST, bool PHASES = false>
 __global__ void __launch_bounds__(REGS_NW * 64, 2) k_mlp_train_regs(const MlpDesc d, const RegsArgs a) {
 	using Lay = RegsLayout<IN_T, NH>;
 	constexpr int T = 4, KS = 2;
@@ -75,8 +112,146 @@ __global__ void __launch_bounds__(REGS_NW * 64, 2) k_mlp_train_regs(const MlpDes
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t c = lane & 15, q = lane >> 4;
 
-	// ---- weight fragments and the selection fragments into LDS
-	for (uint32_t i = tid; i < (uint32_t)Lay::n_frags * 64; i += REGS_NW * 64) lds_frag[i] = a.image[i];
+	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
+	// The fragment reads are loop-invariant, and left alone the compiler hoists all of them out of the trip loop (136 registers,
+	// spilled to scratch).  An opaque per-trip lane offset keeps each read next to its use.
+	uint32_t lane_off = lane * 16;
+	auto frag = [&](const int slot) -> h8 { return *(const h8*)(smem + lane_off + slot * 1024); };
+
+	f4 wacc[Lay::n_tiles];
+#pragma unroll
+	for (int i = 0; i < Lay::n_tiles; ++i) wacc[i] = f4{0, 0, 0, 0};
+
+	const uint32_t n_blocks = a.n / 16;
+	const uint32_t first = blockIdx.x * REGS_NW + wave, step = gridDim.x * REGS_NW;
+	const uint32_t n_total = a.n * a.dims; // loss normalisation (relative_l2.h:58)
+	const uint32_t in_w = 16 * IN_T;
+	// OUTPUT ROWS.  The output layer's fragments are permuted while they are copied to LDS (below) so that accumulator register r
+	// of lane (c, q) holds output q + 4 r of sample c instead of 4 q + r: with n_output_dims <= 4 every lane quarter then has ONE
+	// live output in register 0, and the loss -- a dozen dependent IEEE divisions per output -- runs once per trip instead of
+	// once per output.  n_r = registers that hold live outputs.
+	const uint32_t n_r = FAST ? 1u : (a.dims + 3) / 4;
+	const uint32_t xpf = FAST ? 2u : a.x_plane_f;
+	const bool has_pdf = FAST ? false : a.data_pdf != nullptr;
+	const bool has_out = FAST ? true : a.out != nullptr;
+	const bool has_dx = FAST ? true : a.dL_dx != nullptr;
+	const bool dx_rec = FAST ? true : a.rec_x != nullptr;
+	const uint32_t rec_dims = FAST ? 2u : a.rec_dims;
+
+	// ---- addressing.  Every global access of a trip is "wave-uniform base of the trip's 16-sample block" + "lane offset that
+	// never changes": the bases are scalar arithmetic, the lane offsets are computed once, the trip loop spends (almost) no vector
+	// instruction on addresses (written naively, 30 accesses per trip cost ~250 of them).
+	const uint32_t n4 = a.n * 4;
+	// input: 8 consecutive features 8 q .. 8 q + 7 of sample c, the B operand of layer 0 (natural k order).  in_w = 16: the lanes
+	// q >= 2 have no features; they re-read those of q - 2 and are zeroed after the load.
+	const uint32_t qx = IN_T == 1 ? (q & 1u) : q;
+	uint32_t x_off, x_blk; // lane offset; bytes per 16-sample block
+	if (xpf == 2) { x_off = (4 * qx * a.n + c) * 4; x_blk = 64; }        // levels 4 q + i at + i n 4
+	else if (xpf == 4) { x_off = (2 * qx * a.n + c) * 8; x_blk = 128; }  // levels 2 q + i at + i n 8
+	else if (xpf == 8) { x_off = (qx * a.n + c) * 16; x_blk = 256; }
+	else { x_off = (c * in_w + 8 * qx) * 2; x_blk = 32 * in_w; }
+	auto load_x = [&](const uint32_t blk) -> h8 {
+		const char* base = (const char*)a.x + (size_t)blk * x_blk;
+		uint4 v;
+		if (xpf == 2) { // four 4-byte loads, each a dense 64-byte run per 16 lanes
+			v.x = ld32<uint32_t>(base, x_off);
+			v.y = ld32<uint32_t>(base + (size_t)n4, x_off);
+			v.z = ld32<uint32_t>(base + (size_t)n4 * 2, x_off);
+			v.w = ld32<uint32_t>(base + (size_t)n4 * 3, x_off);
+		} else if (xpf == 4) {
+			const uint2 lo = ld32<uint2>(base, x_off);
+			const uint2 hi = ld32<uint2>(base + (size_t)n4 * 2, x_off);
+			v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+		} else {
+			v = ld32<uint4>(base, x_off);
+		}
+		if (IN_T == 1 && q >= 2) v = uint4{0, 0, 0, 0};
+		return __builtin_bit_cast(h8, v);
+	};
+	// dL/dinput: features k0 .. k0 + 3, k0 = 16 ti + 4 q, of sample c.  Lane offset + per-tile stride + bytes per block + the
+	// distance of the second store where a tile row needs two (dx_second = 0: one store).
+	uint32_t dx_off = 0, dx_tile = 0, dx_blk = 0, dx_second = 0;
+	if (FAST) { // float4 rec[level pair 4 ti + q][n]
+		dx_off = (q * a.n + c) * 16; dx_tile = 4 * a.n * 16; dx_blk = 256;
+	} else if (dx_rec && a.dx_plane_f == 2 && rec_dims == 3) { // float4 rec[level][n], levels 8 ti + 2 q and + 1
+		dx_off = (2 * q * a.n + c) * 16; dx_tile = 8 * a.n * 16; dx_blk = 256; dx_second = a.n * 16;
+	} else if (dx_rec) { // float4 rec[pair or level 4 ti + q][n] (mlp_device.h store_dx_record)
+		dx_off = (q * a.n + c) * 16; dx_tile = 4 * a.n * 16; dx_blk = 256;
+	} else if (a.dx_plane_f == 0) { // AoS [n][in_w]
+		dx_off = (c * in_w + 4 * q) * 2; dx_tile = 32; dx_blk = 32 * in_w;
+	} else if (a.dx_plane_f == 2) { // half2 plane[level][n], levels 8 ti + 2 q and + 1
+		dx_off = (2 * q * a.n + c) * 4; dx_tile = 8 * a.n * 4; dx_blk = 64; dx_second = a.n * 4;
+	} else if (a.dx_plane_f == 4) { // half4 plane[level 4 ti + q][n]
+		dx_off = (q * a.n + c) * 8; dx_tile = 4 * a.n * 8; dx_blk = 128;
+	} else { // F = 8: half8 plane[level 2 ti + q / 2][n], half (q & 1) of the sample's 16 bytes
+		dx_off = ((q >> 1) * a.n + c) * 16 + (q & 1u) * 8; dx_tile = 2 * a.n * 16; dx_blk = 256;
+	}
+
+	// side inputs of a trip: target (and pdf) of output rows q + 4 r, the sample's coordinates for the scatter records, or the
+	// external dL/doutput.  Rows >= dims re-read the last row (masked where they are used): no divergent branches around loads.
+	uint32_t t_off[4];
+#pragma unroll
+	for (int r = 0; r < 4; ++r) t_off[r] = (c * a.dims + min(q + 4 * r, a.dims - 1)) * 4;
+	const uint32_t xs_off = c * rec_dims * 4;
+	const uint32_t o_off = (c * 16 + q) * 2; // out / external dL_dout: column q (+ 4 r: + 8 r bytes) of sample c in [n][16] halves
+	const uint32_t cg_off = (c * a.dims + q) * 2; // compact dL_dout [n][dims] halves (+ 4 r: + 8 r bytes); compact L [n][dims] floats: twice that
+	struct Aux { float t[4], pdf[4], xs[3]; h4 dy; };
+	auto load_aux = [&](const uint32_t blk) -> Aux {
+		Aux r;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			r.t[i] = 0.0f;
+			r.pdf[i] = 1.0f;
+			r.dy[i] = (half_t)0.0f;
+		}
+		if constexpr (LOSS != 0) {
+			const char* tb = (const char*)a.target + (size_t)blk * (64 * a.dims);
+			const char* pb = (const char*)a.data_pdf + (size_t)blk * (64 * a.dims);
+			r.t[0] = ld32<float>(tb, t_off[0]);
+			if (has_pdf) r.pdf[0] = ld32<float>(pb, t_off[0]);
+			if (n_r > 1) { // wave-uniform, rare: more than 4 outputs
+#pragma unroll
+				for (int i = 1; i < 4; ++i) {
+					r.t[i] = ld32<float>(tb, t_off[i]);
+					if (has_pdf) r.pdf[i] = ld32<float>(pb, t_off[i]);
+				}
+			}
+		} else {
+			const char* yb = (const char*)a.ext_dy + (size_t)blk * 512;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) r.dy[i] = ld32<half_t>(yb + 8 * i, o_off);
+		}
+		r.xs[0] = r.xs[1] = r.xs[2] = 0.0f;
+		if (dx_rec) { // wave-uniform
+			const char* xb = (const char*)a.rec_x + (size_t)blk * (64 * rec_dims);
+			r.xs[0] = ld32<float>(xb, xs_off);
+			r.xs[1] = ld32<float>(xb + 4, xs_off);
+			if (rec_dims > 2) r.xs[2] = ld32<float>(xb + 8, xs_off);
+		}
+		return r;
+	};
+	// The next trip's inputs are requested at the START of a trip, ahead of this trip's stores: vmcnt retires in issue order, so a
+	// load issued behind the stores would also wait for their write acknowledgements.
+	h8 pre_x = h8{0, 0, 0, 0, 0, 0, 0, 0};
+	Aux pre_aux{};
+	if (first < n_blocks) {
+		pre_x = load_x(first);
+		pre_aux = load_aux(first);
+	}
+
+	// ---- weight fragments and the selection fragments into LDS (after the first trip's loads are on their way; all of a
+	// thread's fragment loads are issued before the first LDS write)
+	{
+		constexpr uint32_t N16 = (uint32_t)Lay::n_frags * 64;
+		constexpr int FILL = (N16 + REGS_NW * 64 - 1) / (REGS_NW * 64);
+		h8 tmp[FILL];
+#pragma unroll
+		for (int k = 0; k < FILL; ++k) tmp[k] = a.image[min(tid + k * REGS_NW * 64, N16 - 1)];
+#pragma unroll
+		for (int k = 0; k < FILL; ++k) {
+			if (tid + k * REGS_NW * 64 < N16) lds_frag[tid + k * REGS_NW * 64] = tmp[k];
+		}
+	}
 	if (tid < 4 * 64) {
 		const uint32_t which = tid >> 6;
 		uint32_t j = 8; // no element
@@ -91,107 +266,62 @@ __global__ void __launch_bounds__(REGS_NW * 64, 2) k_mlp_train_regs(const MlpDes
 		lds_frag[Lay::sel * 64 + tid] = v;
 	}
 	__syncthreads();
-	// The fragment reads are loop-invariant, and left alone the compiler hoists all of them out of the trip loop (136 registers,
-	// spilled to scratch).  An opaque per-trip lane offset keeps each read next to its use.
-	uint32_t lane_off = lane * 16;
-	auto frag = [&](const int slot) -> h8 { return *(const h8*)(smem + lane_off + slot * 1024); };
-
-	f4 wacc[Lay::n_tiles];
+	{
+		// the output-row permutation (see n_r): position rho = 4 q + r of the output tile <-> output pi(rho) = q + 4 r.
+		//   forward fragments of Wout (A rows = output positions): lane (rho, qq) takes the row of lane (pi(rho), qq);
+		//   fragments of Wout^T (k = output position, chain order: element j < 4 of lane quarter qq is position 4 qq + j, the
+		//   elements 4..7 are the zero padding of 16 outputs to a k-step of 32): element j takes output qq + 4 j = the original
+		//   element qq of lane quarter j.
+		h8 v = h8{0, 0, 0, 0, 0, 0, 0, 0};
+		const bool mine = tid < (KS + T) * 64;
+		const uint32_t which = tid >> 6; // 0 .. KS - 1: forward k-steps; KS .. KS + T - 1: Wout^T row tiles
+		if (mine) {
+			if (which < (uint32_t)KS) {
+				v = lds_frag[(Lay::fwd_out + which) * 64 + ((c >> 2) + 4 * (c & 3)) + 16 * q];
+			} else {
+				const half_t* src = (const half_t*)(lds_frag + (Lay::bwd_out + which - KS) * 64);
 #pragma unroll
-	for (int i = 0; i < Lay::n_tiles; ++i) wacc[i] = f4{0, 0, 0, 0};
-	float loss_sum = 0.0f;
-
-	const uint32_t n_blocks = a.n / 16;
-	const uint32_t first = blockIdx.x * REGS_NW + wave, step = gridDim.x * REGS_NW;
-	const uint32_t n_total = a.n * a.dims; // loss normalisation (relative_l2.h:58)
-	const uint32_t in_w = 16 * IN_T;
-	// outputs live in rows 4 q + r of the output tile: r < max_r covers every row < dims
-	const uint32_t max_r = a.dims >= 4 ? 4 : a.dims;
-
-	// 8 consecutive input features 8 q .. 8 q + 7 of one sample: the B operand of layer 0 (natural k order)
-	auto load_x = [&](const uint32_t sample) -> h8 {
-		const uint32_t k0 = 8 * q;
-		if (IN_T == 1 && q >= 2) return h8{0, 0, 0, 0, 0, 0, 0, 0};
-		if (a.x_plane_f == 2) {
-			uint4 v;
-			v.x = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 0) * a.n + sample) * 2);
-			v.y = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 1) * a.n + sample) * 2);
-			v.z = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 2) * a.n + sample) * 2);
-			v.w = *(const uint32_t*)(a.x + ((size_t)(k0 / 2 + 3) * a.n + sample) * 2);
-			return __builtin_bit_cast(h8, v);
-		} else if (a.x_plane_f == 4) {
-			const uint2 lo = *(const uint2*)(a.x + ((size_t)(k0 / 4) * a.n + sample) * 4);
-			const uint2 hi = *(const uint2*)(a.x + ((size_t)(k0 / 4 + 1) * a.n + sample) * 4);
-			uint4 v;
-			v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
-			return __builtin_bit_cast(h8, v);
-		} else if (a.x_plane_f == 8) {
-			return *(const h8*)(a.x + ((size_t)(k0 / 8) * a.n + sample) * 8);
-		}
-		return *(const h8*)(a.x + (size_t)sample * in_w + k0);
-	};
-	// per-lane side inputs of a trip: targets (and pdf) of output rows 4 q + r, the sample's coordinates for the scatter records.
-	// Loads are unconditional at clamped addresses (rows >= dims re-read row 0 and are masked where they are used): no divergent
-	// branches around single loads.
-	struct Aux { float t[4], pdf[4], xs[3]; h4 dy; };
-	auto load_aux = [&](const uint32_t sample) -> Aux {
-		Aux r;
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const uint32_t j = 4 * q + i;
-			const uint32_t idx = sample * a.dims + (j < a.dims ? j : 0u);
-			r.t[i] = 0.0f;
-			r.pdf[i] = 1.0f;
-			if constexpr (LOSS != 0) {
-				if (i < (int)max_r) { // wave-uniform
-					r.t[i] = a.target[idx];
-					if (a.data_pdf) r.pdf[i] = a.data_pdf[idx];
-				}
+				for (int j = 0; j < 4; ++j) v[j] = src[(c + 16 * j) * 8 + q];
 			}
 		}
-		r.xs[0] = r.xs[1] = r.xs[2] = 0.0f;
-		if (a.rec_x) { // wave-uniform
-			r.xs[0] = a.rec_x[(size_t)sample * a.rec_dims];
-			r.xs[1] = a.rec_x[(size_t)sample * a.rec_dims + 1];
-			if (a.rec_dims > 2) r.xs[2] = a.rec_x[(size_t)sample * a.rec_dims + 2];
-		}
-		if constexpr (LOSS == 0) r.dy = *(const h4*)(a.ext_dy + (size_t)sample * 16 + 4 * q);
-		else r.dy = h4{0, 0, 0, 0};
-		return r;
-	};
-
-	// The next trip's inputs are requested at the START of a trip, ahead of this trip's stores: vmcnt retires in issue order, so a
-	// load issued behind the stores would also wait for their write acknowledgements.
-	h8 pre_x = h8{0, 0, 0, 0, 0, 0, 0, 0};
-	Aux pre_aux{};
-	if (first < n_blocks) {
-		pre_x = load_x(first * 16 + c);
-		pre_aux = load_aux(first * 16 + c);
+		__syncthreads();
+		if (mine) lds_frag[(which < (uint32_t)KS ? Lay::fwd_out + which : Lay::bwd_out + which - KS) * 64 + lane] = v;
 	}
+	__syncthreads();
+	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
+	unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_prev = 0;
+#define TCNN_PHASE(i) do { if constexpr (PHASES) { const unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - ph_prev; ph_prev = now_; } } while (0)
+	// [sample][feature] tiles by selection products.  sel 0 / 1: chain-order fragment -> tile of parity 0 / 1 of its k-step; sel 2 / 3:
+	// natural-order fragment -> tile 0 / 1
+	auto transpose_chain = [&](const h8 f, const int parity) -> h4 { return to_h4(mfma(f, frag(Lay::sel + parity), f4{0, 0, 0, 0})); };
+	auto transpose_natural = [&](const h8 f, const int tile) -> h4 { return to_h4(mfma(f, frag(Lay::sel + 2 + tile), f4{0, 0, 0, 0})); };
 
 	for (uint32_t blk = first; blk < n_blocks; blk += step) {
+		if constexpr (PHASES) ph_prev = __builtin_readcyclecounter();
 		asm volatile("" : "+v"(lane_off));
-		const uint32_t sample = blk * 16 + c;
 		const h8 bx = pre_x;
 		const Aux aux = pre_aux;
-		if (blk + step < n_blocks) {
-			pre_x = load_x((blk + step) * 16 + c);
-			pre_aux = load_aux((blk + step) * 16 + c);
+		{ // unconditionally (the last trip re-reads its own block): a branch here would cost the counted wait, see FAST
+			const uint32_t next = min(blk + step, n_blocks - 1);
+			pre_x = load_x(next);
+			pre_aux = load_aux(next);
 		}
 
-		// =============================================================== forward chain
+		// =============================================================== forward chain.  The [sample][feature] copies of the inputs
+		// of every layer (B operands of the weight-gradient products) are formed as soon as their source exists: they do not depend
+		// on the loss, whose long scalar-style arithmetic they then overlap.
 		f4 acc[T];
 #pragma unroll
 		for (int t = 0; t < T; ++t) acc[t] = mfma(frag(Lay::fwd0 + t), bx, f4{0, 0, 0, 0});
-		h8 hf[NH][KS]; // post-activation hidden layers as chain fragments (kept for the backward pass and the weight gradients)
+		h4 px[IN_T];
+#pragma unroll
+		for (int tc = 0; tc < IN_T; ++tc) px[tc] = transpose_natural(bx, tc);
+		h8 hf[NH][KS];   // post-activation hidden layers as chain fragments (kept for the backward pass)
+		h4 ph_t[NH][T];  // ... and as [sample][feature] tiles
 		auto finish = [&](const int l) {
 			h4 v[T];
 #pragma unroll
-			for (int t = 0; t < T; ++t) {
-				v[t] = to_h4(acc[t]);
-#pragma unroll
-				for (int r = 0; r < 4; ++r) v[t][r] = act_fwd_t<ACT>(d.activation, v[t][r]);
-			}
+			for (int t = 0; t < T; ++t) v[t] = act_fwd_tile<ACT>(to_h4(acc[t]));
 #pragma unroll
 			for (int s = 0; s < KS; ++s) hf[l][s] = join(v[2 * s], v[2 * s + 1]);
 		};
@@ -203,65 +333,70 @@ __global__ void __launch_bounds__(REGS_NW * 64, 2) k_mlp_train_regs(const MlpDes
 				acc[t] = mfma(frag(Lay::fwd_hidden(l) + t * KS + 0), hf[l - 1][0], f4{0, 0, 0, 0});
 				acc[t] = mfma(frag(Lay::fwd_hidden(l) + t * KS + 1), hf[l - 1][1], acc[t]);
 			}
+#pragma unroll
+			for (int tc = 0; tc < T; ++tc) ph_t[l - 1][tc] = transpose_chain(hf[l - 1][tc / 2], tc & 1);
 			finish(l);
 		}
 
+		TCNN_PHASE(0);
 		// =============================================================== output layer + loss on the accumulator tile
-		h4 gv; // dL/d(pre-activation output), rows 4 q + r
+		h4 gv = h4{0, 0, 0, 0}; // dL/d(pre-activation output), outputs q + 4 r
 		{
 			f4 o = mfma(frag(Lay::fwd_out + 0), hf[NH - 1][0], f4{0, 0, 0, 0});
 			o = mfma(frag(Lay::fwd_out + 1), hf[NH - 1][1], o);
+#pragma unroll
+			for (int tc = 0; tc < T; ++tc) ph_t[NH - 1][tc] = transpose_chain(hf[NH - 1][tc / 2], tc & 1);
 			const h4 ov = to_h4(o); // output activation None (mlp_train_regs_supported)
 			if constexpr (LOSS == 0) {
 				gv = aux.dy;
 			} else {
-				float lv[4] = {0, 0, 0, 0};
-				gv = h4{0, 0, 0, 0};
-#pragma unroll
-				for (int r = 0; r < 4; ++r) { // l2.h:40-74 / relative_l2.h:40-75
-					if (r < (int)max_r) { // wave-uniform
-						const float prediction = (float)ov[r];
-						const float difference = prediction - aux.t[r];
-						float value, gradient;
-						if constexpr (LOSS == 2) {
-							const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-							value = difference * difference / prediction_sq_plus_epsilon;
-							gradient = 2 * difference / prediction_sq_plus_epsilon;
-						} else {
-							value = difference * difference;
-							gradient = 2 * difference;
-						}
-						if (a.data_pdf) { // wave-uniform; a division by 1 changes nothing
-							value = value / aux.pdf[r];
-							gradient = gradient / aux.pdf[r];
-						}
-						value = value / n_total;
-						const half_t grad = (half_t)(a.loss_scale * gradient / n_total);
-						const bool live = 4 * q + r < a.dims;
-						lv[r] = live ? value : 0.0f;
-						gv[r] = live ? grad : (half_t)0.0f;
+				// l2.h:40-74 / relative_l2.h:40-75, the same operations in the same order.  Values and gradients of the live
+				// outputs go to the compact context matrices [n][dims].
+				char* gb = (char*)a.dL_dout + (size_t)blk * (32 * a.dims);
+				char* lb = (char*)a.L + (size_t)blk * (64 * a.dims);
+				auto loss_row = [&](const int r) {
+					const float prediction = (float)ov[r];
+					const float difference = prediction - aux.t[r];
+					const float pdf = aux.pdf[r];
+					float value, gradient;
+					if constexpr (LOSS == 2) {
+						const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
+						value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total; // pdf = 1 without data_pdf: exact
+						gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
+					} else {
+						value = difference * difference / pdf / n_total;
+						gradient = 2 * difference / pdf;
 					}
+					const half_t grad = (half_t)(a.loss_scale * gradient / n_total);
+					const bool live = q + 4 * r < a.dims;
+					gv[r] = live ? grad : (half_t)0.0f;
+					if (live) st32(gb + 8 * r, cg_off, grad);
+					if (live) st32(lb + 16 * r, 2 * cg_off, value);
+				};
+				loss_row(0);
+				if (n_r > 1) { // wave-uniform, rare: more than 4 outputs
+#pragma unroll
+					for (int r = 1; r < 4; ++r) loss_row(r);
 				}
-				loss_sum += (lv[0] + lv[1]) + (lv[2] + lv[3]);
-				if (a.L) *(f4*)(a.L + (size_t)sample * 16 + 4 * q) = f4{lv[0], lv[1], lv[2], lv[3]};
-				if (a.dL_dout) *(h4*)(a.dL_dout + (size_t)sample * 16 + 4 * q) = gv;
 			}
-			if (a.out) *(h4*)(a.out + (size_t)sample * 16 + 4 * q) = ov;
+			if (has_out) { // [n][16]: this lane holds the columns q, q + 4, q + 8, q + 12 of its sample's row
+				char* ob = (char*)a.out + (size_t)blk * 512;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) st32(ob + 8 * r, o_off, ov[r]);
+			}
 		}
-		const h8 dyf = join(gv, h4{0, 0, 0, 0}); // B fragment of the first backward product (k = output index, 16 of 32 used)
+		const h8 dyf = join(gv, h4{0, 0, 0, 0}); // B fragment of the first backward product (k = output position, 16 of 32 used)
 
-		// [sample][feature] tiles by selection products.  sel 0 / 1: chain-order fragment -> tile of parity 0 / 1 of its k-step
-		auto transpose_chain = [&](const h8 f, const int parity) -> h4 { return to_h4(mfma(f, frag(Lay::sel + parity), f4{0, 0, 0, 0})); };
-		auto transpose_natural = [&](const h8 f, const int tile) -> h4 { return to_h4(mfma(f, frag(Lay::sel + 2 + tile), f4{0, 0, 0, 0})); };
-
+		TCNN_PHASE(1);
 		// =============================================================== dWout = dY^T H_last   (slots after the hidden ones)
 		constexpr int W_OUT = T * IN_T + (NH - 1) * T * T;
-		if (a.slabs) {
+		{
 			const h4 pa = transpose_chain(dyf, 0);
 #pragma unroll
-			for (int tc = 0; tc < T; ++tc) wacc[W_OUT + tc] = mfma16(pa, transpose_chain(hf[NH - 1][tc / 2], tc & 1), wacc[W_OUT + tc]);
+			for (int tc = 0; tc < T; ++tc) wacc[W_OUT + tc] = mfma16(pa, ph_t[NH - 1][tc], wacc[W_OUT + tc]);
 		}
 
+		TCNN_PHASE(2);
 		// =============================================================== backward chain
 #pragma unroll
 		for (int t = 0; t < T; ++t) acc[t] = mfma(frag(Lay::bwd_out + t), dyf, f4{0, 0, 0, 0});
@@ -273,130 +408,131 @@ __global__ void __launch_bounds__(REGS_NW * 64, 2) k_mlp_train_regs(const MlpDes
 				h4 g[T];
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
-					g[t] = to_h4(acc[t]);
-#pragma unroll
-					for (int r = 0; r < 4; ++r) g[t][r] = act_bwd_t<ACT>(d.activation, g[t][r], hf[l][t / 2][(t & 1) * 4 + r]);
+					const h8 f = hf[l][t / 2];
+					const h4 fwd = (t & 1) ? h4{f[4], f[5], f[6], f[7]} : h4{f[0], f[1], f[2], f[3]};
+					g[t] = act_bwd_tile<ACT>(to_h4(acc[t]), fwd);
 				}
 #pragma unroll
 				for (int s = 0; s < KS; ++s) gf[s] = join(g[2 * s], g[2 * s + 1]);
 			}
-			if (a.slabs) { // dW_l = dH_l^T In_l
-				if (l > 0) {
-					h4 pb[T];
+			// dW_l = dH_l^T In_l
+			if (l > 0) {
 #pragma unroll
-					for (int tc = 0; tc < T; ++tc) pb[tc] = transpose_chain(hf[l - 1][tc / 2], tc & 1);
+				for (int tr = 0; tr < T; ++tr) {
+					const h4 pa = transpose_chain(gf[tr / 2], tr & 1);
 #pragma unroll
-					for (int tr = 0; tr < T; ++tr) {
-						const h4 pa = transpose_chain(gf[tr / 2], tr & 1);
-#pragma unroll
-						for (int tc = 0; tc < T; ++tc) {
-							const int slot = T * IN_T + (l - 1) * T * T + tr * T + tc;
-							wacc[slot] = mfma16(pa, pb[tc], wacc[slot]);
-						}
-					}
-				} else {
-					h4 pb[IN_T];
-#pragma unroll
-					for (int tc = 0; tc < IN_T; ++tc) pb[tc] = transpose_natural(bx, tc);
-#pragma unroll
-					for (int tr = 0; tr < T; ++tr) {
-						const h4 pa = transpose_chain(gf[tr / 2], tr & 1);
-#pragma unroll
-						for (int tc = 0; tc < IN_T; ++tc) wacc[tr * IN_T + tc] = mfma16(pa, pb[tc], wacc[tr * IN_T + tc]);
+					for (int tc = 0; tc < T; ++tc) {
+						const int slot = T * IN_T + (l - 1) * T * T + tr * T + tc;
+						wacc[slot] = mfma16(pa, ph_t[l - 1][tc], wacc[slot]);
 					}
 				}
-			}
-			if (l > 0) {
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
 					acc[t] = mfma(frag(Lay::bwd_hidden(l) + t * KS + 0), gf[0], f4{0, 0, 0, 0});
 					acc[t] = mfma(frag(Lay::bwd_hidden(l) + t * KS + 1), gf[1], acc[t]);
 				}
+			} else {
+#pragma unroll
+				for (int tr = 0; tr < T; ++tr) {
+					const h4 pa = transpose_chain(gf[tr / 2], tr & 1);
+#pragma unroll
+					for (int tc = 0; tc < IN_T; ++tc) wacc[tr * IN_T + tc] = mfma16(pa, px[tc], wacc[tr * IN_T + tc]);
+				}
 			}
 		}
 
+		TCNN_PHASE(3);
 		// =============================================================== dX = W0^T dH_0
-		if (a.dL_dx) {
+		if (has_dx) {
 #pragma unroll
 			for (int ti = 0; ti < IN_T; ++ti) {
 				f4 o = mfma(frag(Lay::bwd0 + ti * KS + 0), gf[0], f4{0, 0, 0, 0});
 				o = mfma(frag(Lay::bwd0 + ti * KS + 1), gf[1], o);
 				const h4 v = to_h4(o);
-				if (a.rec_x) store_dx_record(a.dL_dx, a.dx_plane_f, a.rec_dims, a.n, sample, 16 * ti + 4 * q, v, aux.xs);
-				else store_dx(a.dL_dx, a.dx_plane_f, a.n, in_w, sample, 16 * ti + 4 * q, v);
+				char* base = (char*)a.dL_dx + (size_t)blk * dx_blk + (size_t)ti * dx_tile;
+				const uint2 g = __builtin_bit_cast(uint2, v);
+				if (dx_rec) { // scatter records (mlp_device.h store_dx_record)
+					typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+					const uint32_t x0 = __builtin_bit_cast(uint32_t, aux.xs[0]), x1 = __builtin_bit_cast(uint32_t, aux.xs[1]), x2 = __builtin_bit_cast(uint32_t, aux.xs[2]);
+					if (dx_second) {
+						st32(base, dx_off, u4{x0, x1, x2, g.x});
+						st32(base + dx_second, dx_off, u4{x0, x1, x2, g.y});
+					} else {
+						st32(base, dx_off, u4{x0, x1, g.x, g.y});
+					}
+				} else if (dx_second) {
+					st32(base, dx_off, g.x);
+					st32(base + dx_second, dx_off, g.y);
+				} else {
+					st32(base, dx_off, g);
+				}
 			}
 		}
+		TCNN_PHASE(4);
 	}
-
-	// ---- loss: lanes -> wave -> workgroup in a fixed order
-	if (a.loss_sums) {
-		float s = loss_sum;
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-		__syncthreads(); // everyone is done with the fragments
-		float* red = (float*)smem;
-		if (lane == 0) red[wave] = s;
-		__syncthreads();
-		if (tid == 0) {
-			float t = 0.0f;
-			for (int w = 0; w < REGS_NW; ++w) t += red[w];
-			a.loss_sums[blockIdx.x] = t;
+#undef TCNN_PHASE
+	if constexpr (PHASES) {
+		if (a.dbg && tid == 0) {
+			for (int i = 0; i < 5; ++i) a.dbg[(size_t)gridDim.x * (4 + REGS_NW) + blockIdx.x * 8 + i] = ph[i];
 		}
 	}
-	if (!a.slabs) return;
 
-	// ---- weight gradients: fixed tree over the 8 waves through LDS (the upper half writes, the lower half adds), then the
-	// sum goes to LDS in parameter order and out to the workgroup's slab with dense 16-byte stores
-	f4* region = (f4*)smem; // [4][n_tiles][64]
+	if (a.dbg && lane == 0) a.dbg[gridDim.x * 4 + blockIdx.x * REGS_NW + wave] = __builtin_readcyclecounter();
+	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
+
+	// ---- weight gradients: 8 waves -> 4 -> the slab, through LDS regions that lie BEHIND the fragments (a wave that is done
+	// dumps its accumulators without waiting for anybody).  Fixed order of additions: bitwise reproducible.
+	//   round A: waves 4..7 dump, waves 0..3 add region w;   then wave w sums the four regions for the tiles i = w (mod 8) and
+	//   stores them into the workgroup's slab.
+	f4* region = (f4*)(smem + (Lay::n_frags + 4) * 1024); // [4][n_tiles][64]
+	if (wave >= 4) {
+		f4* dst = region + (size_t)(wave - 4) * Lay::n_tiles * 64 + lane;
+#pragma unroll
+		for (int i = 0; i < Lay::n_tiles; ++i) dst[i * 64] = wacc[i];
+	}
 	__syncthreads();
+	if (wave < 4) {
+		f4* reg = region + (size_t)wave * Lay::n_tiles * 64 + lane;
 #pragma unroll
-	for (int half = REGS_NW / 2; half >= 1; half >>= 1) {
-		if (wave >= (uint32_t)half && wave < 2u * half) {
-			f4* dst = region + (size_t)(wave - half) * Lay::n_tiles * 64 + lane;
-#pragma unroll
-			for (int i = 0; i < Lay::n_tiles; ++i) dst[i * 64] = wacc[i];
+		for (int i = 0; i < Lay::n_tiles; ++i) {
+			const f4 v = reg[i * 64];
+			reg[i * 64] = f4{wacc[i][0] + v[0], wacc[i][1] + v[1], wacc[i][2] + v[2], wacc[i][3] + v[3]}; // own lane's slot: no hazard
 		}
-		__syncthreads();
-		if (wave < (uint32_t)half) {
-			const f4* src = region + (size_t)wave * Lay::n_tiles * 64 + lane;
-#pragma unroll
-			for (int i = 0; i < Lay::n_tiles; ++i) {
-				const f4 v = src[i * 64];
-				wacc[i] = f4{wacc[i][0] + v[0], wacc[i][1] + v[1], wacc[i][2] + v[2], wacc[i][3] + v[3]};
-			}
-		}
-		__syncthreads();
 	}
-	float* flat = (float*)smem;
-	if (wave == 0) {
-		// tile (row tile tr, column tile tc) of a matrix with `cols` columns: lane (c, q) holds rows 16 tr + 4 q + r of column 16 tc + c
-		auto put = [&](const f4& v, const uint32_t w_off, const uint32_t cols, const int tr, const int tc) {
+	__syncthreads();
+	{
+		float* slab = a.slabs + (size_t)blockIdx.x * a.n_params;
+		// tile (row tile tr, column tile tc) of a matrix with `cols` columns: lane (c, q) holds rows 16 tr + 4 q + r of column
+		// 16 tc + c -- of the output layer: output q + 4 r (the row permutation above)
+		auto finish_tile = [&](const int i, const uint32_t w_off, const uint32_t cols, const int tr, const int tc, const bool out_layer) {
+			if ((uint32_t)(i % REGS_NW) != wave) return; // wave-uniform
+			const f4* src = region + (size_t)i * 64 + lane;
+			const f4 r0 = src[0], r1 = src[(size_t)Lay::n_tiles * 64], r2 = src[(size_t)2 * Lay::n_tiles * 64], r3 = src[(size_t)3 * Lay::n_tiles * 64];
 #pragma unroll
-			for (int r = 0; r < 4; ++r) flat[w_off + (16 * tr + 4 * q + r) * cols + 16 * tc + c] = v[r];
+			for (int r = 0; r < 4; ++r) {
+				const uint32_t row = out_layer ? q + 4 * r : 16 * tr + 4 * q + r;
+				slab[w_off + row * cols + 16 * tc + c] = (r0[r] + r1[r]) + (r2[r] + r3[r]);
+			}
 		};
 #pragma unroll
 		for (int tr = 0; tr < T; ++tr)
 #pragma unroll
-			for (int tc = 0; tc < IN_T; ++tc) put(wacc[tr * IN_T + tc], d.layers[0].w_off, 16 * IN_T, tr, tc);
+			for (int tc = 0; tc < IN_T; ++tc) finish_tile(tr * IN_T + tc, d.layers[0].w_off, 16 * IN_T, tr, tc, false);
 #pragma unroll
 		for (int l = 1; l < NH; ++l)
 #pragma unroll
 			for (int tr = 0; tr < T; ++tr)
 #pragma unroll
-				for (int tc = 0; tc < T; ++tc) put(wacc[T * IN_T + (l - 1) * T * T + tr * T + tc], d.layers[l].w_off, 64, tr, tc);
+				for (int tc = 0; tc < T; ++tc) finish_tile(T * IN_T + (l - 1) * T * T + tr * T + tc, d.layers[l].w_off, 64, tr, tc, false);
 #pragma unroll
-		for (int tc = 0; tc < T; ++tc) put(wacc[T * IN_T + (NH - 1) * T * T + tc], d.layers[NH].w_off, 64, 0, tc);
+		for (int tc = 0; tc < T; ++tc) finish_tile(T * IN_T + (NH - 1) * T * T + tc, d.layers[NH].w_off, 64, 0, tc, true);
 	}
-	__syncthreads();
-	f4* slab = (f4*)(a.slabs + (size_t)blockIdx.x * a.n_params);
-	for (uint32_t i = tid; i < a.n_params / 4; i += REGS_NW * 64) slab[i] = ((const f4*)flat)[i];
+	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
 }
 
 template <int IN_T, int NH> uint32_t regs_lds_bytes() {
 	using Lay = RegsLayout<IN_T, NH>;
-	const uint32_t frags = (Lay::n_frags + 4) * 1024;
-	const uint32_t tree = (REGS_NW / 2) * Lay::n_tiles * 1024;
-	return std::max(frags, tree);
+	return (Lay::n_frags + 4) * 1024 + (REGS_NW / 2) * Lay::n_tiles * 1024; // fragments, then the regions of the final reduction
 }
 
 template <int IN_T, int NH> bool regs_layout_matches(const MlpDesc& d) {
@@ -420,12 +556,32 @@ template <int IN_T, int NH> void launch_regs(hipStream_t stream, const MlpDesc& 
 		HIP_CHECK_THROW(hipGetLastError());
 	};
 	const bool relu = d.activation == (uint32_t)Activation::ReLU;
+	constexpr int RELU = (int)Activation::ReLU, NONE = (int)Activation::None;
+	// the compile-time formats of k_mlp_train_regs<FAST> (TCNN_AMD_MLP_FAST=0: the general form, for A/B runs and tests)
+	const char* fast_env = getenv("TCNN_AMD_MLP_FAST");
+	const bool fast = !(fast_env && fast_env[0] == '0') && loss != 0 && relu && a.x_plane_f == 2 && a.dims <= 4 && a.data_pdf == nullptr && a.out != nullptr && a.dL_dx != nullptr &&
+	                  a.rec_x != nullptr && a.rec_dims == 2 && a.dx_plane_f == 2;
+	if constexpr (IN_T == 2 && NH == 2) {
+		static const bool phases = getenv("TCNN_AMD_MLP_TIMING") && getenv("TCNN_AMD_MLP_TIMING")[0] == '2';
+		if (phases && a.dbg && fast && loss == 2) return go(k_mlp_train_regs<IN_T, NH, RELU, 2, true, true>);
+	}
+	if (fast) return loss == 1 ? go(k_mlp_train_regs<IN_T, NH, RELU, 1, true>) : go(k_mlp_train_regs<IN_T, NH, RELU, 2, true>);
 #define TCNN_REGS_CASE(L_) \
-	if (loss == L_) { if (relu) go(k_mlp_train_regs<IN_T, NH, (int)Activation::ReLU, L_>); else go(k_mlp_train_regs<IN_T, NH, (int)Activation::None, L_>); return; }
+	if (loss == L_) return relu ? go(k_mlp_train_regs<IN_T, NH, RELU, L_, false>) : go(k_mlp_train_regs<IN_T, NH, NONE, L_, false>);
 	TCNN_REGS_CASE(0)
 	TCNN_REGS_CASE(1)
 	TCNN_REGS_CASE(2)
 #undef TCNN_REGS_CASE
+}
+
+// compact context matrices -> the reference's padded ones: dL_dout [n][16] halves, L [n][16] floats, zero beyond `dims`
+__global__ void __launch_bounds__(256) k_expand_context(const uint32_t n, const uint32_t dims, const half_t* __restrict__ cg, const float* __restrict__ cl, half_t* __restrict__ dL_dout,
+                                                        float* __restrict__ L) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n * 16) return;
+	const uint32_t s = i >> 4, j = i & 15;
+	dL_dout[i] = j < dims ? cg[s * dims + j] : (half_t)0.0f;
+	L[i] = j < dims ? cl[s * dims + j] : 0.0f;
 }
 
 } // namespace
@@ -437,7 +593,7 @@ static bool regs_enabled() {
 }
 
 bool mlp_train_regs_supported(const MlpDesc& d, uint32_t n) {
-	if (!regs_enabled() || n == 0 || n % 16 != 0) return false;
+	if (!regs_enabled() || n == 0 || n % 16 != 0 || n > (1u << 22)) return false; // 32-bit byte offsets into [n][...] matrices
 	return regs_layout_matches<2, 2>(d) || regs_layout_matches<1, 2>(d) || regs_layout_matches<2, 1>(d) || regs_layout_matches<1, 1>(d);
 }
 
@@ -447,19 +603,59 @@ uint32_t mlp_train_regs_grid(const MlpDesc& d, uint32_t n) {
 }
 
 void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
-                    const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, float* loss_sums, void* dL_dx,
+                    const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* compact_dL_dout, float* compact_L, void* dL_dx,
                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params) {
 	CHECK_THROW(mlp_train_regs_supported(d, n));
 	CHECK_THROW(external_dL_dy != nullptr || (target != nullptr && (loss == LossType::L2 || loss == LossType::RelativeL2)));
-	CHECK_THROW(n_params % 4 == 0);
-	RegsArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)dL_dout, L, loss_sums, (half_t*)dL_dx, slabs, (const h8*)image,
-	           dx_record_x, n, dims, dx_record_dims, x_plane_features, dx_plane_features, n_params, loss_scale};
+	CHECK_THROW(slabs != nullptr && dims >= 1 && dims <= 16);
+	CHECK_THROW(external_dL_dy || (compact_dL_dout != nullptr && compact_L != nullptr));
+	RegsArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)compact_dL_dout, compact_L, (half_t*)dL_dx, slabs, (const h8*)image,
+	           dx_record_x, n, dims, dx_record_dims, x_plane_features, dx_plane_features, n_params, loss_scale, nullptr};
 	const int loss_id = external_dL_dy ? 0 : (loss == LossType::L2 ? 1 : 2);
 	const uint32_t grid = mlp_train_regs_grid(d, n);
-	if (regs_layout_matches<2, 2>(d)) return launch_regs<2, 2>(stream, d, a, grid, loss_id);
-	if (regs_layout_matches<1, 2>(d)) return launch_regs<1, 2>(stream, d, a, grid, loss_id);
-	if (regs_layout_matches<2, 1>(d)) return launch_regs<2, 1>(stream, d, a, grid, loss_id);
-	return launch_regs<1, 1>(stream, d, a, grid, loss_id);
+	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
+	static int timing_left = 5;
+	if (timing && timing_left > 0) {
+		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * (32 + 8 * REGS_NW + 64)));
+		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * (32 + 8 * REGS_NW + 64)));
+	}
+	if (regs_layout_matches<2, 2>(d)) launch_regs<2, 2>(stream, d, a, grid, loss_id);
+	else if (regs_layout_matches<1, 2>(d)) launch_regs<1, 2>(stream, d, a, grid, loss_id);
+	else if (regs_layout_matches<2, 1>(d)) launch_regs<2, 1>(stream, d, a, grid, loss_id);
+	else launch_regs<1, 1>(stream, d, a, grid, loss_id);
+	if (a.dbg) {
+		std::vector<unsigned long long> h((size_t)grid * (4 + REGS_NW + 8));
+		HIP_CHECK_THROW(hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+		if (--timing_left == 0) {
+			double fill = 0, loop = 0, tail = 0, skew = 0;
+			for (uint32_t g = 0; g < grid; ++g) { // last wave's loop end - first wave's loop end
+				const unsigned long long* e = h.data() + (size_t)grid * 4 + (size_t)g * REGS_NW;
+				skew += (double)(*std::max_element(e, e + REGS_NW) - *std::min_element(e, e + REGS_NW));
+			}
+			unsigned long long t_min = ~0ull, t_max = 0;
+			for (uint32_t g = 0; g < grid; ++g) {
+				fill += (double)(h[g * 4 + 1] - h[g * 4]);
+				loop += (double)(h[g * 4 + 2] - h[g * 4 + 1]);
+				tail += (double)(h[g * 4 + 3] - h[g * 4 + 2]);
+				t_min = std::min(t_min, h[g * 4]);
+				t_max = std::max(t_max, h[g * 4 + 3]);
+			}
+			fprintf(stderr, "k_mlp_train_regs wave 0 clocks, mean over %u workgroups: fill %.0f trips %.0f (%u blocks of 16 per wave) tail %.0f (of which the waves' loop ends are spread over %.0f)\n", grid,
+			        fill / grid, loop / grid, div_round_up(n / 16, grid * REGS_NW), tail / grid, skew / grid);
+			(void)t_min; (void)t_max;
+			double p[5] = {0, 0, 0, 0, 0};
+			for (uint32_t g = 0; g < grid; ++g)
+				for (int i = 0; i < 5; ++i) p[i] += (double)h[(size_t)grid * (4 + REGS_NW) + (size_t)g * 8 + i];
+			if (p[0] > 0) fprintf(stderr, "  phases (wave 0, summed over its trips): forward %.0f output+loss %.0f dWout %.0f backward+dW %.0f dX+stores %.0f\n", p[0] / grid, p[1] / grid, p[2] / grid, p[3] / grid, p[4] / grid);
+		}
+		(void)hipFree(a.dbg);
+	}
+}
+
+void mlp_expand_context(hipStream_t stream, uint32_t n, uint32_t dims, const void* compact_dL_dout, const float* compact_L, void* dL_dout, float* L) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_expand_context, dim3(div_round_up(n * 16, 256)), dim3(256), 0, stream, n, dims, (const half_t*)compact_dL_dout, compact_L, (half_t*)dL_dout, L);
+	HIP_CHECK_THROW(hipGetLastError());
 }
 
 } // namespace tcnn_amd

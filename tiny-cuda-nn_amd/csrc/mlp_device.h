@@ -92,19 +92,22 @@ __device__ inline void store_dx(half_t* base, uint32_t plane_f, uint32_t n, uint
 	}
 }
 
-// "Records" for the grid scatter (k_grid_scatter.hip): one 16-byte record per (level, sample) = the sample's D coordinates
-// (floats) followed by its F gradients (halves), so that the scatter fetches everything it needs about a hit with ONE
-// load.  Layout: float4 rec[level][n]; requires 4 D + 2 F <= 16.  v = features k0..k0+3 of sample s.
+// "Records" for the grid scatter (k_grid_scatter.hip): 16-byte records = the sample's D coordinates (floats) followed by
+// gradients (halves), so that the scatter fetches everything it needs about a hit with ONE load.  Requires 4 D + 2 F <= 16.
+//   D = 2, F = 2: float4 rec[level / 2][n] = {x, y, gradients of the even level, gradients of the odd level} (two levels share a record)
+//   D = 3, F = 2: float4 rec[level][n]     = {x, y, z, gradients}
+//   D = 2, F = 4: float4 rec[level][n]     = {x, y, gradients}
+// v = features k0..k0+3 of sample s (k0 a multiple of 4).
 __device__ inline void store_dx_record(half_t* base, uint32_t F, uint32_t D, uint32_t n, uint32_t s, uint32_t k0, h4 v, const float* xs) {
 	typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 	typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 	u4* recs = (u4*)base;
 	const uint32_t x0 = __builtin_bit_cast(uint32_t, xs[0]), x1 = __builtin_bit_cast(uint32_t, xs[1]), x2 = __builtin_bit_cast(uint32_t, xs[2]);
 	const uint32_t lo = __builtin_bit_cast(uint32_t, (h2{v[0], v[1]})), hi = __builtin_bit_cast(uint32_t, (h2{v[2], v[3]}));
-	if (F == 2) {
-		recs[(size_t)(k0 / 2) * n + s] = D == 3 ? u4{x0, x1, x2, lo} : u4{x0, x1, lo, 0u};
-		recs[(size_t)(k0 / 2 + 1) * n + s] = D == 3 ? u4{x0, x1, x2, hi} : u4{x0, x1, hi, 0u};
-	} else { // F == 4, D == 2
+	if (F == 2 && D == 3) {
+		recs[(size_t)(k0 / 2) * n + s] = u4{x0, x1, x2, lo};
+		recs[(size_t)(k0 / 2 + 1) * n + s] = u4{x0, x1, x2, hi};
+	} else { // F == 2, D == 2: levels k0 / 2 and k0 / 2 + 1 = pair k0 / 4;  F == 4, D == 2: level k0 / 4
 		recs[(size_t)(k0 / 4) * n + s] = u4{x0, x1, lo, hi};
 	}
 }

@@ -243,6 +243,7 @@ public:
 	virtual bool as_identity(float& scale, float& offset) const { return false; }
 	// true: backward() (with level planes allowed) prefers 16-byte records {coordinates, gradients} per (level, sample)
 	virtual bool scatter_records_usable(MatView x) const { return false; }
+	virtual uint32_t scatter_record_planes() const { return 0; } // 16-byte records per sample when scatter_records_usable()
 	// > 0: forward_planes() can write the encoded batch as level planes [padded / F][n][F] (no input gradients in that form)
 	virtual uint32_t forward_plane_features(uint32_t n) { return 0; }
 	virtual EncodingContext forward_planes(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out_planes, bool prepare_param_gradients) {
@@ -534,6 +535,8 @@ public:
 		const bool enabled = !(e && e[0] == '0');
 		return enabled && lds_scatter_usable() && !m_any_binned && grid_scatter_records_supported(m_meta) && x.stride_dim == 1 && x.stride_sample == m_meta.n_pos_dims;
 	}
+
+	uint32_t scatter_record_planes() const override { return grid_scatter_record_planes(m_meta); }
 
 	// half precision, F >= 2, and every level's table either cut into at most 64 chunks (the sample filter) or binned
 	bool lds_scatter_usable() const { return !m_fp32 && m_meta.n_features_per_level >= 2 && use_lds_scatter() && m_scatter_levels_ok; }
@@ -1234,7 +1237,7 @@ public:
 		_Float16* g = (_Float16*)gradients;
 		if (ctx.fused) {
 			if (dL_dinput) throw std::runtime_error{"NetworkWithInputEncoding::backward: input gradients were not prepared by forward()"};
-			fused_mlp_and_scatter(stream, ctx, n, input, nullptr, nullptr, dL_doutput, LossType::L2, 1.0f, nullptr, nullptr, nullptr, nullptr, params, gradients, mode);
+			fused_mlp_and_scatter(stream, ctx, n, input, nullptr, nullptr, dL_doutput, LossType::L2, 1.0f, nullptr, nullptr, nullptr, false, nullptr, params, gradients, mode);
 			return;
 		}
 		ArenaBuf dL_dnetwork_input;
@@ -1259,11 +1262,13 @@ public:
 		return v;
 	}
 	bool fused_step_supported(uint32_t n) const { return use_fused_step() && mlp_train_fused_supported(m_network->desc(), n); }
+	// the register-resident fused kernel (k_train_regs.hip) writes dL_doutput / L as compact [n][dims] matrices (TrainContext::compact)
+	bool fused_compact_context_supported(uint32_t n) const { return use_fused_step() && mlp_train_regs_supported(m_network->desc(), n) && m_network->padded_output_width() == 16; }
 
 	// forward + loss + backward of a training step with the MLP part as ONE kernel (k_train.hip): same results as
 	// forward() -> loss_evaluate() -> backward(), activations never leave the CU.  out / dL_dout / L: [n][padded_out].
 	std::unique_ptr<ModelContext> fused_step(hipStream_t stream, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
-	                                         LossType loss, float loss_scale, void* out, void* dL_dout, float* L, MatViewMut* dL_dinput, const void* params,
+	                                         LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, MatViewMut* dL_dinput, const void* params,
 	                                         void* gradients, GradientMode mode) {
 		check_batch(n);
 		auto ctx = std::make_unique<Ctx>();
@@ -1271,7 +1276,7 @@ public:
 		// ~5 us each, independent of the encoding kernels) on a side stream was measured and lost 13-15 us per step on every
 		// workload: a cross-stream event dependency costs more here than the kernels it hides (the same happened with Adam).
 		fused_encode(stream, *ctx, n, input, params, dL_dinput != nullptr, mode != GradientMode::Ignore);
-		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, dL_dinput, params, gradients, mode);
+		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, compact_context, dL_dinput, params, gradients, mode);
 		return ctx;
 	}
 
@@ -1290,7 +1295,8 @@ public:
 	// second half: ONE MLP kernel (forward recomputed in registers, loss or external dL/doutput, backward, weight gradients),
 	// the slab reduction and the encoding's backward pass.  target == nullptr requires external_dL_dy.
 	void fused_mlp_and_scatter(hipStream_t stream, const Ctx& ctx, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
-	                           LossType loss, float loss_scale, void* out, void* dL_dout, float* L, MatViewMut* dL_dinput, const void* params, void* gradients, GradientMode mode) {
+	                           LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, MatViewMut* dL_dinput, const void* params, void* gradients,
+	                           GradientMode mode) {
 		const _Float16* p = (const _Float16*)params;
 		_Float16* g = (_Float16*)gradients;
 		const uint32_t n_net = (uint32_t)m_network->n_params();
@@ -1300,7 +1306,7 @@ public:
 		const uint32_t plane_f = need_dx ? m_encoding->level_plane_features(dL_dinput != nullptr, mode) : 0;
 		// scatter records: the MLP kernel interleaves the samples' coordinates with dL/d(encoding) so that the grid scatter needs one gather per hit
 		const bool records = plane_f > 0 && m_encoding->padded_output_width() == m_encoding->output_width() && m_encoding->scatter_records_usable(input);
-		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, records ? (size_t)n * (m_encoding->output_width() / plane_f) * 16 : (size_t)n * m_encoding->padded_output_width() * 2};
+		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, records ? (size_t)n * m_encoding->scatter_record_planes() * 16 : (size_t)n * m_encoding->padded_output_width() * 2};
 		ctx.encoding_ctx.dy_records = records;
 
 		ArenaBuf image = m_network->prepare(stream, params, true);
@@ -1312,7 +1318,7 @@ public:
 			n_slabs = mlp_train_fused_grid(d, n);
 			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
 		}
-		mlp_train_fused(stream, d, image.data(), n, ctx.network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L,
+		mlp_train_fused(stream, d, image.data(), n, ctx.network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L, compact_context,
 		                dL_dnetwork_input.data(), plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u, slabs.as<float>(), n_net);
 		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
 		if (need_dx) {
@@ -1866,7 +1872,27 @@ struct TrainContext { // Trainer::ForwardContext, trainer.h:89-95
 	ArenaBuf L;           // float [n][padded_out]
 	std::unique_ptr<ModelContext> model_ctx;
 	uint32_t n = 0;
+
+	// Compact form (the register-resident fused MLP kernel, k_train_regs.hip): of the reference's [n][16] matrices dL_doutput and
+	// L only the n_output_dims live columns are non-zero, and at 96 bytes per sample they would be more than a third of what that
+	// kernel stores.  The step writes them dense as [n][dims]; the padded matrices are produced from those on first access
+	// (tcnn_train_ctx_dL_doutput / _L), and loss() sums the compact L.
+	bool compact = false;
+	uint32_t dims = 0, padded_width = 0;
+	hipStream_t stream = nullptr;
+	ArenaBuf compact_dL_doutput; // half  [n][dims]
+	ArenaBuf compact_L;          // float [n][dims]
+	void materialize();
 };
+
+inline void TrainContext::materialize() {
+	if (!compact || L) return;
+	L = ArenaBuf{stream, (size_t)n * padded_width * sizeof(float)};
+	dL_doutput = ArenaBuf{stream, (size_t)n * padded_width * 2};
+	dL_doutput_ptr = dL_doutput.data();
+	CHECK_THROW(padded_width == 16);
+	mlp_expand_context(stream, n, dims, compact_dL_doutput.data(), compact_L.as<float>(), dL_doutput.data(), L.as<float>());
+}
 
 inline MatView make_view(const float* data, uint32_t width, uint32_t n, int layout) {
 	return layout == 1 ? MatView{data, width, 1u} : MatView{data, 1u, n};
@@ -1931,6 +1957,7 @@ public:
 	}
 
 	void backward(hipStream_t stream, const TrainContext& ctx, uint32_t n, MatView input, MatViewMut* dL_dinput, bool use_inference_params, GradientMode mode) { // trainer.h:147-149
+		const_cast<TrainContext&>(ctx).materialize(); // a context of the fused step keeps dL_doutput compact until somebody asks for it
 		m_model->backward(stream, *ctx.model_ctx, n, input, ctx.output.data(), ctx.dL_doutput_ptr, dL_dinput, use_inference_params ? params_inference() : m_params.data(), m_grads.data(), mode);
 	}
 
@@ -1949,17 +1976,28 @@ public:
 			ctx->n = n;
 			const uint32_t pw = m_model->padded_output_width();
 			ctx->output = ArenaBuf{stream, (size_t)n * pw * 2};
-			ctx->L = ArenaBuf{stream, (size_t)n * pw * sizeof(float)};
-			if (external_dL_dy) {
-				ctx->dL_doutput_ptr = external_dL_dy;
-				HIP_CHECK_THROW(hipMemsetAsync(ctx->L.data(), 0, ctx->L.bytes(), stream));
-			} else {
+			ctx->compact = !external_dL_dy && mode != GradientMode::Ignore && m_model->fused_compact_context_supported(n);
+			if (ctx->compact) {
 				CHECK_THROW(target != nullptr);
-				ctx->dL_doutput = ArenaBuf{stream, (size_t)n * pw * 2};
-				ctx->dL_doutput_ptr = ctx->dL_doutput.data();
+				ctx->dims = m_model->output_width();
+				ctx->padded_width = pw;
+				ctx->stream = stream;
+				ctx->compact_dL_doutput = ArenaBuf{stream, (size_t)n * ctx->dims * 2};
+				ctx->compact_L = ArenaBuf{stream, (size_t)n * ctx->dims * sizeof(float)};
+			} else {
+				ctx->L = ArenaBuf{stream, (size_t)n * pw * sizeof(float)};
+				if (external_dL_dy) {
+					ctx->dL_doutput_ptr = external_dL_dy;
+					HIP_CHECK_THROW(hipMemsetAsync(ctx->L.data(), 0, ctx->L.bytes(), stream));
+				} else {
+					CHECK_THROW(target != nullptr);
+					ctx->dL_doutput = ArenaBuf{stream, (size_t)n * pw * 2};
+					ctx->dL_doutput_ptr = ctx->dL_doutput.data();
+				}
 			}
-			ctx->model_ctx = m_model->fused_step(stream, n, input, target, data_pdf, external_dL_dy, m_loss, loss_scale, ctx->output.data(), ctx->dL_doutput.data(),
-			                                     ctx->L.as<float>(), dL_dinput, m_params.data(), m_grads.data(), mode);
+			ctx->model_ctx = m_model->fused_step(stream, n, input, target, data_pdf, external_dL_dy, m_loss, loss_scale, ctx->output.data(),
+			                                     ctx->compact ? ctx->compact_dL_doutput.data() : ctx->dL_doutput.data(),
+			                                     ctx->compact ? ctx->compact_L.as<float>() : ctx->L.as<float>(), ctx->compact, dL_dinput, m_params.data(), m_grads.data(), mode);
 		} else {
 			ctx = forward(stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy);
 			backward(stream, *ctx, n, input, dL_dinput, use_inference_params, mode);
@@ -1971,7 +2009,8 @@ public:
 	float loss(hipStream_t stream, const TrainContext& ctx) { // trainer.h:205-207 + reduce_sum.h:140-151
 		float* partials = m_scalar.as<float>();
 		float* result = partials + 1024;
-		reduce_sum(stream, (size_t)ctx.n * m_model->padded_output_width(), ctx.L.as<float>(), partials, result);
+		if (ctx.compact && !ctx.L) reduce_sum(stream, (size_t)ctx.n * ctx.dims, ctx.compact_L.as<float>(), partials, result); // the padding columns are zeros
+		else reduce_sum(stream, (size_t)ctx.n * m_model->padded_output_width(), ctx.L.as<float>(), partials, result);
 		float host = 0;
 		HIP_CHECK_THROW(hipMemcpyAsync(&host, result, sizeof(float), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK_THROW(hipStreamSynchronize(stream));

@@ -121,8 +121,10 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
                        const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records = false,
                        uint64_t* task_times = nullptr); // task_times (optional): device uint64[n_tasks][8], per-task timestamps for the plan tuner
-// dy_records: dL_dy is float4 [n_levels][n] scatter records {coordinates, F halves} (see mlp_train_fused); x is then not read
+// dy_records: dL_dy is float4 [grid_scatter_record_planes()][n] scatter records {coordinates, gradient halves} (mlp_device.h
+// store_dx_record; D = 2 with F = 2 packs two levels into one record); x is then not read
 bool grid_scatter_records_supported(const GridMeta& meta);
+uint32_t grid_scatter_record_planes(const GridMeta& meta);
 
 // ---- binned form for levels cut into more than 64 chunks (k_grid_bin.hip; GridLevel::scatter_binned): no filter, no gathers.
 // Same exact result as grid_backward_lds; writes every gradient element of the binned levels.  workspace: grid_bin_workspace_bytes().
@@ -201,21 +203,26 @@ bool mlp_train_fused_supported(const MlpDesc& d, uint32_t n);
 uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n); // workgroups = number of weight-gradient slabs
 // x [n][in_width] half (x_plane_features = 0) or level planes [in_width / F][n][F] (x_plane_features = F in {2, 4, 8}).
 // target / data_pdf [n][dims] float or external_dL_dy [n][out_width] half (loss-scaled).
+// compact_context (only where mlp_train_regs_supported() and slabs != nullptr): dL_dout and L are the COMPACT matrices [n][dims]
+// (the live columns of the padded ones; mlp_expand_context pads them), else the padded [n][out_width] ones.
 // Writes out, dL_dout, L ([n][out_width]; dL_dout and L only without external_dL_dy), dL_dx (optional; AoS or level planes),
 // and -- if slabs != nullptr -- one fp32 slab of partial weight gradients per workgroup: slabs[grid][n_params].
-// dx_record_x != nullptr (with dx_plane_features = F): dL_dx is written as 16-byte scatter records float4 [in_width / F][n] =
-// {coordinates (dx_record_dims floats, read from dx_record_x [n][dims]), F halves}; needs 4 dims + 2 F <= 16.
+// dx_record_x != nullptr (with dx_plane_features = F): dL_dx is written as 16-byte scatter records {coordinates (dx_record_dims
+// floats, read from dx_record_x [n][dims]), gradient halves}, float4 [in_width / F][n] or, for 2 dims and F = 2, [in_width / 4][n]
+// with two levels per record (mlp_device.h store_dx_record); needs 4 dims + 2 F <= 16.
 void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
-                     const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, void* dL_dx,
+                     const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, void* dL_dx,
                      uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params);
 // ---- the same step for (16 | 32) -> 64 -> [64 ->] 16 networks with everything in registers (k_train_regs.hip): no LDS images, no
 // barriers, transposes on the matrix cores.  mlp_train_fused* dispatch to it when it applies (TCNN_AMD_MLP_REGS=0: never).
-// loss_sums (optional): float[grid], the sum of the workgroup's loss values (lets callers skip the [n][16] float matrix L).
+// Writes dL_dout and L as compact matrices [n][dims] (96 of the 256 bytes per sample the padded ones would add to the kernel's
+// stores are zeros); mlp_expand_context produces the reference's [n][16] matrices from them.  Requires slabs != nullptr.
 bool mlp_train_regs_supported(const MlpDesc& d, uint32_t n);
 uint32_t mlp_train_regs_grid(const MlpDesc& d, uint32_t n);
 void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
-                    const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, float* loss_sums, void* dL_dx,
+                    const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* compact_dL_dout, float* compact_L, void* dL_dx,
                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params);
+void mlp_expand_context(hipStream_t stream, uint32_t n, uint32_t dims, const void* compact_dL_dout, const float* compact_L, void* dL_dout, float* L);
 // grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once
 void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate);
 // fully_fused_mlp.cu:757-762: result = dL_dout * act'(out), elementwise over n_elems halfs

@@ -38,23 +38,25 @@ class ForwardContext:
         if h and _C is not None and getattr(_C, 'lib', None) is not None:  # modules may already be torn down at exit
             _C.lib.tcnn_train_ctx_destroy(h)
 
-    def _view(self, ptr, dtype, itemsize):
-        # copy the device buffer into a fresh torch tensor (the context owns the original)
+    def _view(self, accessor, dtype, itemsize):
+        # copy the device buffer into a fresh torch tensor (the context owns the original).  The fused step's context pads dL_doutput / L
+        # inside the accessor, on the step's stream: synchronise after the call, not before.
+        ptr = accessor(self._h)
+        if not ptr:
+            raise RuntimeError(_C.lib.tcnn_last_error().decode("utf-8", "replace"))
+        torch.cuda.synchronize()
         out = torch.empty((self.n, self.padded_out), dtype=dtype, device="cuda")
         _C.memcpy_dtod(out.data_ptr(), ptr, self.n * self.padded_out * itemsize)
         return out
 
     def output(self):
-        torch.cuda.synchronize()
-        return self._view(_C.lib.tcnn_train_ctx_output(self._h), torch.half, 2)
+        return self._view(_C.lib.tcnn_train_ctx_output, torch.half, 2)
 
     def dL_doutput(self):
-        torch.cuda.synchronize()
-        return self._view(_C.lib.tcnn_train_ctx_dL_doutput(self._h), torch.half, 2)
+        return self._view(_C.lib.tcnn_train_ctx_dL_doutput, torch.half, 2)
 
     def L(self):
-        torch.cuda.synchronize()
-        return self._view(_C.lib.tcnn_train_ctx_L(self._h), torch.float32, 4)
+        return self._view(_C.lib.tcnn_train_ctx_L, torch.float32, 4)
 
 
 class Trainer:
