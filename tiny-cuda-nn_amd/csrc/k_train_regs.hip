@@ -43,6 +43,7 @@ struct RegsArgs {
 	uint32_t n, dims, rec_dims;
 	uint32_t x_plane_f, dx_plane_f, n_params;
 	float loss_scale;
+	uint32_t prio_mode;      // 1 (default): the waves of a SIMD alternate their priority per trip; 0: no priorities; 2: the younger half at priority 1 (TCNN_AMD_MLP_PRIO, A/B runs)
 	unsigned long long* dbg; // development aid (TCNN_AMD_MLP_TIMING): per workgroup, wave 0's clock at kernel start / first trip / last trip done / end
 };
 
@@ -69,9 +70,12 @@ template <int IN_T, int NH> struct RegsLayout {
 __device__ inline h4 to_h4(const f4 v) { return __builtin_convertvector(v, h4); }
 __device__ inline h8 join(const h4 lo, const h4 hi) { return h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
 
-// hidden activation on a tile, packed (v_pk_max_f16): ReLU(half) = max(x, 0) (common_device.h:92-98); ACT None: identity
+// hidden activation on a tile, packed: ReLU(half) = x > 0 ? x : 0 (common_device.h:92-98).  As a SIGNED INTEGER maximum of the bit
+// patterns (v_pk_max_i16): negative halves, -0 included, are negative integers.  v_pk_max_f16 may return -0 for max(-0, +0), and
+// the backward pass below tells "positive" from "zero" by the bits.  ACT None: identity
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int ACT> __device__ inline h4 act_fwd_tile(const h4 v) {
-	if constexpr (ACT == (int)Activation::ReLU) return __builtin_elementwise_max(v, h4{0, 0, 0, 0});
+	if constexpr (ACT == (int)Activation::ReLU) return __builtin_bit_cast(h4, __builtin_elementwise_max(__builtin_bit_cast(s16x4, v), s16x4{0, 0, 0, 0}));
 	else return v;
 }
 // ... and its derivative from the forward output (common_device.h:241-297): ReLU keeps the gradient where the output is
@@ -296,8 +300,17 @@ __global__ void __launch_bounds__(REGS_NW * 64, 2) k_mlp_train_regs(const MlpDes
 	auto transpose_chain = [&](const h8 f, const int parity) -> h4 { return to_h4(mfma(f, frag(Lay::sel + parity), f4{0, 0, 0, 0})); };
 	auto transpose_natural = [&](const h8 f, const int tile) -> h4 { return to_h4(mfma(f, frag(Lay::sel + 2 + tile), f4{0, 0, 0, 0})); };
 
+	// The two waves of a SIMD (waves w and w + 4) are arbitrated oldest first: left alone the older one takes every contended issue
+	// slot, finishes its trips thousands of clocks before its partner and then waits at the final reduction (measured: the loop
+	// ends of a workgroup's waves spread over a third of the loop time).  Alternating the priority per trip keeps them level.
+	if (a.prio_mode == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+	uint32_t prio_phase = wave >= 4 ? 1u : 0u;
 	for (uint32_t blk = first; blk < n_blocks; blk += step) {
 		if constexpr (PHASES) ph_prev = __builtin_readcyclecounter();
+		if (a.prio_mode != 0 && a.prio_mode != 2) { // wave-uniform
+			if (prio_phase & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+			prio_phase ^= 1u;
+		}
 		asm volatile("" : "+v"(lane_off));
 		const h8 bx = pre_x;
 		const Aux aux = pre_aux;
@@ -610,7 +623,8 @@ void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uin
 	CHECK_THROW(slabs != nullptr && dims >= 1 && dims <= 16);
 	CHECK_THROW(external_dL_dy || (compact_dL_dout != nullptr && compact_L != nullptr));
 	RegsArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)compact_dL_dout, compact_L, (half_t*)dL_dx, slabs, (const h8*)image,
-	           dx_record_x, n, dims, dx_record_dims, x_plane_features, dx_plane_features, n_params, loss_scale, nullptr};
+	           dx_record_x, n, dims, dx_record_dims, x_plane_features, dx_plane_features, n_params, loss_scale, 1u, nullptr};
+	if (const char* e = getenv("TCNN_AMD_MLP_PRIO")) a.prio_mode = (uint32_t)atoi(e);
 	const int loss_id = external_dL_dy ? 0 : (loss == LossType::L2 ? 1 : 2);
 	const uint32_t grid = mlp_train_regs_grid(d, n);
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
