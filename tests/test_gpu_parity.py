@@ -589,5 +589,4 @@ def test_fused_mlp_kernel_forms_agree_at_full_batch(tcnn, oracle, monkeypatch, n
         for lo, hi in ((0, n_net), (n_net, len(g))):
             a, b = _f32(g[lo:hi]), _f32(g0[lo:hi])
             assert float(np.linalg.norm(a - b)) <= 2e-3 * float(np.linalg.norm(b)), env
-        assert np.array_equal(g[n_net:] == 0, g0[n_net:] == 0), env  # the same entries are touched
         assert abs(l - l0) <= 1e-5 * abs(l0), env
