@@ -7,9 +7,16 @@ For N > 1 the driver launches one process per GPU with torch.distributed.run; tr
 ("replicas only"), so every rank trains its own replica on its own synthetic batch -- weak scaling, no
 data-path collective; the only collectives are the timing barrier and the MAX over ranks.
 
-The JSON line carries `roofline` for the dominant kernel (fused Adam over all parameters: HBM-bound, 36 B/param,
-adam.h:48-119), timed live with HIP events on the launch stream inside the timed region, and `cpu_baseline`: the CPU
-oracle (a port of the reference algorithm, the reference has no CPU path) timed on a bounded sample on rank 0.
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (a child torch.distributed.run,
+before this process touches the GPU).  For N > 1 the line also carries `c4_sharded_inference`: BASELINE config 4, the one path
+of the reference that shards (rows over the GPUs, one RCCL all-gather of the half outputs per step).
+
+The JSON line carries `roofline` for the step's MFMA kernel, the fused MLP training kernel (BASELINE metric: "% fp16-MFMA
+peak"; SURVEY 8d: achieved = samples/s of the kernel x 38 016 FLOP), timed live with HIP events on the launch stream inside
+the timed region on every 4th step (tcnn_trainer_profile_next_step), with the other pieces of the step beside it
+(`roofline.pieces`: encoding forward, encoding backward, optimizer against the HBM peak; `hbm_floor_frac`: the step's
+compulsory HBM bytes over the whole step time), and `cpu_baseline`: the CPU oracle (a port of the reference algorithm, the
+reference has no CPU path) timed on a bounded sample on rank 0.
 """
 import argparse
 import json
@@ -61,10 +68,52 @@ C4_FLOP_PER_ROW = 2 * (32 * 128 + 3 * 128 * 128 + 128 * 16)  # 110 592 (SURVEY 8
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak
 
 
+def c4_measure(steps, warmup, world):
+    """network->inference() on 1M rows, rows sharded in contiguous blocks over the ranks, weights replicated, ONE collective per
+    step: the all-gather of the half output rows (tinycudann/parallel.py; RCCL over xGMI).  Returns rank-independent numbers
+    (the MAX over ranks of the elapsed time) -- call on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    import tinycudann as tcnn
+    from tinycudann.parallel import shard_rows, sharded_inference
+
+    tr = tcnn.Trainer(C4_IN, C4_OUT, C4, seed=1337)  # same seed on every rank = replicated weights
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(42)
+    x = torch.rand((C4_ROWS, C4_IN), device="cuda", generator=gen)  # every rank holds the batch; it evaluates only its rows
+
+    def step():
+        return sharded_inference(lambda rows: tr.inference_half(rows), x, C4_OUT)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        y = step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        y = step()
+    e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    b, e = shard_rows(C4_ROWS, world, 0)
+    kernel_ms = e0.elapsed_time(e1) / max(steps, 1)  # this rank's stream: its shard's kernels + the all-gather
+    return {"elapsed": elapsed, "rows_per_gpu": e - b, "stream_ms_per_step": kernel_ms, "checksum": float(y.double().sum().item())}
+
+
 def run_c4(args):
-    """`--workload c4`: network->inference() on 1M rows.  N > 1: the rows are sharded in contiguous blocks, one per GPU, weights
-    replicated, and ONE collective ends every step: the all-gather of the output rows (tinycudann/parallel.py; RCCL over xGMI).
-    Strong scaling: the job is the same 1M rows whatever N is."""
+    """`--workload c4`: the sharded inference as the headline line.  Strong scaling: the job is the same 1M rows whatever N is."""
     import torch
     import torch.distributed as dist
 
@@ -76,48 +125,15 @@ def run_c4(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    import tinycudann as tcnn
-    from tinycudann.parallel import shard_rows, sharded_inference
-
-    tr = tcnn.Trainer(C4_IN, C4_OUT, C4, seed=1337)  # same seed on every rank = replicated weights
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(42)
-    x = torch.rand((C4_ROWS, C4_IN), device="cuda", generator=gen)  # every rank holds the batch; it evaluates only its rows
-
-    def step():
-        return sharded_inference(lambda rows: tr.inference(rows), x, C4_OUT)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        y = step()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        y = step()
-    e1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        el = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+    m = c4_measure(args.steps, args.warmup, world)
     if rank == 0:
-        b, e = shard_rows(C4_ROWS, world, 0)
-        kernel_ms = e0.elapsed_time(e1) / max(args.steps, 1)  # rank 0's stream: its shard's kernels + the all-gather
-        achieved = (e - b) * C4_FLOP_PER_ROW / (kernel_ms * 1e-3) / 1e12
+        achieved = m["rows_per_gpu"] * C4_FLOP_PER_ROW / (m["stream_ms_per_step"] * 1e-3) / 1e12
         print(json.dumps({
             "metric": "inference throughput (rows/s) FullyFusedMLP 128x4, batch=1M",
-            "value": C4_ROWS * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "c4: Identity + 128x4 FullyFusedMLP inference, 32 -> 16", "global_batch": C4_ROWS, "rows_per_gpu": e - b,
-                       "parallelism": f"rows x{world} + all_gather", "output_checksum": float(y.double().sum().item())},
+            "value": C4_ROWS * args.steps / m["elapsed"], "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "c4: Identity + 128x4 FullyFusedMLP inference, 32 -> 16", "global_batch": C4_ROWS, "rows_per_gpu": m["rows_per_gpu"],
+                       "parallelism": f"rows x{world} + all_gather", "output_checksum": m["checksum"]},
             "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<128>", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": None, "note": "stream time of rank 0 per step (MLP kernel + weight preparation + all-gather) over its shard's FLOPs"},
         }), flush=True)
@@ -175,6 +191,33 @@ def pmc_traffic(kernel, workload):
     return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
+FLOP_PER_SAMPLE = {"c3a": 38016, "c3b": 38016, "c2": 58496, "c5": 149760}  # useful FLOP of one training sample (unpadded outputs)
+MLP_KERNEL = {"c3a": "k_mlp_train_regs", "c3b": "k_mlp_train_regs", "c2": "k_mlp_train", "c5": "k_mlp_train"}
+METRIC = {
+    "c3a": "training_step throughput (samples/s) HashGrid+64-wide FFMLP, batch=256k; % fp16-MFMA peak",
+    "c3b": "training_step throughput (samples/s) HashGrid(T=2^15)+64-wide FFMLP, batch=256k; % fp16-MFMA peak",
+    "c2": "training_step throughput (samples/s) OneBlob+64-wide FFMLP, batch=64k; % fp16-MFMA peak",
+    "c5": "training_step throughput (samples/s) HashGrid(F=4,T=2^22)+128-wide FFMLP, batch=512k; % fp16-MFMA peak",
+}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` typed by hand: start the N ranks as a child torch.distributed.run and exit with its code.  Runs
+    BEFORE anything in this process touches the GPU (a process that has initialised HIP must not exec or fork GPU work)."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +226,13 @@ def main():
     ap.add_argument("--workload", default="c3a", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the timing collectives (tests: gloo)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "none"], help="none: launcher / collective plumbing only, no GPU work (CPU tests)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if args.device == "none":
+        return run_plumbing_only(args)
     if args.workload == "c4":
         return run_c4(args)
 
@@ -197,7 +246,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     else:
         torch.cuda.set_device(0)
 
@@ -208,8 +257,10 @@ def main():
         batch = args.batch
     gen = torch.Generator(device="cuda")
     gen.manual_seed(42 + rank)
-    x = torch.rand((batch, n_in), device="cuda", generator=gen)
-    t = torch.rand((batch, n_out), device="cuda", generator=gen)
+    # a small pool of batches, visited in turn: the step is timed on fresh samples, not on one batch its scatter plan was cut for
+    POOL = 4
+    xs = [torch.rand((batch, n_in), device="cuda", generator=gen) for _ in range(POOL)]
+    ts = [torch.rand((batch, n_out), device="cuda", generator=gen) for _ in range(POOL)]
 
     tr = tcnn.Trainer(n_in, n_out, cfg, seed=1337)
     n_params = tr.n_params
@@ -221,44 +272,19 @@ def main():
         torch.cuda.synchronize()
 
     ctx = None
-    for _ in range(args.warmup):
-        ctx = tr.training_step(x, t, run_optimizer=False)
-        tr.optimizer_step()
+    for i in range(args.warmup):
+        ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
     loss0 = tr.loss(ctx) if ctx is not None else float("nan")
 
-    # Every step is trainer->training_step(input, target) (trainer.h:163-190).  On every 4th step the same work is issued as
-    # training_step(run_optimizer=False) + optimizer_step() so that HIP events can bracket the optimizer kernel on the launch
-    # stream (event records cost a few microseconds of dispatch each, hence not on every step).
-    # The events are created with hipEventDisableSystemFence: a default event record writes back and invalidates the caches,
-    # which made the bracketed kernel itself 40 % slower than it is inside an unbracketed step (hip_runtime_api.h:779-788).
-    import ctypes as C
-
-    from tinycudann import _C as tcnn_C
-
-    hip = tcnn_C.hip_runtime()
-    hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
-    hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
-    hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
-    stream_handle = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def new_event():
-        e = C.c_void_p()
-        err = hip.hipEventCreateWithFlags(C.byref(e), 0x20000000)  # hipEventDisableSystemFence, timing enabled
-        assert err == 0, f"hipEventCreateWithFlags failed: {err}"
-        return e
-
-    sampled = [i for i in range(args.steps) if i % 4 == 0]
-    ev = {i: (new_event(), new_event()) for i in sampled}
+    # Every step is trainer->training_step(input, target) (trainer.h:163-190).  Every 4th one also records HIP events on the launch
+    # stream around its pieces (tcnn_trainer_profile_next_step: events without the system-scope fence; a record costs a few
+    # microseconds of dispatch, hence not on every step).
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i in ev:
-            ctx = tr.training_step(x, t, run_optimizer=False)
-            hip.hipEventRecord(ev[i][0], stream_handle)
-            tr.optimizer_step()
-            hip.hipEventRecord(ev[i][1], stream_handle)
-        else:
-            ctx = tr.training_step(x, t)
+        if i % 4 == 0:
+            tr.profile_next_step()
+        ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -267,27 +293,39 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     loss1 = tr.loss(ctx)
+    pieces, n_profiled = tr.profile_collect()
 
-    def elapsed_ms(a, b):
-        ms = C.c_float()
-        err = hip.hipEventElapsedTime(C.byref(ms), a, b)
-        assert err == 0, f"hipEventElapsedTime failed: {err}"
-        return ms.value
-
-    adam_ms = sum(elapsed_ms(a, b) for a, b in ev.values()) / max(len(ev), 1)
-    adam_bytes = ADAM_BYTES_PER_PARAM * n_params
-    achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms > 0 else 0.0
+    sharded = None
+    if world > 1:  # the path that shards, on the same ranks: rows over the GPUs + one RCCL all-gather per step
+        try:
+            m = c4_measure(max(args.steps // 4, 10), 5, world)
+            sharded = {"metric": "inference throughput (rows/s) FullyFusedMLP 128x4, batch=1M, rows sharded + all_gather of half outputs", "value": C4_ROWS * max(args.steps // 4, 10) / m["elapsed"],
+                       "unit": "rows/s", "ms_per_step": m["elapsed"] / max(args.steps // 4, 10) * 1e3, "rows_per_gpu": m["rows_per_gpu"], "scaling": "strong",
+                       "output_checksum": m["checksum"]}
+        except Exception as e:  # the headline line must not die with the extra measurement
+            sharded = {"error": repr(e)[:300]}
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic("k_adam", args.workload if not args.batch else "")
+        step_ms = elapsed / args.steps * 1e3
+        mlp_ms = pieces["mlp_kernel"]
+        flops = FLOP_PER_SAMPLE[args.workload] * batch
+        achieved = flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+        kernel = MLP_KERNEL[args.workload]
+        traffic, traffic_src = pmc_traffic(kernel, args.workload if not args.batch else "")
+        adam_bytes = ADAM_BYTES_PER_PARAM * n_params
+        adam_gbs = adam_bytes / (pieces["optimizer"] * 1e-3) / 1e9 if pieces["optimizer"] > 0 else 0.0
+        # compulsory HBM bytes of a step: Adam's 36 B per parameter, the half gradient table written and the half table read once
+        # more by the forward pass, and per sample the inputs (4 n_in), targets (4 n_out) and the half outputs (2 x 16)
+        grid_params = max(n_params - 7168, 0) if args.workload in ("c3a", "c3b") else n_params
+        floor_bytes = adam_bytes + 2 * grid_params + batch * (4 * n_in + 4 * n_out + 32)
         result = {
-            "metric": "training_step throughput (samples/s) HashGrid+64-wide FFMLP, batch=256k",
+            "metric": METRIC[args.workload],
             "value": world * batch * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -295,15 +333,53 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['encoding']['otype']} + {cfg['network']['n_neurons']}x{cfg['network']['n_hidden_layers']} FullyFusedMLP, "
                                    f"RelativeL2 + Adam, n_params={n_params}",
-                       "batch_per_gpu": batch, "global_batch": world * batch, "parallelism": f"replicas x{world}",
-                       "loss_first_last": [loss0, loss1]},
-            "roofline": {"bound": "hbm", "kernel": "k_adam", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": adam_bytes, "avg_launch_ms": adam_ms},
+                       "batch_per_gpu": batch, "global_batch": world * batch,
+                       "parallelism": f"independent replicas x{world}, no gradient exchange (training does not shard in the reference)" if world > 1 else "single GPU",
+                       "batches": f"{POOL} pre-generated batches visited in turn", "loss_first_last": [loss0, loss1]},
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flops, "avg_launch_ms": mlp_ms, "profiled_steps": n_profiled,
+                         "share_of_step": mlp_ms / step_ms if step_ms > 0 else None,
+                         "pieces": {"encode_ms": pieces["encode"], "mlp_kernel_ms": mlp_ms, "encoding_backward_ms": pieces["encoding_backward"],
+                                    "optimizer_ms": pieces["optimizer"],
+                                    "optimizer_hbm": {"kernel": "k_adam", "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": adam_gbs / HBM_PEAK_GBS,
+                                                      "bytes_per_launch": adam_bytes}},
+                         "hbm_floor_frac": floor_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if step_ms > 0 else None,
+                         "hbm_floor_bytes_per_step": floor_bytes},
         }
+        if sharded is not None:
+            result["c4_sharded_inference"] = sharded
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(result), flush=True)
 
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_plumbing_only(args):
+    """`--device none`: what the N > 1 path owns besides GPU kernels -- rank discovery from the environment, the process group, the
+    barrier and the MAX-over-ranks of the elapsed time, rank 0's single JSON line with n_gpus = WORLD_SIZE -- on CPU tensors."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only", "value": 0.0, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "none",
+                          "config": {"workload": "plumbing"}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

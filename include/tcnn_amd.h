@@ -147,6 +147,10 @@ const float* tcnn_train_ctx_L(tcnn_train_ctx_t ctx);           /* float [n][padd
 /* network->inference(stream, input, output) (object.h:147-176): float in, float out [n_output_dims x n] in output_layout */
 int  tcnn_trainer_inference(tcnn_trainer_t t, tcnn_stream_t stream, uint32_t n_elements, const float* input, int input_layout,
                             float* output, int output_layout, int use_inference_params);
+/* network->inference_mixed_precision(stream, input, output) (object.h:133-145): the network's own output, half
+ * [n_elements][padded_output_width] -- what inference() casts to float; half the bytes for a caller that gathers row shards */
+int  tcnn_trainer_inference_mixed_precision(tcnn_trainer_t t, tcnn_stream_t stream, uint32_t n_elements, const float* input, int input_layout,
+                                            void* output_half, int use_inference_params);
 
 size_t   tcnn_trainer_n_params(tcnn_trainer_t t);                 /* trainer.h:338 */
 uint32_t tcnn_trainer_padded_output_width(tcnn_trainer_t t);
@@ -169,6 +173,12 @@ int      tcnn_trainer_serialize(tcnn_trainer_t t, int serialize_optimizer, const
 int      tcnn_trainer_deserialize(tcnn_trainer_t t, const void* bytes, size_t size);
 const char* tcnn_trainer_network_hyperparams(tcnn_trainer_t t);   /* network->hyperparams() */
 uint32_t tcnn_trainer_optimizer_step_count(tcnn_trainer_t t);     /* optimizer->step() adam.h:198 */
+/* Measurement hook (no counterpart in the reference; bench.py): the NEXT fused training_step() records HIP events on
+ * its stream around its pieces -- [0] encoding forward, [1] the fused MLP kernel (forward + loss + backward + weight gradients),
+ * [2] encoding backward, [3] optimizer.  _collect synchronises the stream and returns the milliseconds per piece summed over the
+ * steps profiled since the last call, and their number. */
+int  tcnn_trainer_profile_next_step(tcnn_trainer_t t);
+int  tcnn_trainer_profile_collect(tcnn_trainer_t t, tcnn_stream_t stream, float* ms_per_piece /* [4] */, uint32_t* n_steps);
 
 #ifdef __cplusplus
 }

@@ -80,7 +80,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("n", [1000, 256, 5 * 256 + 17])
+@pytest.mark.parametrize("n", [1000, 256, 5 * 256 + 17, 1024, 4096])  # ragged shards (padded exchange) and equal ones (gathered in place)
 def test_sharded_inference_gloo_world2(n):
     world = 2
     mgr = mp.Manager()
@@ -93,3 +93,19 @@ def test_single_process_is_plain_inference():
     par = _parallel()
     x = torch.rand((512, 4))
     assert torch.equal(par.sharded_inference(_row_fn, x, 3), _row_fn(x))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without RANK in the environment starts two ranks itself (torch.distributed.run as a child) and
+    rank 0 prints ONE JSON line with n_gpus = 2; --device none keeps the run on CPU tensors (gloo)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--device", "none"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1

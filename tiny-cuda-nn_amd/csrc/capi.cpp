@@ -292,6 +292,14 @@ int tcnn_trainer_inference(tcnn_trainer_t t, tcnn_stream_t stream, uint32_t n, c
 	});
 }
 
+int tcnn_trainer_inference_mixed_precision(tcnn_trainer_t t, tcnn_stream_t stream, uint32_t n, const float* input, int input_layout, void* output_half, int use_inference_params) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer && (output_half || n == 0));
+		Trainer& tr = *t->trainer;
+		tr.inference_mixed_precision((hipStream_t)stream, n, make_view(input, tr.model().input_width(), n, input_layout), output_half, use_inference_params != 0);
+	});
+}
+
 size_t tcnn_trainer_n_params(tcnn_trainer_t t) { return t->trainer->n_params(); }
 uint32_t tcnn_trainer_padded_output_width(tcnn_trainer_t t) { return t->trainer->model().padded_output_width(); }
 float* tcnn_trainer_params_full_precision(tcnn_trainer_t t) { return t->trainer->params_full_precision(); }
@@ -326,6 +334,20 @@ const char* tcnn_trainer_network_hyperparams(tcnn_trainer_t t) {
 }
 
 uint32_t tcnn_trainer_optimizer_step_count(tcnn_trainer_t t) { return t->trainer->optimizer().step_count(); }
+
+int tcnn_trainer_profile_next_step(tcnn_trainer_t t) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer);
+		t->trainer->profile().arm();
+	});
+}
+
+int tcnn_trainer_profile_collect(tcnn_trainer_t t, tcnn_stream_t stream, float* ms_per_piece, uint32_t* n_steps) {
+	return guarded([&] {
+		CHECK_THROW(t && t->trainer && ms_per_piece && n_steps);
+		*n_steps = t->trainer->profile().collect((hipStream_t)stream, ms_per_piece);
+	});
+}
 
 int tcnn_trainer_serialize(tcnn_trainer_t t, int serialize_optimizer, const void** out_bytes, size_t* out_size) {
 	return guarded([&] {

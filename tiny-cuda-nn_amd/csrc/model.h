@@ -1135,6 +1135,61 @@ public:
 	}
 };
 
+// Event brackets around the pieces of ONE fused training step, on the step's stream (the measurement hook of bench.py, SURVEY 8d:
+// "time the MLP fwd+bwd+wgrad region separately").  Events are created without the system-scope release a default event
+// performs (hipEventDisableSystemFence): that write-back made a bracketed kernel 40 % slower than it is inside a step.
+struct StepProfile {
+	enum Piece { Encode = 0, MlpKernel = 1, EncodingBackward = 2, Optimizer = 3, N_PIECES = 4 };
+	struct Sample { hipEvent_t begin[N_PIECES], end[N_PIECES]; bool used[N_PIECES]; };
+	std::vector<Sample> samples;
+	bool armed = false;
+	Sample* current = nullptr;
+
+	void arm() { armed = true; }
+	void begin_step() {
+		current = nullptr;
+		if (!armed) return;
+		armed = false;
+		samples.emplace_back();
+		current = &samples.back();
+		for (int i = 0; i < N_PIECES; ++i) {
+			current->used[i] = false;
+			HIP_CHECK_THROW(hipEventCreateWithFlags(&current->begin[i], 0x20000000u)); // hipEventDisableSystemFence, timing enabled
+			HIP_CHECK_THROW(hipEventCreateWithFlags(&current->end[i], 0x20000000u));
+		}
+	}
+	void mark(hipStream_t stream, Piece p, bool end) {
+		if (!current) return;
+		HIP_CHECK_THROW(hipEventRecord(end ? current->end[p] : current->begin[p], stream));
+		if (end) current->used[p] = true;
+	}
+	void end_step() { current = nullptr; }
+	// sums over the profiled steps since the last call (milliseconds per piece) and their number; synchronises the stream
+	uint32_t collect(hipStream_t stream, float* ms) {
+		HIP_CHECK_THROW(hipStreamSynchronize(stream));
+		for (int i = 0; i < N_PIECES; ++i) ms[i] = 0.0f;
+		for (Sample& s : samples) {
+			for (int i = 0; i < N_PIECES; ++i) {
+				float t = 0.0f;
+				if (s.used[i]) HIP_CHECK_THROW(hipEventElapsedTime(&t, s.begin[i], s.end[i]));
+				ms[i] += t;
+				(void)hipEventDestroy(s.begin[i]);
+				(void)hipEventDestroy(s.end[i]);
+			}
+		}
+		const uint32_t n = (uint32_t)samples.size();
+		samples.clear();
+		return n;
+	}
+	~StepProfile() {
+		for (Sample& s : samples)
+			for (int i = 0; i < N_PIECES; ++i) {
+				(void)hipEventDestroy(s.begin[i]);
+				(void)hipEventDestroy(s.end[i]);
+			}
+	}
+};
+
 class NetworkWithInputEncoding : public Model {
 public:
 	NetworkWithInputEncoding(uint32_t n_dims_to_encode, uint32_t n_output_dims, const Json& encoding, const Json& network) {
@@ -1269,14 +1324,16 @@ public:
 	// forward() -> loss_evaluate() -> backward(), activations never leave the CU.  out / dL_dout / L: [n][padded_out].
 	std::unique_ptr<ModelContext> fused_step(hipStream_t stream, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
 	                                         LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, MatViewMut* dL_dinput, const void* params,
-	                                         void* gradients, GradientMode mode) {
+	                                         void* gradients, GradientMode mode, StepProfile* profile = nullptr) {
 		check_batch(n);
 		auto ctx = std::make_unique<Ctx>();
 		// Everything in order on the caller's stream.  Running the two small kernels around the MLP kernel (k_mlp_prep, k_wgrad_reduce,
 		// ~5 us each, independent of the encoding kernels) on a side stream was measured and lost 13-15 us per step on every
 		// workload: a cross-stream event dependency costs more here than the kernels it hides (the same happened with Adam).
+		if (profile) profile->mark(stream, StepProfile::Encode, false);
 		fused_encode(stream, *ctx, n, input, params, dL_dinput != nullptr, mode != GradientMode::Ignore);
-		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, compact_context, dL_dinput, params, gradients, mode);
+		if (profile) profile->mark(stream, StepProfile::Encode, true);
+		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, compact_context, dL_dinput, params, gradients, mode, profile);
 		return ctx;
 	}
 
@@ -1296,7 +1353,7 @@ public:
 	// the slab reduction and the encoding's backward pass.  target == nullptr requires external_dL_dy.
 	void fused_mlp_and_scatter(hipStream_t stream, const Ctx& ctx, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
 	                           LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, MatViewMut* dL_dinput, const void* params, void* gradients,
-	                           GradientMode mode) {
+	                           GradientMode mode, StepProfile* profile = nullptr) {
 		const _Float16* p = (const _Float16*)params;
 		_Float16* g = (_Float16*)gradients;
 		const uint32_t n_net = (uint32_t)m_network->n_params();
@@ -1318,11 +1375,15 @@ public:
 			n_slabs = mlp_train_fused_grid(d, n);
 			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
 		}
+		if (profile) profile->mark(stream, StepProfile::MlpKernel, false);
 		mlp_train_fused(stream, d, image.data(), n, ctx.network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L, compact_context,
 		                dL_dnetwork_input.data(), plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u, slabs.as<float>(), n_net);
+		if (profile) profile->mark(stream, StepProfile::MlpKernel, true);
 		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
 		if (need_dx) {
+			if (profile) profile->mark(stream, StepProfile::EncodingBackward, false);
 			m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + n_net, g ? g + n_net : nullptr, mode, plane_f > 0);
+			if (profile) profile->mark(stream, StepProfile::EncodingBackward, true);
 		}
 	}
 
@@ -1995,9 +2056,18 @@ public:
 					ctx->dL_doutput_ptr = ctx->dL_doutput.data();
 				}
 			}
+			m_profile.begin_step();
 			ctx->model_ctx = m_model->fused_step(stream, n, input, target, data_pdf, external_dL_dy, m_loss, loss_scale, ctx->output.data(),
 			                                     ctx->compact ? ctx->compact_dL_doutput.data() : ctx->dL_doutput.data(),
-			                                     ctx->compact ? ctx->compact_L.as<float>() : ctx->L.as<float>(), ctx->compact, dL_dinput, m_params.data(), m_grads.data(), mode);
+			                                     ctx->compact ? ctx->compact_L.as<float>() : ctx->L.as<float>(), ctx->compact, dL_dinput, m_params.data(), m_grads.data(), mode,
+			                                     &m_profile);
+			if (run_optimizer) {
+				m_profile.mark(stream, StepProfile::Optimizer, false);
+				optimizer_step(stream, loss_scale);
+				m_profile.mark(stream, StepProfile::Optimizer, true);
+			}
+			m_profile.end_step();
+			return ctx;
 		} else {
 			ctx = forward(stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy);
 			backward(stream, *ctx, n, input, dL_dinput, use_inference_params, mode);
@@ -2021,6 +2091,13 @@ public:
 		Model::check_batch(n);
 		if (n == 0) return;
 		m_model->inference_f32(stream, n, input, output, use_inference_params ? params_inference() : m_params.data());
+	}
+
+	// object.h:133-145, inference_mixed_precision: the network's own output, half [n][padded_output_width] (what inference() casts)
+	void inference_mixed_precision(hipStream_t stream, uint32_t n, MatView input, void* output_half, bool use_inference_params) {
+		Model::check_batch(n);
+		if (n == 0) return;
+		m_model->inference(stream, n, input, output_half, use_inference_params ? params_inference() : m_params.data());
 	}
 
 	void set_params_full_precision(const float* params, size_t n_params, bool device_ptr) { // trainer.h:242-254
@@ -2085,6 +2162,7 @@ public:
 
 	NetworkWithInputEncoding& model() { return *m_model; }
 	Optimizer& optimizer() { return *m_optimizer; }
+	StepProfile& profile() { return m_profile; }
 	// trainer.h:329-333: the optimizer's own weights (EMA) if it keeps any, else the training parameters
 	void* params_inference() const { void* custom = m_optimizer->custom_weights(); return custom ? custom : m_params.data(); }
 	size_t n_params() const { return m_model->n_params(); }
@@ -2098,6 +2176,7 @@ private:
 	LossType m_loss;
 	Pcg32 m_rng;
 	DeviceBuf m_params_fp, m_params, m_grads, m_scalar;
+	StepProfile m_profile;
 };
 
 } // namespace tcnn_amd

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "tcnn_train_ctx_dL_doutput": (_vp, [_vp]),
     "tcnn_train_ctx_L": (_vp, [_vp]),
     "tcnn_trainer_inference": (_int, [_vp, _vp, _u32, _vp, _int, _vp, _int, _int]),
+    "tcnn_trainer_inference_mixed_precision": (_int, [_vp, _vp, _u32, _vp, _int, _vp, _int]),
     "tcnn_trainer_n_params": (_sz, [_vp]),
     "tcnn_trainer_padded_output_width": (_u32, [_vp]),
     "tcnn_trainer_params_full_precision": (_vp, [_vp]),
@@ -105,6 +106,8 @@ _SIGNATURES = {
     "tcnn_trainer_hyperparams": (_cp, [_vp]),
     "tcnn_trainer_network_hyperparams": (_cp, [_vp]),
     "tcnn_trainer_optimizer_step_count": (_u32, [_vp]),
+    "tcnn_trainer_profile_next_step": (_int, [_vp]),
+    "tcnn_trainer_profile_collect": (_int, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_u32)]),
     "tcnn_trainer_serialize": (_int, [_vp, _int, _pp, C.POINTER(_sz)]),
     "tcnn_trainer_deserialize": (_int, [_vp, _vp, _sz]),
 }

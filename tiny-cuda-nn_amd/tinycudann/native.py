@@ -88,6 +88,20 @@ class Trainer:
                                                    _ptr(external_dL_dy), C.byref(ctx)))
         return ForwardContext(ctx, n, self.padded_output_width)
 
+    # -- measurement hook (include/tcnn_amd.h): HIP events around the pieces of the next fused training step
+    PROFILE_PIECES = ("encode", "mlp_kernel", "encoding_backward", "optimizer")
+
+    def profile_next_step(self):
+        _C.check(_C.lib.tcnn_trainer_profile_next_step(self._h))
+
+    def profile_collect(self, stream=None):
+        """-> ({piece: mean milliseconds per profiled step}, number of profiled steps)"""
+        ms = (C.c_float * 4)()
+        n = C.c_uint32()
+        _C.check(_C.lib.tcnn_trainer_profile_collect(self._h, _stream(stream), ms, C.byref(n)))
+        k = max(n.value, 1)
+        return {name: ms[i] / k for i, name in enumerate(self.PROFILE_PIECES)}, n.value
+
     # -- trainer.h:205-207
     def loss(self, ctx, stream=None):
         out = C.c_float()
@@ -114,6 +128,15 @@ class Trainer:
             shape = (n, self.n_output_dims) if output_layout == LAYOUT_AOS else (self.n_output_dims, n)
             output = torch.empty(shape, dtype=torch.float32, device=input.device)
         _C.check(_C.lib.tcnn_trainer_inference(self._h, _stream(stream), n, _ptr(input), input_layout, _ptr(output), output_layout, 1))
+        return output
+
+    # -- object.h:133-145: network->inference_mixed_precision(stream, input, output): half [n][padded_output_width]
+    def inference_half(self, input, output=None, input_layout=LAYOUT_AOS, stream=None):
+        n = input.shape[0] if input_layout == LAYOUT_AOS else input.shape[1]
+        if output is None:
+            output = torch.empty((n, self.padded_output_width), dtype=torch.half, device=input.device)
+        assert output.dtype == torch.half and output.is_contiguous() and output.shape == (n, self.padded_output_width)
+        _C.check(_C.lib.tcnn_trainer_inference_mixed_precision(self._h, _stream(stream), n, _ptr(input), input_layout, _ptr(output), 1))
         return output
 
     @property

@@ -23,27 +23,37 @@ def shard_rows(n_rows, world_size, rank, granularity=BATCH_SIZE_GRANULARITY):
     return min(begin_u * granularity, n_rows), min(end_u * granularity, n_rows)
 
 
-def sharded_inference(infer_fn, x, n_out, group=None, out_dtype=torch.float32):
+def sharded_inference(infer_fn, x, n_out, group=None, out_dtype=None):
     """Every rank holds the full input `x` [n, n_in] (or at least its own rows); rank r evaluates rows shard_rows(...) with
-    `infer_fn(x_rows) -> [rows, n_out]` and all ranks end up with the full [n, n_out] output.
+    `infer_fn(x_rows) -> [rows, n_out]` and all ranks end up with the full [n, n_out] output, in the dtype infer_fn returns
+    (half for Trainer.inference_half: SURVEY 8e's 4 MB per GPU for BASELINE config 4) unless out_dtype says otherwise.
 
-    One collective: all_gather of equally sized (padded) shards -- 7 simultaneous point-to-point transfers per GPU on a
-    fully connected xGMI node rather than a ring."""
+    One collective: all_gather_into_tensor -- 7 simultaneous point-to-point transfers per GPU on a fully connected xGMI node
+    rather than a ring.  Equal shards (n a multiple of world_size x 256, e.g. config 4) are gathered straight into the result;
+    ragged ones go through padded buffers."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = x.shape[0]
     begin, end = shard_rows(n, world, rank)
-    local = infer_fn(x[begin:end]) if end > begin else torch.empty((0, n_out), dtype=out_dtype, device=x.device)
+    if end > begin:
+        local = infer_fn(x[begin:end])
+        if out_dtype is not None:
+            local = local.to(out_dtype)
+    else:
+        local = torch.empty((0, n_out), dtype=out_dtype or torch.float32, device=x.device)
     if world == 1:
         return local
-    # equal-size buffers for all_gather_into_tensor: the largest shard, padded
-    max_rows = max(e - b for b, e in (shard_rows(n, world, r) for r in range(world)))
-    send = torch.zeros((max_rows, n_out), dtype=out_dtype, device=x.device)
-    send[: end - begin] = local.to(out_dtype)
-    recv = torch.empty((world * max_rows, n_out), dtype=out_dtype, device=x.device)
+    shards = [shard_rows(n, world, r) for r in range(world)]
+    max_rows = max(e - b for b, e in shards)
+    if all(e - b == max_rows for b, e in shards):  # the shards tile the result in rank order: no padding, no copies
+        out = torch.empty((n, n_out), dtype=local.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    send = torch.zeros((max_rows, n_out), dtype=local.dtype, device=x.device)
+    send[: end - begin] = local
+    recv = torch.empty((world * max_rows, n_out), dtype=local.dtype, device=x.device)
     dist.all_gather_into_tensor(recv, send, group=group)
-    out = torch.empty((n, n_out), dtype=out_dtype, device=x.device)
-    for r in range(world):
-        b, e = shard_rows(n, world, r)
+    out = torch.empty((n, n_out), dtype=local.dtype, device=x.device)
+    for r, (b, e) in enumerate(shards):
         out[b:e] = recv[r * max_rows : r * max_rows + (e - b)]
     return out
