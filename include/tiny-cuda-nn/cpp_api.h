@@ -33,6 +33,22 @@ inline bool has_networks() { return tcnn_has_networks() != 0; }
 inline float default_loss_scale(Precision p) { return tcnn_default_loss_scale((int)p); }
 inline Precision preferred_precision() { return (Precision)tcnn_preferred_precision(); }
 
+// cpp_api.h:80, cpp_api.cu:61-63 (bound by the torch extension, bindings.cpp:304).  The C ABI takes a function pointer and a user
+// pointer; the std::function is kept here.  An empty callback restores the library's default sink (stderr).
+namespace detail {
+inline std::function<void(LogSeverity, const std::string&)>& log_callback() {
+	static std::function<void(LogSeverity, const std::string&)> f;
+	return f;
+}
+inline void log_trampoline(int severity, const char* message, void*) {
+	if (log_callback()) log_callback()((LogSeverity)severity, std::string{message ? message : ""});
+}
+}
+inline void set_log_callback(const std::function<void(LogSeverity, const std::string&)>& callback) {
+	detail::log_callback() = callback;
+	tcnn_set_log_callback(callback ? detail::log_trampoline : nullptr, nullptr);
+}
+
 struct Context { // cpp_api.h:82-84
 	std::shared_ptr<void> ctx;
 };

@@ -42,6 +42,14 @@ static int host_checks() {
 	threw = false;
 	try { Loss<network_precision_t> l{json{{"otype", "Huber"}}}; } catch (const std::runtime_error&) { threw = true; }
 	REQUIRE(threw);
+	// cpp_api.h:80 set_log_callback: the library's messages (here: the error it reports for an invalid network) reach the callback
+	{
+		std::string seen;
+		cpp::set_log_callback([&](cpp::LogSeverity severity, const std::string& msg) { if (severity == cpp::LogSeverity::Error) seen = msg; });
+		try { std::unique_ptr<cpp::Module> bad{cpp::create_network(32, 3, json{{"otype", "NoSuchNetwork"}})}; } catch (const std::runtime_error&) {}
+		cpp::set_log_callback(nullptr);
+		REQUIRE(seen.find("Invalid network type") != std::string::npos);
+	}
 
 	// <tiny-cuda-nn/random.h>: the stream of default_rng_t{1337} (tests/golden/reference_kat.json "pcg32", computed from the
 	// reference's own dependencies/pcg32 at survey time), advance(), comments in configs, pretty-printed dump
