@@ -62,6 +62,12 @@ CONFIG_C1 = {  # Identity -> MLP 32 x 1 (CutlassMLP semantics), SURVEY 8d C1
     "encoding": {"otype": "Identity", "scale": 1.0, "offset": 0.0},
     "network": {"otype": "CutlassMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 32, "n_hidden_layers": 1},
 }
+CONFIG_C5 = {  # BASELINE config 5 at its real size: HashGrid L16 F4 T=2^22, 3-D -> 128 x 2; 210 937 856 parameters
+    "loss": {"otype": "RelativeL2"},
+    "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},
+    "encoding": {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 4, "log2_hashmap_size": 22, "base_resolution": 16, "per_level_scale": 2.0},
+    "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 2},
+}
 CONFIG_C5_SMALL = {  # C5's shape (F = 4, 3-D, 128-wide) with a small table so the oracle finishes in seconds
     "loss": {"otype": "L2"},
     "optimizer": {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6},

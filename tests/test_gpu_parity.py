@@ -590,3 +590,151 @@ def test_fused_mlp_kernel_forms_agree_at_full_batch(tcnn, oracle, monkeypatch, n
             a, b = _f32(g[lo:hi]), _f32(g0[lo:hi])
             assert float(np.linalg.norm(a - b)) <= 2e-3 * float(np.linalg.norm(b)), env
         assert abs(l - l0) <= 1e-5 * abs(l0), env
+
+
+# ---------------------------------------------------------------------------------------------------- exact steps through the trainer
+def _linear_net_params(oracle, ref_model, seed):
+    """Parameters that make every sum of the MLP's backward pass exact in fp32 whatever its order: no activation needed when the
+    weights are in {-1, 0, 1} and sparse (at most a few non-zeros per row), so dL/d(encoded input) has the oracle's bits."""
+    rs = np.random.RandomState(seed)
+    n_net = ref_model.network.n_params
+    params = oracle.Pcg32(3).uniform_strided(ref_model.n_params, -1.0, 1.0).astype(np.float32)
+    params[:n_net] = rs.choice([-1.0, 0.0, 1.0], size=n_net, p=[1 / 16, 7 / 8, 1 / 16])
+    return oracle.half_bits(params), rs
+
+
+def _exact_external_dy(rs, n, width):
+    dy = (rs.randint(-128, 129, size=(n, width)) / 64.0).astype(np.float32)
+    dy[::7] = 0
+    return dy
+
+
+@pytest.mark.parametrize("cfg,n_in", [(CONFIG_C3A, 2), (CONFIG_C5_SMALL, 3)])
+def test_gradient_mode_accumulate_matches_oracle(tcnn, oracle, cfg, n_in):
+    """GradientMode::Accumulate (trainer.h:147-149, grid.h:858 skipped) through the trainer: a second backward pass added to the
+    first one's fp16 gradients -- the scatter starts its exact sums from the existing value and rounds once more -- is
+    bit-identical to the oracle's exact accumulation, for the filtered form (C3a) and the binned one (C5's shape)."""
+    from tinycudann.native import GRADIENT_ACCUMULATE, GRADIENT_OVERWRITE
+
+    cfg = {**cfg, "network": {**cfg["network"], "activation": "None"}}
+    n = 4096
+    ref = oracle.Trainer(n_in, 3, cfg, seed=1337)
+    tr = tcnn.Trainer(n_in, 3, cfg, seed=1337)
+    params_h, rs = _linear_net_params(oracle, ref.model, 5)
+    tr.set_params(_t(params_h.view(np.float16)))
+    n_net = ref.model.network.n_params
+    want = np.zeros(ref.model.encoding.n_params, dtype=np.uint16)
+    for step, mode in enumerate((GRADIENT_OVERWRITE, GRADIENT_ACCUMULATE)):
+        x = oracle.Pcg32(42 + step).uniform_strided(n * n_in).reshape(n, n_in)
+        dy = oracle.half_bits(_exact_external_dy(rs, n, ref.model.padded_output_width))
+        out, ctx = ref.model.forward(x, params_h)
+        _, dnet_in = ref.model.backward(x, params_h, ctx, out, dy)
+        ref.model.encoding.backward_exact(x, dnet_in, want, accumulate=step > 0)
+        tr.training_step(_t(x), None, run_optimizer=False, gradient_mode=mode, external_dL_dy=_t(dy.view(np.float16)))
+        got = _bits(tr.param_gradients())[n_net:]
+        assert np.count_nonzero(want) > 0
+        assert np.array_equal(got, want), f"pass {step}"
+
+
+def test_oneblob_backward_input(tcnn, oracle):
+    """oneblob.h:99-164 (kernel_one_blob_backward): dL/dx = sum over bins of dL/dy * d(bin)/dx in fp32, through tcnn.Encoding's
+    autograd path (k_oneblob_bwd_input) against orc_oneblob_backward_input."""
+    import torch
+
+    for n_bins in (4, 16, 64):
+        cfg = {"otype": "OneBlob", "n_bins": n_bins}
+        enc = tcnn.Encoding(3, cfg)
+        ref = oracle.create_encoding(3, cfg, alignment=0)
+        n = 512
+        x = oracle.Pcg32(42).uniform_strided(n * 3).reshape(n, 3)
+        dy = oracle.half_bits(oracle.Pcg32(9).uniform_strided(n * ref.padded_output_width, -2.0, 2.0).reshape(n, ref.padded_output_width))
+        want = ref.backward(x, {}, dy, want_dL_dx=True)
+        xt = _t(x).requires_grad_(True)
+        out = enc(xt)
+        out.backward(_t(dy.view(np.float16)).to(out.dtype))
+        got = xt.grad.detach().cpu().numpy()
+        # modules.py scales the incoming gradient by the loss scale (128) before the native call and divides afterwards: exact
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-7), n_bins
+        assert np.any(got != 0)
+
+
+# ---------------------------------------------------------------------------------------------------- BASELINE config 5 at its real size
+def test_c5_full_size_training_step(tcnn, oracle):
+    """HashGrid L16 F4 T=2^22 (3-D) + 128 x 2 FullyFusedMLP, 210.9 M parameters: the one combination of trainer + binned scatter
+    (k_bin_*) + k_mlp_train<128> + Adam over the whole table.
+      (i)  4096 samples against the oracle: outputs within 1e-2, loss within 2e-2, grid gradients within 5e-2 in norm and
+           exactly zero where no sample lands, Adam moved exactly the touched entries;
+      (ii) with a linear {-1, 0, 1} network and an external dL/doutput the step is exact: grid gradients bit-identical to the
+           oracle's exact scatter (grid.h:215-320) and master weights after Adam within 1e-5 of the update (adam.h:48-119,
+           zero-gradient skip :76-79);
+      (iii) one 524 288-sample step twice from the same state: bit-identical gradients and parameters (no atomics, no race)."""
+    from conftest import CONFIG_C5
+
+    n_in, n = 3, 4096
+    ref = oracle.Trainer(n_in, 3, CONFIG_C5, seed=1337)
+    tr = tcnn.Trainer(n_in, 3, CONFIG_C5, seed=1337)
+    assert tr.n_params == ref.model.n_params == 210937856
+    n_net = ref.model.network.n_params
+    p0 = tr.params_full_precision().cpu().numpy()
+    assert np.array_equal(p0.view(np.uint32), ref.params_fp.view(np.uint32))
+
+    # (i)
+    x, t = oracle.synthetic_batch(n, n_in, 3, seed=42)
+    grads32 = np.zeros(ref.model.n_params, dtype=np.float32)
+    want = ref.training_step(x, t, run_optimizer=True, grads_f32=grads32)
+    ctx = tr.training_step(_t(x), _t(t), run_optimizer=True)
+    got_out = _f32(_bits(ctx.output()))
+    assert rel_err(got_out[:, :3], _f32(want["output"])[:, :3]) < 1e-2
+    loss = tr.loss(ctx)
+    assert abs(loss - want["loss"]) <= 2e-2 * abs(want["loss"])
+    g = _f32(_bits(tr.param_gradients()))
+    assert rel_err(g[:n_net], grads32[:n_net]) < 3e-2
+    ge, we = g[n_net:], grads32[n_net:]
+    assert float(np.linalg.norm(ge - we)) <= 5e-2 * float(np.linalg.norm(we))
+    assert np.all(ge[we == 0] == 0)
+    p1 = tr.params_full_precision().cpu().numpy()
+    moved = p1[n_net:] != p0[n_net:]
+    assert np.array_equal(moved, ge != 0)          # Adam steps exactly the entries with a gradient (adam.h:76-79)
+    assert tr.optimizer_step_count() == 1
+    del want, grads32, g, ge, we, moved
+
+    # (ii)
+    cfg_lin = {**CONFIG_C5, "network": {**CONFIG_C5["network"], "activation": "None"}}
+    ref2 = oracle.Trainer(n_in, 3, cfg_lin, seed=1337)
+    tr2 = tcnn.Trainer(n_in, 3, cfg_lin, seed=1337)
+    params_h, rs = _linear_net_params(oracle, ref2.model, 5)
+    params_f = params_h.view(np.float16).astype(np.float32)
+    tr2.set_params(_t(params_h.view(np.float16)))
+    ref2.params[:] = params_h
+    ref2.params_fp[:] = params_f
+    x2 = oracle.Pcg32(43).uniform_strided(n * n_in).reshape(n, n_in)
+    dy = oracle.half_bits(_exact_external_dy(rs, n, ref2.model.padded_output_width))
+    out, fctx = ref2.model.forward(x2, params_h)
+    ref2.grads[:] = 0
+    _, dnet_in = ref2.model.backward(x2, params_h, fctx, out, dy, grads_half=ref2.grads)
+    want_g = np.zeros(ref2.model.encoding.n_params, dtype=np.uint16)
+    ref2.model.encoding.backward_exact(x2, dnet_in, want_g)
+    tr2.training_step(_t(x2), None, run_optimizer=True, external_dL_dy=_t(dy.view(np.float16)))
+    got_g = _bits(tr2.param_gradients())
+    assert np.count_nonzero(want_g) > 1000
+    assert np.array_equal(got_g[n_net:], want_g)
+    ref2.grads[:] = got_g                          # identical gradients -> the update itself
+    ref2.optimizer.step(128.0, ref2.params_fp, ref2.params, ref2.grads)
+    got_p = tr2.params_full_precision().cpu().numpy()
+    upd = np.abs(ref2.params_fp - params_f)
+    assert np.max(np.abs(got_p - ref2.params_fp)) <= 1e-5 * np.max(upd) + 1e-9
+    assert np.array_equal(got_p[n_net:][want_g == 0].view(np.uint32), params_f[n_net:][want_g == 0].view(np.uint32))
+    del ref, ref2, tr2, got_p, upd, want_g, got_g
+
+    # (iii)
+    big = 1 << 19
+    xb, tb = oracle.synthetic_batch(big, n_in, 3, seed=7)
+    runs = []
+    for _ in range(2):
+        trb = tcnn.Trainer(n_in, 3, CONFIG_C5, seed=1337)
+        for _ in range(2):  # the second step runs the tuned scatter plan
+            ctxb = trb.training_step(_t(xb), _t(tb), run_optimizer=True)
+        runs.append((_bits(trb.param_gradients()), _bits(trb.params()), trb.loss(ctxb)))
+        del trb
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
+    assert np.isfinite(runs[0][2]) and np.count_nonzero(runs[0][0][n_net:]) > 10_000_000
