@@ -133,7 +133,7 @@ def test_encoding_double_backward_through_torch(tcnn):
     c = torch.rand(n, 3, device="cuda") - 0.5
 
     def grad_of(x, params=None):
-        y = enc(x) if params is None else tcnn.modules._ModuleFunction.apply(enc.native_tcnn_module, x, params, enc.loss_scale)
+        y = enc(x) if params is None else tcnn.modules._Evaluate.apply(x, params, enc.native_tcnn_module, enc.loss_scale)
         (g,) = torch.autograd.grad((y.float() * w).sum(), x, create_graph=True)
         return g
 

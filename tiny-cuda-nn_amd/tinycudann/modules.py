@@ -2,7 +2,7 @@
 
 Same names, constructor arguments and tensor contracts as the reference's Python package
 (bindings/torch/tinycudann/modules.py:162-329 and the `_C.Module` methods of bindings.cpp:75-266), so instant-ngp-style
-callers can switch by changing nothing but the installed package.  PyTorch is used for what it is here: device memory,
+callers can switch by changing nothing but the installed package; the implementation behind those names is this package's.  PyTorch is used for what it is here: device memory,
 streams and autograd plumbing; every computation happens in libtcnn_amd.so behind the C ABI.
 """
 import gc
@@ -161,17 +161,57 @@ def _create(fn, *args):
     return NativeModule(h)
 
 
-class _ModuleFunction(torch.autograd.Function):
-    """modules.py:91-118 of the reference: forward through the native module, backward with loss scaling."""
+# ----------------------------------------------------------------------------------------------------------------------
+# autograd glue.  What has to match the reference (bindings/torch/tinycudann/modules.py:91-160) is behaviour: the native
+# forward runs in inference mode when nothing requires a gradient; gradients are computed at loss_scale and divided
+# afterwards; the first-order backward pass is itself differentiable with respect to dL_doutput, input and params (second-order
+# INPUT gradients: eikonal / SDF losses); nothing is propagated through dL_dparams.  The construction is this package's own:
+# one record per call, two Functions that only shuttle tensors in and out of it.
+# ----------------------------------------------------------------------------------------------------------------------
+class _Call:
+    """What one forward call leaves behind for its backward passes."""
 
+    __slots__ = ("native", "native_ctx", "loss_scale", "wants_input", "wants_params")
+
+    def __init__(self, native, loss_scale, wants_input, wants_params):
+        self.native = native
+        self.native_ctx = None
+        self.loss_scale = loss_scale
+        self.wants_input = wants_input
+        self.wants_params = wants_params
+
+    def flagged(self, input, params, wants_input=None, wants_params=None):
+        """The native entry points key on requires_grad (bindings.cpp:85, 126-131): aliases that carry exactly the flags of this call."""
+        wi = self.wants_input if wants_input is None else wants_input
+        wp = self.wants_params if wants_params is None else wants_params
+        return input.detach().requires_grad_(wi), params.detach().requires_grad_(wp)
+
+    def first_order(self, input, params, output, doutput):
+        """(dL/dinput, dL/dparams) for an upstream gradient doutput; None where the call did not ask for one."""
+        inp, par = self.flagged(input, params)
+        gi, gp = self.native.bwd(self.native_ctx, inp, par, output, (doutput * self.loss_scale).contiguous())
+        inv = 1.0 / self.loss_scale
+        return (None if gi is None else gi * inv), (None if gp is None else gp * inv)
+
+    def second_order(self, input, params, doutput, d_input_grad, wants_doutput, wants_input, wants_params):
+        """Gradients of <d_input_grad, dL/dinput> with respect to (doutput, input, params).  dL/dinput is linear in doutput: the
+        term for doutput carries no loss scale, the other two were computed at loss_scale."""
+        inp, par = self.flagged(input, params, wants_input, wants_params)
+        scaled = (doutput.detach() * self.loss_scale).contiguous().requires_grad_(wants_doutput)
+        g_doutput, g_params, g_input = self.native.bwd_bwd_input(self.native_ctx, inp, par, d_input_grad.contiguous().float(), scaled)
+        inv = 1.0 / self.loss_scale
+        return g_doutput, (None if g_input is None else g_input * inv), (None if g_params is None else g_params * inv)
+
+
+class _Evaluate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, native, input, params, loss_scale):
-        ctx.set_materialize_grads(False)
-        native_ctx, output = native.fwd(input, params)
+    def forward(ctx, input, params, native, loss_scale):
+        call = _Call(native, loss_scale, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        inp, par = call.flagged(input, params)
+        call.native_ctx, output = native.fwd(inp, par)  # no flag set: inference mode, no context
+        ctx.call = call
         ctx.save_for_backward(input, params, output)
-        ctx.native = native
-        ctx.native_ctx = native_ctx
-        ctx.loss_scale = loss_scale
+        ctx.set_materialize_grads(False)
         return output
 
     @staticmethod
@@ -182,107 +222,99 @@ class _ModuleFunction(torch.autograd.Function):
             warnings.warn("doutput must be a CUDA tensor, but isn't. This indicates suboptimal performance.")
             doutput = doutput.cuda()
         input, params, output = ctx.saved_tensors
-        # the backward pass is itself a differentiable function (modules.py:107-118): second-order input gradients
-        input_grad, params_grad = _ModuleFunctionBackward.apply(ctx, doutput, input, params, output)
-        return None, _null_tensor_to_none(input_grad), _null_tensor_to_none(params_grad), None
+        g_input, g_params = _Differentiate.apply(doutput, input, params, output, ctx.call)
+        return g_input, g_params, None, None
 
 
-def _null_tensor_like(tensor):
-    return torch.empty([], dtype=tensor.dtype, device=tensor.device)
-
-
-def _null_tensor_to_none(tensor):
-    return None if len(tensor.shape) == 0 else tensor
-
-
-class _ModuleFunctionBackward(torch.autograd.Function):
-    """modules.py:120-160 of the reference.  Supported, like there: d(dL_dinput)/d(dL_doutput), d(dL_dinput)/d(params),
-    d(dL_dinput)/d(input); nothing flows back from dL_dparams."""
+class _Differentiate(torch.autograd.Function):
+    """The first-order backward pass as a differentiable function of (doutput, input, params)."""
 
     @staticmethod
-    def forward(ctx, ctx_fwd, doutput, input, params, output):
-        ctx.ctx_fwd = ctx_fwd
-        ctx.save_for_backward(input, params, doutput)
+    def forward(ctx, doutput, input, params, output, call):
+        ctx.call = call
+        ctx.save_for_backward(doutput, input, params)
+        ctx.set_materialize_grads(False)
         with torch.no_grad():
-            # the native bwd keys on requires_grad; inside a Function's forward the flags of the arguments are not reliable
-            input_g = input.detach().requires_grad_(ctx_fwd.needs_input_grad[1])
-            params_g = params.detach().requires_grad_(ctx_fwd.needs_input_grad[2])
-            scaled = (doutput * ctx_fwd.loss_scale).contiguous()
-            input_grad, params_grad = ctx_fwd.native.bwd(ctx_fwd.native_ctx, input_g, params_g, output, scaled)
-            input_grad = _null_tensor_like(input) if input_grad is None else (input_grad / ctx_fwd.loss_scale)
-            params_grad = _null_tensor_like(params) if params_grad is None else (params_grad / ctx_fwd.loss_scale)
-        return input_grad, params_grad
+            g_input, g_params = call.first_order(input, params, output, doutput)
+        if g_params is not None:
+            ctx.mark_non_differentiable(g_params)  # like the reference: nothing flows back from dL_dparams
+        return g_input, g_params
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dinput_grad, dparams_grad):
-        input, params, doutput = ctx.saved_tensors
-        fwd = ctx.ctx_fwd
-        if dinput_grad is None or len(dinput_grad.shape) == 0:
+    def backward(ctx, d_input_grad, _d_params_grad):
+        if d_input_grad is None:
             return None, None, None, None, None
-        need_doutput, need_input, need_params = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        scaled = (doutput.detach() * fwd.loss_scale).contiguous().requires_grad_(need_doutput)
-        input_g = input.detach().requires_grad_(need_input)
-        params_g = params.detach().requires_grad_(need_params)
-        doutput_grad, params_grad, input_grad = fwd.native.bwd_bwd_input(fwd.native_ctx, input_g, params_g, dinput_grad.contiguous().float(), scaled)
-        # loss scale bookkeeping (modules.py:150-156): doutput_grad is linear in dinput_grad only; the other two also in doutput
-        params_grad = None if params_grad is None else (params_grad / fwd.loss_scale)
-        input_grad = None if input_grad is None else (input_grad / fwd.loss_scale)
-        return None, doutput_grad, input_grad, params_grad, None
+        doutput, input, params = ctx.saved_tensors
+        wants_doutput, wants_input, wants_params = ctx.needs_input_grad[:3]
+        g_doutput, g_input, g_params = ctx.call.second_order(input, params, doutput, d_input_grad, wants_doutput, wants_input, wants_params)
+        return g_doutput, g_input, g_params, None, None
+
+
+def _pad_rows(x, multiple):
+    """x with its row count rounded up to a multiple (zero rows appended); the batch granularity of the kernels (common.h:235)"""
+    n = x.shape[0]
+    padded = -(-n // multiple) * multiple
+    if padded == n:
+        return x
+    buf = x.new_zeros((padded,) + tuple(x.shape[1:]))
+    buf[:n] = x
+    return buf
 
 
 class Module(torch.nn.Module):
+    """Base of `Network`, `Encoding`, `NetworkWithInputEncoding` (reference: modules.py:162-217): an fp32 `params` Parameter
+    initialised by the native module from `seed`, `forward(x)` for [n, n_input_dims] -> [n, n_output_dims] with any n."""
+
     def __init__(self, seed=1337):
         super().__init__()
         _require_gpu()
-        self.native_tcnn_module = self._native_tcnn_module()
-        self.dtype = _torch_precision(self.native_tcnn_module.param_precision())
         self.seed = seed
-        initial_params = self.native_tcnn_module.initial_params(seed)
-        self.params = torch.nn.Parameter(initial_params, requires_grad=True)
-        self.register_parameter(name="params", param=self.params)
-        self.loss_scale = _C.default_loss_scale(self.native_tcnn_module.param_precision())
+        self._attach_native()
+        self.params = torch.nn.Parameter(self.native_tcnn_module.initial_params(seed), requires_grad=True)
+
+    def _attach_native(self):
+        """(re)creates everything that is derived from the configuration alone: the native handle and what it reports"""
+        self.native_tcnn_module = self._native_tcnn_module()
+        precision = self.native_tcnn_module.param_precision()
+        self.dtype = _torch_precision(precision)
+        self.loss_scale = _C.default_loss_scale(precision)
 
     def forward(self, x):
         if not x.is_cuda:
             warnings.warn("input must be a CUDA tensor, but isn't. This indicates suboptimal performance.")
             x = x.cuda()
-        batch_size = x.shape[0]
-        g = _C.batch_size_granularity()
-        padded = (batch_size + g - 1) // g * g
-        x_padded = x if batch_size == padded else torch.nn.functional.pad(x, [0, 0, 0, padded - batch_size])
-        output = _ModuleFunction.apply(
-            self.native_tcnn_module,
-            x_padded.to(torch.float).contiguous(),
-            self.params.to(_torch_precision(self.native_tcnn_module.param_precision())).contiguous(),
-            self.loss_scale,
-        )
-        return output[:batch_size, : self.n_output_dims]
+        n = x.shape[0]
+        rows = _pad_rows(x.to(torch.float), _C.batch_size_granularity()).contiguous()
+        output = _Evaluate.apply(rows, self.params.to(self.dtype).contiguous(), self.native_tcnn_module, self.loss_scale)
+        return output[:n, : self.n_output_dims]
 
+    # native handles do not pickle: drop them, and rebuild them from the configuration on the other side
     def __getstate__(self):
-        state = self.__dict__.copy()
-        del state["native_tcnn_module"]  # native handles are not picklable (modules.py:194-199)
-        return state
+        return {k: v for k, v in self.__dict__.items() if k != "native_tcnn_module"}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        self.native_tcnn_module = self._native_tcnn_module()
+        self._attach_native()
 
     def extra_repr(self):
         return (f"n_input_dims={self.n_input_dims}, n_output_dims={self.n_output_dims}, seed={self.seed}, dtype={self.dtype}, "
                 f"hyperparams={self.native_tcnn_module.hyperparams()}")
 
 
+def _needs_networks(what):
+    if not _C.has_networks():
+        raise RuntimeError(f"Cannot create `{what}` because tiny-cuda-nn was not compiled with neural network support.")
+
+
 class NetworkWithInputEncoding(Module):
-    """Input encoding followed by a neural network: [:, n_input_dims] float -> [:, n_output_dims] (half)."""
+    """Input encoding followed by a neural network: [:, n_input_dims] float -> [:, n_output_dims] (half).
+    Arguments as in the reference (modules.py:219-260): dimensions, the `encoding` and `network` configuration dicts, seed."""
 
     def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, seed=1337):
-        if not _C.has_networks():
-            raise RuntimeError("Cannot create `NetworkWithInputEncoding` because tiny-cuda-nn was not compiled with neural network support.")
-        self.n_input_dims = n_input_dims
-        self.n_output_dims = n_output_dims
-        self.encoding_config = encoding_config
-        self.network_config = network_config
+        _needs_networks("NetworkWithInputEncoding")
+        self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+        self.encoding_config, self.network_config = encoding_config, network_config
         super().__init__(seed=seed)
 
     def _native_tcnn_module(self):
@@ -291,13 +323,11 @@ class NetworkWithInputEncoding(Module):
 
 
 class Network(Module):
-    """Neural network on raw inputs (Identity encoding inside, cpp_api.cu:151-153)."""
+    """Neural network on raw inputs (an Identity encoding inside, cpp_api.cu:151-153); arguments as modules.py:262-292."""
 
     def __init__(self, n_input_dims, n_output_dims, network_config, seed=1337):
-        if not _C.has_networks():
-            raise RuntimeError("Cannot create `Network` because tiny-cuda-nn was not compiled with neural network support.")
-        self.n_input_dims = n_input_dims
-        self.n_output_dims = n_output_dims
+        _needs_networks("Network")
+        self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
         self.network_config = network_config
         super().__init__(seed=seed)
 
@@ -306,20 +336,21 @@ class Network(Module):
 
 
 class Encoding(Module):
-    """Input encoding: [:, n_input_dims] float -> [:, n_output_dims] in `dtype` (default: half)."""
+    """Input encoding: [:, n_input_dims] float -> [:, n_output_dims] in `dtype` (default: the preferred precision, half);
+    arguments as modules.py:294-329.  n_output_dims is what the native encoding reports."""
+
+    _PRECISIONS = {None: None, torch.float32: _C.Precision.Fp32, torch.float16: _C.Precision.Fp16}
 
     def __init__(self, n_input_dims, encoding_config, seed=1337, dtype=None):
+        if dtype not in self._PRECISIONS:
+            raise ValueError(f"Encoding only supports fp32 or fp16 precision, but got {dtype}")
         self.n_input_dims = n_input_dims
         self.encoding_config = encoding_config
-        if dtype is None:
-            self.precision = _C.preferred_precision()
-        elif dtype == torch.float32:
-            self.precision = _C.Precision.Fp32
-        elif dtype == torch.float16:
-            self.precision = _C.Precision.Fp16
-        else:
-            raise ValueError(f"Encoding only supports fp32 or fp16 precision, but got {dtype}")
+        self.precision = _C.preferred_precision() if dtype is None else self._PRECISIONS[dtype]
         super().__init__(seed=seed)
+
+    def _attach_native(self):
+        super()._attach_native()
         self.n_output_dims = self.native_tcnn_module.n_output_dims()
 
     def _native_tcnn_module(self):
