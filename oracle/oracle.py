@@ -475,16 +475,19 @@ class SphericalHarmonicsEncoding:
 
 
 class CompositeEncoding:
-    """encodings/composite.h:126-420, reduction Concatenation: nested encodings over slices of the input dims; padded nested
-    outputs side by side (each padded so that the next starts at a multiple of its required alignment, :189-200; the last one
-    absorbs the composite's own padding, :375-385); parameters one after the other (:422-428)."""
+    """encodings/composite.h:126-420: nested encodings over slices of the input dims, parameters one after the other (:422-428).
+    Concatenation: padded nested outputs side by side (each padded so that the next starts at a multiple of its required
+    alignment, :189-200; the last one absorbs the composite's own padding, :375-385).  Sum / Product (:47-133, :199-211,
+    :259-330): nested outputs of equal width at the common alignment, combined in fp32 in nesting order and rounded once; the
+    product's backward pass multiplies the OTHER factors up (no division)."""
 
     def __init__(self, n_in, cfg):
         nested = _ci(cfg, "nested", None)
         if not isinstance(nested, list):
             raise RuntimeError("Must provide an array of nested encodings to CompositeEncoding.")
-        if _norm(_ci(cfg, "reduction", "Concatenation")) != "concatenation":
-            raise RuntimeError("CompositeEncoding: only Concatenation is restated")
+        self.reduction = _norm(_ci(cfg, "reduction", "Concatenation"))
+        if self.reduction not in ("concatenation", "sum", "product"):
+            raise RuntimeError("Invalid reduction type: " + str(_ci(cfg, "reduction", "")))
         total = 0
         for c in nested:
             total += int(c.get("n_dims_to_encode", 0))
@@ -509,27 +512,47 @@ class CompositeEncoding:
                 self.nested.append(create_encoding(dims, c, alignment=1))
                 self.begin.append(offset)
             offset += dims
-        so_far = 0
-        for i in range(len(self.nested) - 1):
-            desired = self.nested[i + 1].required_output_alignment
-            e = self.nested[i]
-            e.n_to_pad = next_multiple(so_far + e.n_output_dims, desired) - so_far - e.n_output_dims
-            so_far += e.padded_output_width
+        self.required_output_alignment = int(np.lcm.reduce([e.required_output_alignment for e in self.nested]))
+        if self.reduction == "concatenation":
+            so_far = 0
+            for i in range(len(self.nested) - 1):
+                desired = self.nested[i + 1].required_output_alignment
+                e = self.nested[i]
+                e.n_to_pad = next_multiple(so_far + e.n_output_dims, desired) - so_far - e.n_output_dims
+                so_far += e.padded_output_width
+        else:
+            for e in self.nested:
+                e.set_alignment(self.required_output_alignment)
+            if any(e.n_output_dims != self.nested[0].n_output_dims for e in self.nested):
+                raise RuntimeError("CompositeEncoding: nested encodings of a Sum / Product reduction must have the same output width")
         self.n_in = n_in
         self.n_to_pad = 0
         self.n_params = sum(e.n_params for e in self.nested)
-        self.required_output_alignment = int(np.lcm.reduce([e.required_output_alignment for e in self.nested]))
 
     @property
     def n_output_dims(self):
+        if self.reduction != "concatenation":
+            return self.nested[0].padded_output_width
         return sum(e.padded_output_width for e in self.nested)
 
     @property
     def padded_output_width(self):
         return self.n_output_dims
 
+    def _reduction_width(self):
+        # composite.h:274 lays nested outputs out at their UNPADDED widths, :261 reduces at the PADDED width: defined only if equal
+        for e in self.nested:
+            if e.padded_output_width != e.n_output_dims:
+                raise RuntimeError("CompositeEncoding: a Sum / Product reduction needs nested encodings whose output width is a multiple of the required alignment")
+        return self.nested[0].padded_output_width
+
     def set_alignment(self, alignment):
         a = int(np.lcm(alignment, self.required_output_alignment))
+        if self.reduction != "concatenation":
+            padded = next_multiple(self.n_output_dims, a)
+            for e in self.nested:
+                e.n_to_pad = padded - e.n_output_dims
+            return
         last = self.nested[-1]
         prev = self.n_output_dims - last.padded_output_width
         last.n_to_pad = next_multiple(self.n_output_dims, a) - prev - last.n_output_dims
@@ -547,6 +570,18 @@ class CompositeEncoding:
     def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
         n = x.shape[0]
         x = np.ascontiguousarray(x, dtype=np.float32)
+        if self.reduction != "concatenation":
+            w = self._reduction_width()
+            ctxs, parts = [], []
+            for (e, sl), b in zip(self._param_slices(), self.begin):
+                p = None if params_half is None or e.n_params == 0 else np.ascontiguousarray(params_half[sl])
+                o, c = e.forward(np.ascontiguousarray(x[:, b:b + e.n_in]), p, want_dy_dx=want_dy_dx)
+                parts.append(o.view(np.float16).astype(np.float32))
+                ctxs.append(c)
+            acc = np.full((n, w), 1.0 if self.reduction == "product" else 0.0, dtype=np.float32)
+            for v in parts:  # fp32, nesting order (composite.h:59-62, :101-104)
+                acc = acc * v if self.reduction == "product" else acc + v
+            return acc.astype(np.float16).view(np.uint16), {"nested": ctxs, "to_reduce": parts}
         out = np.empty((n, self.padded_output_width), dtype=np.uint16)
         ctxs, col = [], 0
         for (e, sl), b in zip(self._param_slices(), self.begin):
@@ -561,6 +596,23 @@ class CompositeEncoding:
         n = x.shape[0]
         x = np.ascontiguousarray(x, dtype=np.float32)
         dL_dx = np.zeros((n, self.n_in), dtype=np.float32) if want_dL_dx else None
+        if self.reduction != "concatenation":
+            parts = ctx["to_reduce"]
+            upstream = np.asarray(dL_dy).view(np.float16).astype(np.float32)
+            for k, ((e, sl), b, c) in enumerate(zip(self._param_slices(), self.begin, ctx["nested"])):
+                if self.reduction == "sum":
+                    dy = np.ascontiguousarray(np.asarray(dL_dy))  # composite.h:83-86: passed through
+                else:
+                    result = upstream.copy()
+                    for l in range(len(parts) - 1):  # :122-131: the other factors, in nesting order
+                        result = result * parts[l if l < k else l + 1]
+                    dy = result.astype(np.float16).view(np.uint16)
+                gh = None if grad_half is None or e.n_params == 0 else grad_half[sl]
+                g32 = None if grad_f32 is None or e.n_params == 0 else grad_f32[sl]
+                d = e.backward(np.ascontiguousarray(x[:, b:b + e.n_in]), c, dy, gh, want_dL_dx, g32)
+                if want_dL_dx and d is not None:
+                    dL_dx[:, b:b + e.n_in] = d
+            return dL_dx
         col = 0
         for (e, sl), b, c in zip(self._param_slices(), self.begin, ctx["nested"]):
             dy = np.ascontiguousarray(dL_dy[:, col:col + e.padded_output_width])
@@ -573,7 +625,8 @@ class CompositeEncoding:
         return dL_dx
 
     def hyperparams(self):
-        return {"otype": "Composite", "reduction": "Concatenation", "nested": [e.hyperparams() for e in self.nested]}
+        return {"otype": "Composite", "reduction": {"concatenation": "Concatenation", "sum": "Sum", "product": "Product"}[self.reduction],
+                "nested": [e.hyperparams() for e in self.nested]}
 
 
 def create_encoding(n_in, cfg, alignment=8):

@@ -113,3 +113,109 @@ def test_trainer_with_composite_encoding(tcnn, oracle):
     assert tr.loss(ctx) < 0.7 * first
     y = tr.inference(torch.from_numpy(x).cuda())
     assert y.shape == (1024, 3) and torch.isfinite(y).all()
+
+
+# ---------------------------------------------------------------------------------------------------- Sum / Product reductions
+def _reduced(reduction):
+    """two hash grids over the same 3 dims (16 features each: no padding at the common alignment) and a third over 2 of them"""
+    grid = {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 10, "base_resolution": 4, "per_level_scale": 1.5}
+    return {"otype": "Composite", "reduction": reduction, "nested": [
+        {"n_dims_to_encode": 3, "dims_to_encode_begin": 0, **grid},
+        {"n_dims_to_encode": 3, "dims_to_encode_begin": 0, **grid, "base_resolution": 5},
+        {"n_dims_to_encode": 2, "dims_to_encode_begin": 1, **grid, "log2_hashmap_size": 9},
+    ]}
+
+
+@pytest.mark.parametrize("reduction", ["Sum", "Product"])
+def test_oracle_composite_reductions(oracle, reduction):
+    """composite.h:47-133 restated: fp32 combination in nesting order, one rounding; the product's backward pass is the product
+    of the other factors -- checked against float64 arithmetic on the nested outputs."""
+    enc = oracle.create_encoding(3, _reduced(reduction), alignment=16)
+    assert enc.padded_output_width == enc.n_output_dims == 16 and enc.hyperparams()["reduction"] == reduction
+    assert enc.n_params == sum(e.n_params for e in enc.nested)
+    rs = np.random.RandomState(0)
+    x = rs.uniform(0.05, 0.95, (128, 3)).astype(np.float32)
+    params = oracle.half_bits(rs.uniform(0.5, 1.5, enc.n_params).astype(np.float32))
+    out, ctx = enc.forward(x, params)
+    parts = []
+    off = 0
+    for e, b in zip(enc.nested, enc.begin):
+        o, _ = e.forward(np.ascontiguousarray(x[:, b:b + e.n_in]), params[off:off + e.n_params])
+        parts.append(oracle.half_to_f32(o).astype(np.float64))
+        off += e.n_params
+    want = parts[0] + parts[1] + parts[2] if reduction == "Sum" else parts[0] * parts[1] * parts[2]
+    got = oracle.half_to_f32(out).astype(np.float64)
+    assert np.allclose(got, want, rtol=2e-3, atol=1e-6)  # one fp16 rounding
+    # backward: gradient of <dy, out> with respect to the grid of the second nested encoding = its own backward of dy * (others)
+    dy = oracle.half_bits(rs.uniform(-1, 1, (128, 16)).astype(np.float32))
+    g32 = np.zeros(enc.n_params, dtype=np.float32)
+    enc.backward(x, ctx, dy, grad_f32=g32)
+    e1 = enc.nested[1]
+    upstream = oracle.half_to_f32(dy).astype(np.float64) * (1.0 if reduction == "Sum" else parts[0] * parts[2])
+    want_g = np.zeros(e1.n_params, dtype=np.float32)
+    _, c1 = e1.forward(np.ascontiguousarray(x), params[enc.nested[0].n_params:enc.nested[0].n_params + e1.n_params])
+    e1.backward(np.ascontiguousarray(x), c1, oracle.half_bits(upstream.astype(np.float32)), grad_f32=want_g)
+    sl = slice(enc.nested[0].n_params, enc.nested[0].n_params + e1.n_params)
+    assert np.linalg.norm(g32[sl] - want_g) <= 2e-3 * np.linalg.norm(want_g)
+    with pytest.raises(RuntimeError, match="same output width"):
+        bad = _reduced(reduction)
+        bad["nested"][2] = {**bad["nested"][2], "n_levels": 4}
+        oracle.create_encoding(3, bad, alignment=16)
+    with pytest.raises(RuntimeError, match="Invalid reduction type"):
+        oracle.create_encoding(3, {**_reduced(reduction), "reduction": "Mean"}, alignment=16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reduction", ["Sum", "Product"])
+def test_composite_reductions_match_oracle(tcnn, oracle, reduction):
+    """encodings/composite.h:259-330 through the C ABI: forward bit-exact (exact grid values, the same fp32 combination in the
+    same order, one rounding), parameter gradients bit-exact (the same fp16 dL/d(nested output) into the exact scatter),
+    input gradients within fp32 summation order."""
+    from test_gpu_parity import _bits, _f32, _t
+
+    n = 1024
+    cfg = _reduced(reduction)
+    enc = tcnn.Encoding(3, cfg)
+    native = enc.native_tcnn_module
+    ref = oracle.create_encoding(3, cfg, alignment=0)
+    assert enc.n_output_dims == ref.padded_output_width == 16 and native.n_params() == ref.n_params
+    assert native.hyperparams()["reduction"] == reduction
+    rs = np.random.RandomState(1)
+    params = oracle.half_bits(rs.uniform(0.5, 1.5, ref.n_params).astype(np.float32))
+    x = oracle.Pcg32(42).uniform_strided(n * 3).reshape(n, 3)
+    want, ctx = ref.forward(x, params, want_dy_dx=True)
+    xt = _t(x).requires_grad_(True)
+    pt = _t(params.view(np.float16)).requires_grad_(True)
+    nctx, out = native.fwd(xt, pt)
+    assert np.array_equal(_bits(out), want)
+    dy = oracle.half_bits(oracle.Pcg32(5).uniform_strided(n * 16, -1.0, 1.0).reshape(n, 16))
+    want_g = np.zeros(ref.n_params, dtype=np.uint16)
+    # exact scatter of every nested grid (the oracle's backward in exact mode is per encoding)
+    off = 0
+    parts = ctx["to_reduce"]
+    up = oracle.half_to_f32(dy)
+    for k, (e, b) in enumerate(zip(ref.nested, ref.begin)):
+        if reduction == "Sum":
+            dk = dy
+        else:
+            r = up.copy()
+            for l in range(len(parts) - 1):
+                r = r * parts[l if l < k else l + 1]
+            dk = oracle.half_bits(r)
+        e.backward_exact(np.ascontiguousarray(x[:, b:b + e.n_in]), dk, want_g[off:off + e.n_params])
+        off += e.n_params
+    want_dx = ref.backward(x, ctx, dy, want_dL_dx=True)
+    gx, gp = native.bwd(nctx, xt, pt, out, _t(dy.view(np.float16)))
+    assert np.array_equal(_bits(gp), want_g)
+    assert np.allclose(gx.cpu().numpy(), want_dx, rtol=1e-4, atol=1e-5)
+    # trains inside a network: 16 reduced features -> 64 x 2 MLP
+    tr = tcnn.Trainer(3, 3, {"loss": {"otype": "L2"}, "optimizer": {"otype": "Adam", "learning_rate": 1e-2}, "encoding": cfg,
+                             "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}}, seed=1337)
+    xs, ts = oracle.synthetic_batch(4096, 3, 3, seed=3)
+    first = last = None
+    for s in range(40):
+        c = tr.training_step(_t(xs), _t(ts))
+        if s == 0:
+            first = tr.loss(c)
+    last = tr.loss(c)
+    assert np.isfinite(last) and last < first

@@ -191,3 +191,27 @@ def test_unknown_optimizer_is_reported(tcnn):
 
     with pytest.raises(RuntimeError, match="Invalid optimizer type: Shampoo"):
         tcnn.Trainer(2, 3, {**CONFIG_C3B, "optimizer": {"otype": "Shampoo"}})
+
+
+@pytest.mark.gpu
+def test_composite_optimizer_with_unaligned_slices(tcnn, oracle):
+    """A nested optimizer may own a slice that starts at ANY element offset (optimizers/composite.h:126-135): here the second
+    Adam starts at an odd offset, where the vectorised Adam kernel's 16-byte accesses would be misaligned -- the element-wise
+    kernel takes over, with the same arithmetic."""
+    from test_gpu_parity import CONFIG_C3B
+
+    sizes = oracle.Trainer(2, 3, CONFIG_C3B, seed=1337).model
+    n_net, n = sizes.network.n_params, sizes.n_params
+    adam = {"otype": "Adam", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-15, "l2_reg": 1e-6}
+    cfg = {"otype": "Composite", "nested": [
+        {"otype": "SGD", "learning_rate": 1e-2, "l2_reg": 1e-4, "n_params_to_optimize": n_net},
+        {**adam, "n_params_to_optimize": 333},
+        {**adam, "learning_rate": 5e-3, "n_params_to_optimize": n - n_net - 333 - 5},  # the last 5 entries belong to nobody
+    ]}
+    ref, tr, p0 = _drive(tcnn, oracle, cfg, steps=3)
+    got = tr.params_full_precision().cpu().numpy()
+    assert np.array_equal(got[:n_net].view(np.uint32), ref.params_fp[:n_net].view(np.uint32))
+    upd = np.abs(ref.params_fp[n_net:] - p0[n_net:])
+    assert np.max(upd) > 0
+    assert np.max(np.abs(got[n_net:] - ref.params_fp[n_net:])) <= 1e-5 * np.max(upd) + 1e-9
+    assert np.array_equal(got[-5:].view(np.uint32), p0[-5:].view(np.uint32))

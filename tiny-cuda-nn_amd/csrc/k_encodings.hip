@@ -192,4 +192,59 @@ void sh_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t degre
 	else hipLaunchKernelGGL((k_sh_bwd_input<half_t>), dim3(div_round_up(n, 128)), dim3(128), 0, stream, n, degree, n_to_pad, norms, x, (const half_t*)dL_dy, dy_stride, dL_dx);
 }
 
+namespace {
+// composite.h:47-133, one thread per element of the reduced output: the nested values are combined in fp32 in nesting order
+template <typename T, bool PRODUCT>
+__global__ void __launch_bounds__(256) k_composite_reduce_fwd(const size_t n_elems, const uint32_t n_nested, const T* __restrict__ in, T* __restrict__ out) {
+	const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n_elems) return;
+	float result = PRODUCT ? 1.0f : 0.0f;
+	for (uint32_t k = 0; k < n_nested; ++k) {
+		const float v = (float)in[(size_t)k * n_elems + e];
+		if (PRODUCT) result *= v; else result += v;
+	}
+	out[e] = (T)result;
+}
+
+template <typename T, bool PRODUCT>
+__global__ void __launch_bounds__(256) k_composite_reduce_bwd(const size_t n_elems, const uint32_t n_nested, const T* __restrict__ in, const T* __restrict__ dL_dout, T* __restrict__ dL_din) {
+	const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n_elems) return;
+	const T passed = dL_dout[e];
+	for (uint32_t k = 0; k < n_nested; ++k) {
+		if (!PRODUCT) {
+			dL_din[(size_t)k * n_elems + e] = passed; // :83-86
+		} else { // :118-131: the product of the OTHER factors, multiplied up in nesting order (no division)
+			float result = (float)passed;
+			for (uint32_t l = 0; l + 1 < n_nested; ++l) result *= (float)in[(size_t)(l < k ? l : l + 1) * n_elems + e];
+			dL_din[(size_t)k * n_elems + e] = (T)result;
+		}
+	}
+}
+} // namespace
+
+void composite_reduce_forward(hipStream_t stream, bool fp32, bool product, size_t n_elems, uint32_t n_nested, const void* in, void* out) {
+	if (n_elems == 0) return;
+	const dim3 grid((uint32_t)((n_elems + 255) / 256));
+	if (fp32) {
+		if (product) hipLaunchKernelGGL((k_composite_reduce_fwd<float, true>), grid, dim3(256), 0, stream, n_elems, n_nested, (const float*)in, (float*)out);
+		else hipLaunchKernelGGL((k_composite_reduce_fwd<float, false>), grid, dim3(256), 0, stream, n_elems, n_nested, (const float*)in, (float*)out);
+	} else {
+		if (product) hipLaunchKernelGGL((k_composite_reduce_fwd<_Float16, true>), grid, dim3(256), 0, stream, n_elems, n_nested, (const _Float16*)in, (_Float16*)out);
+		else hipLaunchKernelGGL((k_composite_reduce_fwd<_Float16, false>), grid, dim3(256), 0, stream, n_elems, n_nested, (const _Float16*)in, (_Float16*)out);
+	}
+}
+
+void composite_reduce_backward(hipStream_t stream, bool fp32, bool product, size_t n_elems, uint32_t n_nested, const void* in, const void* dL_dout, void* dL_din) {
+	if (n_elems == 0) return;
+	const dim3 grid((uint32_t)((n_elems + 255) / 256));
+	if (fp32) {
+		if (product) hipLaunchKernelGGL((k_composite_reduce_bwd<float, true>), grid, dim3(256), 0, stream, n_elems, n_nested, (const float*)in, (const float*)dL_dout, (float*)dL_din);
+		else hipLaunchKernelGGL((k_composite_reduce_bwd<float, false>), grid, dim3(256), 0, stream, n_elems, n_nested, (const float*)in, (const float*)dL_dout, (float*)dL_din);
+	} else {
+		if (product) hipLaunchKernelGGL((k_composite_reduce_bwd<_Float16, true>), grid, dim3(256), 0, stream, n_elems, n_nested, (const _Float16*)in, (const _Float16*)dL_dout, (_Float16*)dL_din);
+		else hipLaunchKernelGGL((k_composite_reduce_bwd<_Float16, false>), grid, dim3(256), 0, stream, n_elems, n_nested, (const _Float16*)in, (const _Float16*)dL_dout, (_Float16*)dL_din);
+	}
+}
+
 } // namespace tcnn_amd

@@ -379,6 +379,22 @@ __global__ void __launch_bounds__(256) k_adam(
 	}
 }
 
+// One parameter per thread, no vector accesses: for parameter ranges that do not start on a 16-byte boundary (a Composite
+// optimizer hands its nested optimizers slices at arbitrary offsets, optimizers/composite.h:126-135)
+__global__ void __launch_bounds__(256) k_adam_scalar(
+	const AdamArgs a, const size_t n, const size_t n_matrix,
+	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps,
+	const float* __restrict__ debias_table
+) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float debias = debias_table[a.common_step];
+	bool up;
+	half_t wh;
+	adam_one(a, debias_table, debias, i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
+	if (up) w[i] = wh;
+}
+
 // ---- pcg32 strided uniform fill, random.h:40-55 (N_TO_GENERATE = 4, thread i advances a copy of the rng by 4 i)
 __global__ void __launch_bounds__(128) k_random_uniform(const size_t n, const uint64_t state, const uint64_t inc, float* __restrict__ out, const float lower, const float upper) {
 	const uint64_t MULT = 0x5851f42d4c957f2dULL;
@@ -539,6 +555,12 @@ void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix
 	int exponent = 0;
 	a.inv_loss_scale_exact = (std::frexp(loss_scale, &exponent) == 0.5f && loss_scale >= 1.0f / 65536 && loss_scale <= 65536.0f) ? 1 : 0;
 	a.inv_loss_scale = 1.0f / loss_scale;
+	// the quad kernel reads float4 / uint4 / half4: every base pointer must allow that
+	const auto aligned = [](const void* p, size_t bytes) { return ((uintptr_t)p & (bytes - 1)) == 0; };
+	if (!(aligned(w_fp, 16) && aligned(m1, 16) && aligned(m2, 16) && aligned(steps, 16) && aligned(w_half, 8) && aligned(g_half, 8))) {
+		hipLaunchKernelGGL(k_adam_scalar, dim3(blocks_for(n, 256)), dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
+		return;
+	}
 	const dim3 grid(blocks_for((n + 3) / 4, 256 * ADAM_Q));
 	if (n_matrix % 4 == 0) hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
 	else hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);

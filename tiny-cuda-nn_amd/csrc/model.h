@@ -202,6 +202,7 @@ struct Pcg32 {
 // Encodings
 // ------------------------------------------------------------------------------------------------------------------
 struct EncodingContext {
+	ArenaBuf to_reduce; // Composite encoding with a Sum / Product reduction: the nested outputs [nested][n][width]
 	ArenaBuf dy_dx;       // grid only: float [n][L*F][D]
 	ArenaBuf chunk_mask;  // grid only: uint64 [L][32][n/64] bit planes, which samples touch which scatter chunk (filter for the LDS scatter)
 	uint32_t n = 0;
@@ -740,8 +741,11 @@ class CompositeEncoding : public Encoding {
 public:
 	CompositeEncoding(uint32_t n_dims_to_encode, const Json& params, bool fp32) : Encoding{fp32}, m_n_dims{n_dims_to_encode} {
 		if (!params.contains("nested") || !params["nested"].is_array()) throw std::runtime_error{"Must provide an array of nested encodings to CompositeEncoding."};
-		const std::string reduction = params.value("reduction", "Concatenation");
-		if (!equals_case_insensitive(reduction, "Concatenation")) throw std::runtime_error{"CompositeEncoding: reduction '" + reduction + "' is not provided by this build (Concatenation only)"};
+		const std::string reduction = params.value("reduction", "Concatenation"); // common.h string_to_reduction_type
+		if (equals_case_insensitive(reduction, "Concatenation")) m_reduction = Reduction::Concatenation;
+		else if (equals_case_insensitive(reduction, "Sum")) m_reduction = Reduction::Sum;
+		else if (equals_case_insensitive(reduction, "Product")) m_reduction = Reduction::Product;
+		else throw std::runtime_error{"Invalid reduction type: " + reduction};
 		const Json& nested = params["nested"];
 		m_config = params;
 		uint32_t total = 0;
@@ -771,16 +775,26 @@ public:
 			offset += dims;
 		}
 		if (m_nested.empty()) throw std::runtime_error{"CompositeEncoding: no nested encoding encodes anything"};
-		// composite.h:189-200: pad each nested output so that the next one starts at a multiple of ITS required alignment
-		uint32_t so_far = 0;
-		for (size_t i = 0; i + 1 < m_nested.size(); ++i) {
-			const uint32_t desired = m_nested[i + 1]->required_output_alignment();
-			m_nested[i]->set_padded_output_width(next_multiple(so_far + m_nested[i]->output_width(), desired) - so_far);
-			so_far += m_nested[i]->padded_output_width();
+		if (m_reduction == Reduction::Concatenation) {
+			// composite.h:189-200: pad each nested output so that the next one starts at a multiple of ITS required alignment
+			uint32_t so_far = 0;
+			for (size_t i = 0; i + 1 < m_nested.size(); ++i) {
+				const uint32_t desired = m_nested[i + 1]->required_output_alignment();
+				m_nested[i]->set_padded_output_width(next_multiple(so_far + m_nested[i]->output_width(), desired) - so_far);
+				so_far += m_nested[i]->padded_output_width();
+			}
+		} else {
+			// composite.h:199-211: every nested encoding at the common alignment, and all of the same width
+			const uint32_t alignment = required_output_alignment();
+			for (auto& e : m_nested) e->set_alignment(alignment);
+			for (auto& e : m_nested) {
+				if (e->output_width() != m_nested.front()->output_width()) throw std::runtime_error{"CompositeEncoding: nested encodings of a Sum / Product reduction must have the same output width"};
+			}
 		}
 	}
 	uint32_t input_width() const override { return m_n_dims; }
-	uint32_t output_width() const override { // composite.h:352-366: the sum of the nested PADDED widths
+	uint32_t output_width() const override { // composite.h:352-366: the sum of the nested PADDED widths; reductions: the (common) padded width
+		if (m_reduction != Reduction::Concatenation) return m_nested.front()->padded_output_width();
 		uint32_t total = 0;
 		for (const auto& e : m_nested) total += e->padded_output_width();
 		return total;
@@ -791,6 +805,10 @@ public:
 		return a;
 	}
 	void set_padded_output_width(uint32_t padded) override { // composite.h:375-385: the last nested encoding absorbs the padding
+		if (m_reduction != Reduction::Concatenation) { // :381-384: every nested encoding is padded to the same width
+			for (auto& e : m_nested) e->set_padded_output_width(padded);
+			return;
+		}
 		const uint32_t prev = output_width() - m_nested.back()->padded_output_width();
 		CHECK_THROW(padded >= prev + m_nested.back()->output_width());
 		m_nested.back()->set_padded_output_width(padded - prev);
@@ -814,6 +832,19 @@ public:
 		ctx.nested.resize(m_nested.size());
 		uint32_t col = 0;
 		size_t p_off = 0;
+		if (m_reduction != Reduction::Concatenation) { // composite.h:259-300
+			const uint32_t w = reduction_width();
+			const size_t block_bytes = (size_t)n * w * elem;
+			ctx.to_reduce = ArenaBuf{stream, block_bytes * m_nested.size()}; // [nested][n][w]: kept for the product's backward pass
+			for (size_t i = 0; i < m_nested.size(); ++i) {
+				Encoding& e = *m_nested[i];
+				const MatView xs{x.data + (size_t)m_begin[i] * x.stride_dim, x.stride_sample, x.stride_dim};
+				ctx.nested[i] = e.forward(stream, n, xs, (const char*)params + p_off * elem, (char*)ctx.to_reduce.data() + i * block_bytes, prepare_input_gradients, prepare_param_gradients);
+				p_off += e.n_params();
+			}
+			composite_reduce_forward(stream, m_fp32, m_reduction == Reduction::Product, (size_t)n * w, (uint32_t)m_nested.size(), ctx.to_reduce.data(), out);
+			return ctx;
+		}
 		for (size_t i = 0; i < m_nested.size(); ++i) {
 			Encoding& e = *m_nested[i];
 			const uint32_t w = e.padded_output_width();
@@ -831,9 +862,35 @@ public:
 		CHECK_THROW(!dy_planes && ctx.nested.size() == m_nested.size());
 		const size_t elem = m_fp32 ? 4 : 2;
 		// input dims no nested encoding looks at have zero gradient
-		if (dL_dx && dL_dx->stride_dim == 1 && dL_dx->stride_sample == m_n_dims) HIP_CHECK_THROW(hipMemsetAsync(dL_dx->data, 0, (size_t)n * m_n_dims * sizeof(float), stream));
+		if (dL_dx) {
+			const bool aos = dL_dx->stride_dim == 1 && dL_dx->stride_sample == m_n_dims, soa = dL_dx->stride_sample == 1 && dL_dx->stride_dim == n;
+			if (aos || soa) {
+				HIP_CHECK_THROW(hipMemsetAsync(dL_dx->data, 0, (size_t)n * m_n_dims * sizeof(float), stream));
+			} else { // any other view: one strided column per input dim
+				for (uint32_t d = 0; d < m_n_dims; ++d) {
+					HIP_CHECK_THROW(hipMemset2DAsync(dL_dx->data + (size_t)d * dL_dx->stride_dim, (size_t)dL_dx->stride_sample * sizeof(float), 0, sizeof(float), n, stream));
+				}
+			}
+		}
 		uint32_t col = 0;
 		size_t p_off = 0;
+		if (m_reduction != Reduction::Concatenation) { // composite.h:302-330: dL/d(nested outputs) from dL/d(reduced output), then the nested passes
+			const uint32_t w = reduction_width();
+			const size_t block_bytes = (size_t)n * w * elem;
+			CHECK_THROW(ctx.to_reduce);
+			ArenaBuf dnested{stream, block_bytes * m_nested.size()};
+			composite_reduce_backward(stream, m_fp32, m_reduction == Reduction::Product, (size_t)n * w, (uint32_t)m_nested.size(), ctx.to_reduce.data(), dL_dy, dnested.data());
+			for (size_t i = 0; i < m_nested.size(); ++i) {
+				Encoding& e = *m_nested[i];
+				const MatView xs{x.data + (size_t)m_begin[i] * x.stride_dim, x.stride_sample, x.stride_dim};
+				MatViewMut dxs{};
+				if (dL_dx) dxs = MatViewMut{dL_dx->data + (size_t)m_begin[i] * dL_dx->stride_dim, dL_dx->stride_sample, dL_dx->stride_dim};
+				e.backward(stream, ctx.nested[i], n, xs, (const char*)dnested.data() + i * block_bytes, dL_dx ? &dxs : nullptr, (const char*)params + p_off * elem,
+				           grads ? (char*)grads + p_off * elem : nullptr, mode, false);
+				p_off += e.n_params();
+			}
+			return;
+		}
 		for (size_t i = 0; i < m_nested.size(); ++i) {
 			Encoding& e = *m_nested[i];
 			const uint32_t w = e.padded_output_width();
@@ -850,15 +907,29 @@ public:
 	Json hyperparams() const override {
 		Json j = Json::object();
 		j["otype"] = "Composite";
-		j["reduction"] = "Concatenation";
+		j["reduction"] = m_reduction == Reduction::Sum ? "Sum" : (m_reduction == Reduction::Product ? "Product" : "Concatenation");
 		Json nested = Json::array();
 		for (const auto& e : m_nested) nested.push_back(e->hyperparams());
 		j["nested"] = nested;
 		return j;
 	}
 private:
+	enum class Reduction { Concatenation, Sum, Product };
+	// Width of a reduction's operands.  The reference lays the nested outputs out at multiples of their UNPADDED width but
+	// reduces at multiples of the PADDED one (composite.h:274 against :261): the two agree -- and the result is defined --
+	// only when no nested output needs padding, which is what this build accepts.
+	uint32_t reduction_width() const {
+		for (const auto& e : m_nested) {
+			if (e->padded_output_width() != e->output_width()) {
+				throw std::runtime_error{"CompositeEncoding: a Sum / Product reduction needs nested encodings whose output width (" + std::to_string(e->output_width()) +
+				                         ") is a multiple of the required alignment (padded to " + std::to_string(e->padded_output_width()) + ")"};
+			}
+		}
+		return m_nested.front()->padded_output_width();
+	}
 	uint32_t m_n_dims;
 	Json m_config;
+	Reduction m_reduction = Reduction::Concatenation;
 	std::vector<std::unique_ptr<Encoding>> m_nested;
 	std::vector<uint32_t> m_begin;
 };

@@ -148,6 +148,9 @@ void identity_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t
 // Frequency / TriangleWave (k_encodings.hip): dy_dx (optional) float [n][n_dims * outputs_per_input], consumed by the backward pass
 void periodic_forward(hipStream_t stream, bool triangle, bool fp32, uint32_t n, uint32_t n_dims, uint32_t n_frequencies, MatView x, void* out, uint32_t out_stride, float* dy_dx);
 void periodic_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims, uint32_t outputs_per_input, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
+// Composite encoding reductions (composite.h:47-133): `in` holds the nested outputs [n_nested][n_elems], T = float if fp32 else half
+void composite_reduce_forward(hipStream_t stream, bool fp32, bool product, size_t n_elems, uint32_t n_nested, const void* in, void* out);
+void composite_reduce_backward(hipStream_t stream, bool fp32, bool product, size_t n_elems, uint32_t n_nested, const void* in, const void* dL_dout, void* dL_din);
 // SphericalHarmonics: degree^2 outputs, the padding columns FIRST (spherical_harmonics.h:58-64)
 void sh_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t degree, MatView x, void* out, uint32_t out_stride);
 void sh_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t degree, MatView x, const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx);
