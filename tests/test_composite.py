@@ -208,6 +208,8 @@ def test_composite_reductions_match_oracle(tcnn, oracle, reduction):
     gx, gp = native.bwd(nctx, xt, pt, out, _t(dy.view(np.float16)))
     assert np.array_equal(_bits(gp), want_g)
     assert np.allclose(gx.cpu().numpy(), want_dx, rtol=1e-4, atol=1e-5)
+    if reduction == "Product":
+        return  # at the grids' initial scale (1e-4) a product of three factors is zero in fp16: nothing to learn from
     # trains inside a network: 16 reduced features -> 64 x 2 MLP
     tr = tcnn.Trainer(3, 3, {"loss": {"otype": "L2"}, "optimizer": {"otype": "Adam", "learning_rate": 1e-2}, "encoding": cfg,
                              "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}}, seed=1337)
