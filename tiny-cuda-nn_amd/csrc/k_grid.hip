@@ -65,7 +65,13 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 		if (interpolation == (uint32_t)InterpolationType::Nearest) { // grid.h:121-140
 			const uint32_t index = level_index<D>(lv, primes, hash_type, cell);
 			const vecF v = *(const vecF*)&lgrid[(size_t)index * F];
-			if (chunk_mask) chunk_mask[(size_t)level * n + i] = 1ull << scatter_chunk(lv, index);
+			if (chunk_mask) {
+				const uint32_t ch = scatter_chunk(lv, index);
+#pragma unroll
+				for (uint32_t half = 0; half < GRID_FILTER_MAX_CHUNKS / 64; ++half) {
+					chunk_mask[((size_t)level * n + i) * (GRID_FILTER_MAX_CHUNKS / 64) + half] = (ch >> 6) == half ? 1ull << (ch & 63u) : 0ull;
+				}
+			}
 #pragma unroll
 			for (int f = 0; f < F; ++f) { if constexpr (F == 1) res[ll * F + f] = v; else res[ll * F + f] = v[f]; }
 			if (dy_dx) {
@@ -79,7 +85,9 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 
 		// N-linear interpolation (grid.h:142-169): weight product in fp32 (dim order), cast to T, fma chain in corner order
 		T acc[F];
-		unsigned long long touched = 0; // scatter chunks of this level the sample's corners fall into
+		unsigned long long touched[GRID_FILTER_MAX_CHUNKS / 64]; // scatter chunks of this level the sample's corners fall into
+#pragma unroll
+		for (uint32_t half = 0; half < GRID_FILTER_MAX_CHUNKS / 64; ++half) touched[half] = 0;
 #pragma unroll
 		for (int f = 0; f < F; ++f) acc[f] = (T)0.0f;
 #pragma unroll
@@ -98,7 +106,11 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 			}
 			const uint32_t index = level_index<D>(lv, primes, hash_type, local);
 			const vecF v = *(const vecF*)&lgrid[(size_t)index * F];
-			touched |= 1ull << scatter_chunk(lv, index);
+			{
+				const uint32_t ch = scatter_chunk(lv, index);
+#pragma unroll
+				for (uint32_t half = 0; half < GRID_FILTER_MAX_CHUNKS / 64; ++half) touched[half] |= (ch >> 6) == half ? 1ull << (ch & 63u) : 0ull;
+			}
 			// The reference rounds the fp32 weight product to fp32 FIRST and to T afterwards.  Without this barrier hipcc
 			// folds "fp32 multiply + convert" into v_fma_mixlo_f16 (one rounding from the exact product), which differs
 			// from the reference in ~1e-5 of the weights.
@@ -113,7 +125,10 @@ __global__ void __launch_bounds__(256) k_grid_fwd(
 		}
 #pragma unroll
 		for (int f = 0; f < F; ++f) res[ll * F + f] = acc[f];
-		if (chunk_mask) chunk_mask[(size_t)level * n + i] = touched;
+		if (chunk_mask) {
+#pragma unroll
+			for (uint32_t half = 0; half < GRID_FILTER_MAX_CHUNKS / 64; ++half) chunk_mask[((size_t)level * n + i) * (GRID_FILTER_MAX_CHUNKS / 64) + half] = touched[half];
+		}
 
 		if (dy_dx) { // grid.h:172-211
 			float grads[F][D];

@@ -22,7 +22,8 @@ namespace {
 
 constexpr int FP_THREADS = 128; // 2 waves per workgroup
 
-constexpr int FP_MAX_CHUNKS = 64; // bit planes per level: levels cut into more chunks get no filter (they are binned, k_grid_bin.hip)
+constexpr int FP_MAX_CHUNKS = GRID_FILTER_MAX_CHUNKS; // bit planes per level: levels cut into more chunks get no filter (they are binned, k_grid_bin.hip)
+constexpr int FP_PER_LANE = FP_MAX_CHUNKS / 64;       // chunks whose words one lane carries out (chunk = lane + 64 j)
 
 // FP_SPT = samples per thread = consecutive 64-sample groups per wave; a work item is FP_THREADS * FP_SPT samples of one level.
 // Two shapes: 8 (32 gathers in flight per thread), and 2 for the big 3-D grids whose 8 corners x 4 features would not fit the registers.
@@ -66,7 +67,9 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 
 		if (lds_or) {
 #pragma unroll
-			for (int k = 0; k < FP_SPT; ++k) planes[wave][k][lane] = 0ull;
+			for (int k = 0; k < FP_SPT; ++k)
+#pragma unroll
+				for (int j = 0; j < FP_PER_LANE; ++j) planes[wave][k][lane + 64 * j] = 0ull;
 		}
 
 		// ---- phase 1: positions, indices, all gathers in flight.
@@ -173,32 +176,37 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 			}
 		}
 
-		// ---- phase 3: bit planes.  Lane c ends up with the FP_SPT consecutive words of chunk c: one dense run per lane.
+		// ---- phase 3: bit planes.  Lane c ends up with the FP_SPT consecutive words of chunk c (and of chunk c + 64): dense runs per lane.
 		if (want_bits) {
-			unsigned long long mine[FP_SPT];
-			if (lds_or) {
-				__builtin_amdgcn_wave_barrier(); // LDS serves one wave's instructions in order; keep the compiler from moving the reads up
 #pragma unroll
-				for (int k = 0; k < FP_SPT; ++k) mine[k] = planes[wave][k][lane];
-			} else {
+			for (int j = 0; j < FP_PER_LANE; ++j) {
+				if (j > 0 && !lds_or) break; // the ballot form serves levels with at most 8 chunks
+				unsigned long long mine[FP_SPT];
+				const uint32_t ch = lane + 64 * j;
+				if (lds_or) {
+					__builtin_amdgcn_wave_barrier(); // LDS serves one wave's instructions in order; keep the compiler from moving the reads up
 #pragma unroll
-				for (int k = 0; k < FP_SPT; ++k) {
-					mine[k] = 0;
-					for (uint32_t c = 0; c < n_chunks; ++c) {
-						const unsigned long long b = __ballot((touched[k] >> c) & 1ull);
-						if (lane == c) mine[k] = b;
-					}
-				}
-			}
-			if (lane < n_chunks) {
-				unsigned long long* dst = bits + ((size_t)level * FP_MAX_CHUNKS + lane) * n_words + base / 64;
-				if (base + FP_WAVE_SAMPLES <= n) {
-					typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-					for (int k = 0; k < FP_SPT; k += 2) *(u64x2*)&dst[k] = u64x2{mine[k], mine[k + 1]};
+					for (int k = 0; k < FP_SPT; ++k) mine[k] = planes[wave][k][ch];
 				} else {
 #pragma unroll
-					for (int k = 0; k < FP_SPT; ++k) if (base + k * 64 < n) dst[k] = mine[k];
+					for (int k = 0; k < FP_SPT; ++k) {
+						mine[k] = 0;
+						for (uint32_t c = 0; c < n_chunks; ++c) {
+							const unsigned long long b = __ballot((touched[k] >> c) & 1ull);
+							if (lane == c) mine[k] = b;
+						}
+					}
+				}
+				if (ch < n_chunks) {
+					unsigned long long* dst = bits + ((size_t)level * FP_MAX_CHUNKS + ch) * n_words + base / 64;
+					if (base + FP_WAVE_SAMPLES <= n) {
+						typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+						for (int k = 0; k < FP_SPT; k += 2) *(u64x2*)&dst[k] = u64x2{mine[k], mine[k + 1]};
+					} else {
+#pragma unroll
+						for (int k = 0; k < FP_SPT; ++k) if (base + k * 64 < n) dst[k] = mine[k];
+					}
 				}
 			}
 		}
@@ -221,7 +229,7 @@ uint32_t max_scatter_chunks(const GridMeta& meta) {
 } // namespace
 
 // samples per thread of the kernel shape used for this grid (see k_grid_fwd_planes)
-uint32_t grid_planes_spt(const GridMeta& meta) { return max_scatter_chunks(meta) <= 64 ? 8u : 2u; }
+uint32_t grid_planes_spt(const GridMeta& meta) { return max_scatter_chunks(meta) <= (uint32_t)FP_MAX_CHUNKS ? 8u : 2u; }
 
 bool grid_planes_supported(const GridMeta& meta, uint32_t n) {
 	const uint32_t F = meta.n_features_per_level;

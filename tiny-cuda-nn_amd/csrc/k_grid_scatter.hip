@@ -33,13 +33,24 @@
 namespace tcnn_amd {
 namespace {
 
-constexpr uint32_t SCATTER_ACC_BYTES = 128 * 1024; // accumulator chunk per workgroup
-constexpr uint32_t SCATTER_THREADS = 1024;
+// One workgroup of 16 waves per CU owning 128 KB of accumulators.  The other shape the LDS allows -- two workgroups of 8 waves
+// with 64 KB each, i.e. tables cut into 128 chunks per level (GRID_FILTER_MAX_CHUNKS = 128) -- was built and measured on C3a:
+// k_grid_scatter 69 -> 89 us (twice the tasks, each still scanning a whole bit plane of n / 64 words and paying its own
+// zeroing and flush for half the hits) and k_grid_fwd_planes 58 -> 71 us (twice the filter words to build and write).
+// TCNN_SCATTER_ACC_KB / TCNN_SCATTER_THREADS / GRID_FILTER_MAX_CHUNKS (tcnn_common.h) are the compile-time knobs of that build.
+#ifndef TCNN_SCATTER_ACC_KB
+#define TCNN_SCATTER_ACC_KB 128
+#endif
+#ifndef TCNN_SCATTER_THREADS
+#define TCNN_SCATTER_THREADS 1024
+#endif
+constexpr uint32_t SCATTER_ACC_BYTES = TCNN_SCATTER_ACC_KB * 1024; // accumulator chunk per workgroup
+constexpr uint32_t SCATTER_THREADS = TCNN_SCATTER_THREADS;
 constexpr uint32_t SCATTER_WAVES = SCATTER_THREADS / 64;
 constexpr int SCATTER_SUB_BATCHES = 2;             // 64-sample batches whose gathers are in flight together per wave
 constexpr uint32_t SCATTER_QUEUE_IDS = 64 * SCATTER_SUB_BATCHES + 64; // wave-private compaction queue (sample ids)
 constexpr uint32_t SCATTER_LDS_BYTES = SCATTER_ACC_BYTES + SCATTER_WAVES * SCATTER_QUEUE_IDS * 4;
-constexpr uint32_t SCATTER_MAX_CHUNKS = 64;        // bit planes per level (the forward mask is a uint64); levels cut finer are binned (k_grid_bin.hip)
+constexpr uint32_t SCATTER_MAX_CHUNKS = GRID_FILTER_MAX_CHUNKS; // bit planes per level; levels cut finer are binned (k_grid_bin.hip)
 
 // REC: dL_dy holds 16-byte records {D coordinates, gradient halves} written by the fused MLP kernel
 // (mlp_device.h store_dx_record; float4 [level][n], or [level / 2][n] where two levels fit one record): one gather per hit instead of two -- gathers cost ~2 clk per lane per CU whatever their width.
@@ -383,22 +394,28 @@ __global__ void __launch_bounds__(256) k_grid_scatter_finalize(const GridScatter
 	}
 }
 
-// [n_levels][n] uint64 masks (written by k_grid_fwd) -> bit planes [n_levels][64][n / 64] uint64: word w of plane (l, c)
-// is the ballot "sample 64 w + lane touches chunk c of level l".  One wave per 64 samples of one level.
+// [n_levels][n][2] uint64 masks (written by k_grid_fwd: bit c of the 128-bit mask = the sample touches chunk c) -> bit planes
+// [n_levels][128][n / 64] uint64: word w of plane (l, c) is the ballot "sample 64 w + lane touches chunk c of level l".
+// One wave per 64 samples of one level.
 __global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __restrict__ meta, const uint32_t n, const unsigned long long* __restrict__ mask, unsigned long long* __restrict__ bits) {
 	const uint32_t level = blockIdx.y;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return; // n is a multiple of 64: whole waves leave together
 	const uint32_t n_chunks = meta->levels[level].scatter_n_chunks;
-	if (n_chunks <= 1 || n_chunks > SCATTER_MAX_CHUNKS) return; // one chunk: no filter; more than 64: binned level, no filter either
-	const unsigned long long m = mask[(size_t)level * n + i];
+	if (n_chunks <= 1 || n_chunks > SCATTER_MAX_CHUNKS) return; // one chunk: no filter; more than the filter describes: binned level, no filter either
 	const uint32_t lane = threadIdx.x & 63;
-	unsigned long long mine = 0;
-	for (uint32_t c = 0; c < n_chunks; ++c) {
-		const unsigned long long b = __ballot((m >> c) & 1ull);
-		if (lane == c) mine = b;
+#pragma unroll
+	for (uint32_t half = 0; half < SCATTER_MAX_CHUNKS / 64; ++half) {
+		if (64 * half >= n_chunks) break;
+		const unsigned long long m = mask[((size_t)level * n + i) * (SCATTER_MAX_CHUNKS / 64) + half];
+		unsigned long long mine = 0;
+		const uint32_t here = min(n_chunks - 64 * half, 64u);
+		for (uint32_t c = 0; c < here; ++c) {
+			const unsigned long long b = __ballot((m >> c) & 1ull);
+			if (lane == c) mine = b;
+		}
+		if (lane < here) bits[((size_t)level * SCATTER_MAX_CHUNKS + 64 * half + lane) * (n / 64) + i / 64] = mine;
 	}
-	if (lane < n_chunks) bits[((size_t)level * SCATTER_MAX_CHUNKS + lane) * (n / 64) + i / 64] = mine;
 }
 
 // set by grid_backward_lds for the duration of one launch: device buffer uint64[n_tasks][8] that receives the per-task
@@ -491,7 +508,7 @@ void grid_scatter_setup_levels(GridMeta& meta) {
 		// of the filtered form costs several gathers (no 16-byte records: 3-D with F = 4) binning already wins from 9 chunks on
 		// (measured on C5: the 64-chunk level 2.4x faster; on C3a, with records, the filtered form is 1.5x faster at 64 chunks).
 		// TCNN_AMD_BIN_MIN_CHUNKS=k moves the threshold (levels with more than k chunks are binned), for A/B runs.
-		uint32_t bin_above = grid_scatter_records_supported(meta) ? SCATTER_MAX_CHUNKS : 8u;
+		uint32_t bin_above = grid_scatter_records_supported(meta) ? SCATTER_MAX_CHUNKS : SCATTER_MAX_CHUNKS / 8u;
 		if (const char* e = getenv("TCNN_AMD_BIN_MIN_CHUNKS")) bin_above = std::min<uint32_t>((uint32_t)std::max(atoi(e), 1), SCATTER_MAX_CHUNKS);
 		const uint32_t bin_capacity = grid_bin_acc_bytes() / (meta.n_features_per_level * 8); // the binned kernels have their own chunk size
 		lv.scatter_binned = (lv.scatter_n_chunks > bin_above && div_round_up(lv.size, bin_capacity) <= grid_bin_max_chunks() && grid_bin_supported(meta)) ? 1u : 0u;
@@ -511,7 +528,7 @@ void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta*
 // x = 256 - ceil(N_f / R) CUs busy for those R rounds; they are launched first.  Without this the coarse tasks were sized
 // like the fine ones and the ~850 equal tasks needed a fourth, nearly empty round (20 of 88 us on C3a).
 static void tuned_splits(const GridMeta& meta, uint32_t n, const std::vector<float>& level_us, std::vector<uint32_t>& splits) {
-	const uint32_t n_cus = 256;
+	const uint32_t n_cus = 256 * std::max(1u, (160u * 1024u) / SCATTER_LDS_BYTES); // workgroups that run at once
 	double w_coarse = 0, w_fine = 0;
 	uint32_t n_fine = 0;
 	auto is_fine = [&](uint32_t l) { return meta.levels[l].scatter_n_chunks > 8; };

@@ -393,7 +393,7 @@ public:
 		if (prepare_input_gradients) ctx.dy_dx = ArenaBuf{stream, (size_t)n * m_n_features * m_meta.n_pos_dims * sizeof(float)};
 		const bool want_filter = prepare_param_gradients && lds_scatter_usable() && n % 64 == 0;
 		ArenaBuf mask;
-		if (want_filter) mask = ArenaBuf{stream, (size_t)m_meta.n_levels * n * sizeof(uint64_t)};
+		if (want_filter) mask = ArenaBuf{stream, (size_t)m_meta.n_levels * n * (GRID_FILTER_MAX_CHUNKS / 64) * sizeof(uint64_t)};
 		grid_forward(stream, m_meta, dev_meta(), m_fp32, n, x, params, out, padded_output_width(), ctx.dy_dx.as<float>(), mask.as<uint64_t>());
 		if (want_filter) {
 			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_scatter_max_chunks() * (n / 64) * sizeof(uint64_t)};

@@ -79,11 +79,11 @@ struct MatViewMut {
 };
 
 // half data travels as void* on the host side
-// chunk_mask (optional, uint64 [n_levels][n]): bit c set <=> the sample touches scatter chunk c of that level (filter for k_grid_scatter)
+// chunk_mask (optional, uint64 [n_levels][n][GRID_FILTER_MAX_CHUNKS / 64]): bit c set <=> the sample touches scatter chunk c of that level (filter for k_grid_scatter)
 void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32, uint32_t n, MatView x, const void* grid, void* out, uint32_t out_stride, float* dy_dx,
                   uint64_t* chunk_mask);
 // ---- training-step forward (k_grid_planes.hip): half, F >= 2, D in {2, 3}; level-major and XCD-aware.
-// out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][64][n / 64], written for levels with 2 .. 64 scatter chunks.
+// out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][GRID_FILTER_MAX_CHUNKS][n / 64], written for levels with 2 .. GRID_FILTER_MAX_CHUNKS scatter chunks.
 bool grid_planes_supported(const GridMeta& meta, uint32_t n);
 uint32_t grid_planes_spt(const GridMeta& meta);        // samples per thread of the kernel shape used for this grid
 void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd);
@@ -103,7 +103,8 @@ struct GridScatterTask {
 	uint32_t pad;
 };
 struct GridScatterRange { size_t grad_begin; uint32_t n_elems; uint32_t scratch_begin; uint32_t pad; }; // shared chunks, for the finalize pass
-uint32_t grid_scatter_max_chunks();                 // chunks per level the sample filter can describe (64)
+constexpr uint32_t GRID_FILTER_MAX_CHUNKS = 64;     // chunks per level the sample filter can describe (bit planes per level)
+uint32_t grid_scatter_max_chunks();                 // = GRID_FILTER_MAX_CHUNKS
 void grid_scatter_setup_levels(GridMeta& meta);     // fills GridLevel::scatter_* (how each level's table is cut into chunks)
 // Plans the task list for a batch of n samples (half gradients, F >= 2).
 // measured_level_us (optional): per-level workgroup time of a first launch (grid_scatter_level_costs) -> tuned task sizes
@@ -111,7 +112,7 @@ void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatter
                        const std::vector<float>* measured_level_us = nullptr);
 // times: uint64[tasks.size()][8] copied back from grid_backward_lds(task_times)
 std::vector<float> grid_scatter_level_costs(const GridMeta& meta, const std::vector<GridScatterTask>& tasks, const std::vector<uint64_t>& times);
-// chunk_mask [n_levels][n] uint64 -> chunk_bits [n_levels][64][n / 64] uint64 (one ballot word per 64 samples per (level, chunk))
+// chunk_mask [n_levels][n][GRID_FILTER_MAX_CHUNKS / 64] uint64 -> chunk_bits [n_levels][GRID_FILTER_MAX_CHUNKS][n / 64] uint64 (one ballot word per 64 samples per (level, chunk))
 void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, const uint64_t* chunk_mask, uint64_t* chunk_bits);
 // dL_dy element (sample i, level l, feature f) at dL_dy[i * dy_stride_sample + l * dy_stride_level + f].
 // chunk_bits: optional filter derived from grid_forward's masks for the SAME batch (n samples); nullptr -> every sample is examined in full.
