@@ -457,7 +457,7 @@ public:
 				cast_float_to_half(stream, n_params(), tmp.as<float>(), grads);
 			} else if (lds_scatter_usable() && n % 64 == 0) {
 				// MI355X path: LDS owner-computes scatter with exact integer accumulation; writes every element (k_grid_scatter.hip)
-				ScatterPlan& plan = scatter_plan(n);
+				ScatterPlan& plan = scatter_plan(n, stream);
 				const uint32_t F = m_meta.n_features_per_level;
 				const uint64_t* mask = (ctx.chunk_mask && ctx.n == n) ? ctx.chunk_mask.as<uint64_t>() : nullptr;
 				// The second filtered launch at this batch size is timed per task and the plan re-cut from the measured
@@ -578,12 +578,16 @@ public:
 		plan.scratch.resize(scratch_elems * sizeof(uint64_t));
 		plan.scratch.memset(0); // the finalize pass leaves it zeroed again after every step
 	}
-	ScatterPlan& scatter_plan(uint32_t n) {
-		auto it = m_scatter_plans.find(n);
+	// One plan per (batch size, stream): a plan owns mutable device state -- the scratch table of the shared chunks, which a step
+	// leaves zeroed for the next one, and the task list the tuner replaces after a stream synchronisation -- so two streams that
+	// run backward passes of this encoding at the same time must not share one.  Steps on ONE stream are ordered and may.
+	ScatterPlan& scatter_plan(uint32_t n, hipStream_t stream) {
+		const auto key = std::make_pair(n, (const void*)stream);
+		auto it = m_scatter_plans.find(key);
 		if (it != m_scatter_plans.end()) return *it->second;
 		auto plan = std::make_unique<ScatterPlan>();
 		build_scatter_plan(*plan, n, nullptr);
-		return *(m_scatter_plans[n] = std::move(plan));
+		return *(m_scatter_plans[key] = std::move(plan));
 	}
 
 	Json hyperparams() const override { // grid.h:1098-1115
@@ -606,7 +610,7 @@ public:
 private:
 	GridMeta m_meta;
 	DeviceBuf m_dev_meta;
-	std::map<uint32_t, std::unique_ptr<ScatterPlan>> m_scatter_plans;
+	std::map<std::pair<uint32_t, const void*>, std::unique_ptr<ScatterPlan>> m_scatter_plans;
 	std::map<uint32_t, std::unique_ptr<PlanesPlan>> m_planes_plans;
 	bool m_scatter_levels_ok = true;
 	bool m_any_binned = false;
