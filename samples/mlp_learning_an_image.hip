@@ -12,19 +12,22 @@
 // coordinates, linear filter, clamp addressing); here k_eval_image does the same arithmetic in a plain HIP kernel:
 //   xB = x * W - 0.5, i = floor(xB), alpha = frac(xB) rounded to 8 fractional bits (the texture unit's 9-bit fixed-point weights),
 //   value = (1-a)(1-b) T[i][j] + a(1-b) T[i+1][j] + (1-a) b T[i][j+1] + a b T[i+1][j+1], indices clamped to the image.
-// Image files: binary PPM (P6) / PGM (P5), 8 bit, decoded like stbi_loadf does (value = (v / 255)^2.2, RGBA floats); "synthetic[:WxH]"
-// renders a deterministic multi-scale test image.  JPEG decoding is the reference's vendored third-party stb_image and is not
-// part of this repository: convert first (e.g. `convert albert.jpg albert.ppm`).  Outputs are written as PPM.
+// Image files: JPEG (baseline and progressive, samples/jpeg_decoder.h -- the reference's data/images/albert.jpg loads as it is) and
+// binary PPM (P6) / PGM (P5), 8 bit, all turned into what stbi_loadf hands the reference's samples (value = (v / 255)^2.2, RGBA
+// floats; stbi_wrapper.cpp:37-44); "synthetic[:WxH]" renders a deterministic multi-scale test image.  Outputs are written as PPM.
 //
-// usage:  mlp_learning_an_image <image.ppm|image.pgm|synthetic[:WxH]> [config.json] [n_training_steps] [final_image.ppm]
+// usage:  mlp_learning_an_image <image.jpg|image.ppm|image.pgm|synthetic[:WxH]> [config.json] [n_training_steps] [final_image.ppm]
 //         mlp_learning_an_image --bench <image> <config.json> [result.json] [--batches 18,16] [--cooldown SECONDS]
 //         mlp_learning_an_image --sample <image> <coords.f32> <out.f32>      (k_eval_image on given coordinates; used by the tests)
 #include <tiny-cuda-nn/config.h>
 #include <tiny-cuda-nn/random.h>
 
+#include "jpeg_decoder.h"
+
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <iterator>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -115,9 +118,31 @@ static std::vector<float> synthetic_image(int width, int height) {
 	return img;
 }
 
+// 8-bit samples -> the floats stbi_loadf hands the reference's samples: linear RGBA with gamma 2.2, alpha 1
+static std::vector<float> ldr_to_linear_rgba(const uint8_t* raw, int width, int height, int comps) {
+	std::vector<float> img((size_t)width * height * 4);
+	float lut[256];
+	for (int v = 0; v < 256; ++v) lut[v] = std::pow(v / 255.0f, 2.2f); // stbi_loadf: LDR -> linear with gamma 2.2
+	for (size_t p = 0; p < (size_t)width * height; ++p) {
+		for (int c = 0; c < 3; ++c) img[p * 4 + c] = lut[raw[p * comps + (comps == 3 ? c : 0)]];
+		img[p * 4 + 3] = 1.0f;
+	}
+	return img;
+}
+
 static std::vector<float> load_pnm(const std::string& filename, int& width, int& height) {
 	std::ifstream f{filename, std::ios::binary};
 	if (!f) throw std::runtime_error{"Could not open image file '" + filename + "'."};
+	if (f.get() == 0xFF && f.get() == 0xD8) { // JPEG (baseline or progressive; samples/jpeg_decoder.h): e.g. the reference's data/images/albert.jpg
+		f.seekg(0);
+		const std::vector<uint8_t> bytes{std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>()};
+		const jpeg_lite::Image img = jpeg_lite::decode(bytes.data(), bytes.size());
+		width = img.width;
+		height = img.height;
+		return ldr_to_linear_rgba(img.pixels.data(), width, height, img.channels);
+	}
+	f.clear();
+	f.seekg(0);
 	auto token = [&]() {
 		std::string t;
 		for (;;) {
@@ -130,7 +155,7 @@ static std::vector<float> load_pnm(const std::string& filename, int& width, int&
 		return t;
 	};
 	const std::string magic = token();
-	if (magic != "P5" && magic != "P6") throw std::runtime_error{"'" + filename + "' is not a binary PPM (P6) or PGM (P5) file (JPEG/PNG: convert first)."};
+	if (magic != "P5" && magic != "P6") throw std::runtime_error{"'" + filename + "' is neither a JPEG nor a binary PPM (P6) / PGM (P5) file (PNG and others: convert first)."};
 	width = std::stoi(token());
 	height = std::stoi(token());
 	const int maxval = std::stoi(token());
@@ -139,14 +164,7 @@ static std::vector<float> load_pnm(const std::string& filename, int& width, int&
 	std::vector<uint8_t> raw((size_t)width * height * comps);
 	f.read((char*)raw.data(), (std::streamsize)raw.size());
 	if ((size_t)f.gcount() != raw.size()) throw std::runtime_error{"'" + filename + "' is truncated."};
-	std::vector<float> img((size_t)width * height * 4);
-	float lut[256];
-	for (int v = 0; v < 256; ++v) lut[v] = std::pow(v / 255.0f, 2.2f); // stbi_loadf: LDR -> linear with gamma 2.2
-	for (size_t p = 0; p < (size_t)width * height; ++p) {
-		for (int c = 0; c < 3; ++c) img[p * 4 + c] = lut[raw[p * comps + (comps == 3 ? c : 0)]];
-		img[p * 4 + 3] = 1.0f;
-	}
-	return img;
+	return ldr_to_linear_rgba(raw.data(), width, height, comps);
 }
 
 static GPUMemory<float> load_image(const std::string& spec, int& width, int& height) {

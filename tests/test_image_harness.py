@@ -119,3 +119,29 @@ def test_bench_protocol_writes_result_json(exe, tmp_path):
         for row in res[method]:
             assert row["training_throughput"] > 1e6 and row["inference_throughput"] > row["training_throughput"]
             assert row["psnr"] > 25.0
+
+
+@pytest.mark.gpu
+def test_sample_learns_a_progressive_jpeg(exe, tmp_path):
+    """BASELINE config 3 trains on a JPEG (data/images/albert.jpg, progressive, grayscale).  The harness reads JPEGs itself
+    (samples/jpeg_decoder.h): a progressive grayscale file written by PIL goes through decode -> gamma 2.2 -> bilinear lookup ->
+    training with the hash-grid config, and the learned image approaches the decoded one."""
+    Image = pytest.importorskip("PIL.Image")
+    h, w = 384, 512
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = 128 + 70 * np.sin(x / 23.0) * np.cos(y / 31.0) + 40 * np.sin((x + y) / 9.0) + 20 * (((x // 32 + y // 32) % 2) - 0.5)
+    jpg = tmp_path / "target.jpg"
+    Image.fromarray(np.clip(img, 0, 255).astype(np.uint8), mode="L").save(jpg, format="JPEG", quality=92, progressive=True)
+    assert b"\xff\xc2" in jpg.read_bytes()
+    cfg = os.path.join(ROOT, "samples", "config_hash.json")
+    final = tmp_path / "final.ppm"
+    r = subprocess.run([exe, str(jpg), cfg, "300", str(final)], capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    psnr = float([l for l in r.stdout.splitlines() if l.startswith("PSNR")][-1].split(":")[1].split()[0])
+    assert psnr > 30.0, r.stdout
+    # reference.ppm is the lookup of the decoded file at the pixel centres: the decoder's output, gamma there and back
+    ref = open(tmp_path / "reference.ppm", "rb").read()
+    assert ref.startswith(b"P6\n512 384\n255\n")
+    got = np.frombuffer(ref[len(b"P6\n512 384\n255\n"):], dtype=np.uint8).reshape(h, w, 3).astype(np.int32)
+    want = np.asarray(Image.open(jpg).convert("L"), dtype=np.int32)
+    assert np.abs(got[:, :, 0] - want).max() <= 3 and np.array_equal(got[:, :, 0], got[:, :, 1])

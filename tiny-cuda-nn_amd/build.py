@@ -58,7 +58,7 @@ def build_samples(verbose=False):
     """samples/mlp_learning_an_image: the caller harness (its own HIP kernels + the C++ header API), linked against the library."""
     src = os.path.join(SAMPLES, "mlp_learning_an_image.hip")
     exe = os.path.join(SAMPLES, "mlp_learning_an_image")
-    deps = [src, LIB] + [os.path.join(INCLUDE, "tiny-cuda-nn", h) for h in ("tcnn_api.h", "random.h", "json_lite.h")] + [os.path.join(INCLUDE, "tcnn_amd.h")]
+    deps = [src, os.path.join(SAMPLES, "jpeg_decoder.h"), LIB] + [os.path.join(INCLUDE, "tiny-cuda-nn", h) for h in ("tcnn_api.h", "random.h", "json_lite.h")] + [os.path.join(INCLUDE, "tcnn_amd.h")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < _newest(deps):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", INCLUDE, src, "-o", exe, "-L", HERE, "-ltcnn_amd",
                                "-Wl,-rpath,$ORIGIN/../tiny-cuda-nn_amd"])
