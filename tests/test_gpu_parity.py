@@ -494,7 +494,9 @@ def test_training_step_variants_agree_bitwise(tcnn, oracle, cfg, n_in, monkeypat
 
     base_g, base_out = grads({})
     assert np.any(base_g[n_net:] != 0)
-    for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_SCATTER_RECORDS": "0", "TCNN_AMD_SCATTER_TUNE": "0"}):
+    # TCNN_AMD_SIDE_JOBS=0: the fragment images and the slab reduction as launches of their own instead of riding on the encoding's
+    # forward kernel and the grid scatter (mlp_side_jobs.h): the same arithmetic
+    for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_SCATTER_RECORDS": "0", "TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_SIDE_JOBS": "0"}):
         g, out = grads(env)
         assert np.array_equal(out, base_out), env
         assert np.array_equal(g, base_g), env
@@ -581,10 +583,10 @@ def test_fused_mlp_kernel_forms_agree_at_full_batch(tcnn, oracle, monkeypatch, n
 
     g0, o0, L0, d0, l0 = run({})
     assert np.isfinite(l0) and np.any(g0[n_net:] != 0)
-    for env in ({"TCNN_AMD_MLP_FAST": "0"}, {"TCNN_AMD_MLP_REGS": "0"}):
+    for env in ({"TCNN_AMD_MLP_FAST": "0"}, {"TCNN_AMD_SIDE_JOBS": "0"}, {"TCNN_AMD_MLP_REGS": "0"}):
         g, o, L, d, l = run(env)
         assert np.array_equal(o, o0) and np.array_equal(L, L0) and np.array_equal(d, d0), env
-        if "TCNN_AMD_MLP_FAST" in env:
+        if "TCNN_AMD_MLP_REGS" not in env:
             assert np.array_equal(g, g0), env
         for lo, hi in ((0, n_net), (n_net, len(g))):
             a, b = _f32(g[lo:hi]), _f32(g0[lo:hi])

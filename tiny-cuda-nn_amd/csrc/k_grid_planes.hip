@@ -11,6 +11,7 @@
 //     here, in LDS with integer ORs (or ballots for levels with few chunks), instead of a uint64 mask per (sample, level)
 //     in HBM plus a transposition kernel.
 #include "grid_device.h"
+#include "mlp_side_jobs.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -30,9 +31,13 @@ constexpr int FP_PER_LANE = FP_MAX_CHUNKS / 64;       // chunks whose words one 
 template <int D, int F, int FP_SPT>
 __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 	const GridMeta* __restrict__ meta, const uint32_t* __restrict__ work, const uint32_t max_items, const uint32_t blocks_per_xcd, const uint32_t n, const MatView x,
-	const half_t* __restrict__ grid, half_t* __restrict__ out, unsigned long long* __restrict__ bits
+	const half_t* __restrict__ grid, half_t* __restrict__ out, unsigned long long* __restrict__ bits, const MlpPrepJob prep
 ) {
 	typedef typename VecOf<half_t, F>::type vecF;
+	if (prep.image) { // side job (mlp_side_jobs.h): the fragment images of the network this batch is encoded for; independent of everything below
+		const uint32_t total = (prep.desc.n_frags_fwd + prep.desc.n_frags_bwd) * 512;
+		for (uint32_t e = blockIdx.x * FP_THREADS + threadIdx.x; e < total; e += gridDim.x * FP_THREADS) mlp_prep_element(prep.desc, (const half_t*)prep.params, (half_t*)prep.image, e);
+	}
 	constexpr int FP_WAVE_SAMPLES = 64 * FP_SPT;
 	constexpr int FP_ITEM_SAMPLES = FP_THREADS * FP_SPT;
 	__shared__ unsigned long long planes[FP_THREADS / 64][FP_SPT][FP_MAX_CHUNKS];
@@ -214,9 +219,12 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 }
 
 template <int D, int F, int SPT>
-void launch_planes(hipStream_t s, const GridMeta* dm, const uint32_t* work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n, MatView x, const void* grid, void* out, uint64_t* bits) {
+void launch_planes(hipStream_t s, const GridMeta* dm, const uint32_t* work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n, MatView x, const void* grid, void* out, uint64_t* bits,
+                   const MlpPrepJob* prep_job) {
+	MlpPrepJob prep{};
+	if (prep_job) prep = *prep_job;
 	hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
-	                   (unsigned long long*)bits);
+	                   (unsigned long long*)bits, prep);
 	HIP_CHECK_THROW(hipGetLastError());
 }
 
@@ -282,14 +290,14 @@ void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& w
 }
 
 void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
-                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits) {
+                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits, const MlpPrepJob* prep_job) {
 	CHECK_THROW(grid_planes_supported(meta, n));
 	const uint32_t F = meta.n_features_per_level;
 #define TCNN_PLANES_F(D, SPT) \
 	switch (F) { \
-		case 2: return launch_planes<D, 2, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
-		case 4: return launch_planes<D, 4, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
-		default: return launch_planes<D, 8, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits); \
+		case 2: return launch_planes<D, 2, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job); \
+		case 4: return launch_planes<D, 4, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job); \
+		default: return launch_planes<D, 8, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job); \
 	}
 #define TCNN_PLANES(D) \
 	if (grid_planes_spt(meta) == 8) { TCNN_PLANES_F(D, 8) } else { TCNN_PLANES_F(D, 2) }

@@ -21,6 +21,7 @@
 //   (elements 0..3 come from accumulator tile 2s, elements 4..7 from tile 2s+1.)
 //   Layer 0 reads its B operand from memory ([n][in] half, 16 bytes per lane) in natural order k = 32 s + 8 q + j.
 #include "mlp_device.h"
+#include "mlp_side_jobs.h"
 
 namespace tcnn_amd {
 namespace {
@@ -35,34 +36,7 @@ namespace {
 __global__ void __launch_bounds__(256) k_mlp_prep(const MlpDesc d, const half_t* __restrict__ params, half_t* __restrict__ image, const uint32_t n_frags_total) {
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gid >= n_frags_total * 512) return;
-	uint32_t frag = gid >> 9;
-	const uint32_t lane = (gid >> 3) & 63;
-	const uint32_t j = gid & 7;
-	const uint32_t r = lane & 15, q = lane >> 4;
-
-	const bool bwd = frag >= d.n_frags_fwd;
-	if (bwd) frag -= d.n_frags_fwd;
-	uint32_t l = 0;
-	for (uint32_t i = 1; i < d.n_layers; ++i) {
-		if (frag >= (bwd ? d.layers[i].bwd_off : d.layers[i].fwd_off)) l = i;
-	}
-	const MlpLayer L = d.layers[l];
-	const half_t* W = params + L.w_off;
-	half_t v = (half_t)0.0f;
-	if (!bwd) {
-		const uint32_t local = frag - L.fwd_off;
-		const uint32_t t = local / L.ks_fwd, s = local - t * L.ks_fwd;
-		const uint32_t row = 16 * t + r;
-		const uint32_t k = L.natural_k ? k_natural(s, q, j) : k_chain(s, q, j);
-		if (row < L.rows && k < L.cols) v = W[(size_t)row * L.cols + k];
-	} else {
-		const uint32_t local = frag - L.bwd_off;
-		const uint32_t t = local / L.ks_bwd, s = local - t * L.ks_bwd;
-		const uint32_t col = 16 * t + r;
-		const uint32_t k = k_chain(s, q, j);
-		if (col < L.cols && k < L.rows) v = W[(size_t)k * L.cols + col];
-	}
-	image[gid] = v;
+	mlp_prep_element(d, params, image, gid); // mlp_side_jobs.h: the encoding's forward kernel can carry this along
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -493,31 +467,10 @@ __global__ void __launch_bounds__(256) k_wgrad(
 
 // Sum of the per-workgroup slabs.  64 elements x 16 slab groups per workgroup: group g adds slabs g, g + 16, ... with four
 // loads in flight, the 16 group sums are combined through LDS in a fixed order (bitwise reproducible, no atomics).
-constexpr int WR_ELEMS = 64, WR_GROUPS = 16;
+constexpr int WR_ELEMS = SLAB_REDUCE_ELEMS, WR_GROUPS = SLAB_REDUCE_GROUPS;
 __global__ void __launch_bounds__(WR_ELEMS * WR_GROUPS) k_wgrad_reduce(const uint32_t n_elems, const uint32_t cols, const uint32_t ldg, const uint32_t n_slabs, const float* __restrict__ slabs, half_t* __restrict__ grad, const int accumulate) {
-	__shared__ float part[WR_GROUPS][WR_ELEMS];
-	const uint32_t e = threadIdx.x & (WR_ELEMS - 1), grp = threadIdx.x / WR_ELEMS;
-	const uint32_t i = blockIdx.x * WR_ELEMS + e;
-	float p[4] = {0, 0, 0, 0};
-	if (i < n_elems) {
-		uint32_t k = grp;
-		for (; k + 3 * WR_GROUPS < n_slabs; k += 4 * WR_GROUPS) {
-#pragma unroll
-			for (int u = 0; u < 4; ++u) p[u] += slabs[(size_t)(k + u * WR_GROUPS) * n_elems + i];
-		}
-		for (; k < n_slabs; k += WR_GROUPS) p[0] += slabs[(size_t)k * n_elems + i];
-	}
-	part[grp][e] = (p[0] + p[1]) + (p[2] + p[3]);
-	__syncthreads();
-	if (grp == 0 && i < n_elems) {
-		float s = 0;
-#pragma unroll
-		for (int g = 0; g < WR_GROUPS; ++g) s += part[g][e];
-		const uint32_t row = i / cols, col = i - row * cols;
-		half_t* g = grad + (size_t)row * ldg + col;
-		if (accumulate) s += (float)*g;
-		*g = (half_t)s;
-	}
+	__shared__ float part[WR_GROUPS * WR_ELEMS];
+	mlp_reduce_block(part, blockIdx.x, threadIdx.x, n_elems, cols, ldg, n_slabs, slabs, grad, accumulate); // mlp_side_jobs.h: the grid scatter can carry this along
 }
 
 // kernel_activation_backward_output (common_device.h:748): dL/d(pre-activation output) from the forward OUTPUT values

@@ -13,6 +13,7 @@
 
 #include "json_lite.h"
 #include "tcnn_common.h"
+#include "mlp_side_jobs.h"
 
 #include <algorithm>
 #include <cctype>
@@ -247,7 +248,9 @@ public:
 	virtual uint32_t scatter_record_planes() const { return 0; } // 16-byte records per sample when scatter_records_usable()
 	// > 0: forward_planes() can write the encoded batch as level planes [padded / F][n][F] (no input gradients in that form)
 	virtual uint32_t forward_plane_features(uint32_t n) { return 0; }
-	virtual EncodingContext forward_planes(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out_planes, bool prepare_param_gradients) {
+	// prep_job (optional): a side job the forward kernel carries along -- the fragment images of the network behind the encoding
+	virtual EncodingContext forward_planes(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out_planes, bool prepare_param_gradients,
+	                                       const MlpPrepJob* prep_job = nullptr) {
 		throw std::runtime_error{"Encoding: level-plane output is not available"};
 	}
 	virtual Json hyperparams() const = 0;
@@ -430,7 +433,8 @@ public:
 		return *(m_planes_plans[n] = std::move(plan));
 	}
 
-	EncodingContext forward_planes(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out_planes, bool prepare_param_gradients) override {
+	EncodingContext forward_planes(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out_planes, bool prepare_param_gradients,
+	                               const MlpPrepJob* prep_job = nullptr) override {
 		EncodingContext ctx;
 		CHECK_THROW(forward_plane_features(n) > 0);
 		const bool want_filter = prepare_param_gradients && lds_scatter_usable();
@@ -439,7 +443,7 @@ public:
 			ctx.n = n;
 		}
 		PlanesPlan& plan = planes_plan(n);
-		grid_forward_planes(stream, m_meta, dev_meta(), plan.dev_work.as<uint32_t>(), plan.max_items, plan.blocks_per_xcd, n, x, params, out_planes, ctx.chunk_mask.as<uint64_t>());
+		grid_forward_planes(stream, m_meta, dev_meta(), plan.dev_work.as<uint32_t>(), plan.max_items, plan.blocks_per_xcd, n, x, params, out_planes, ctx.chunk_mask.as<uint64_t>(), prep_job);
 		return ctx;
 	}
 
@@ -1333,6 +1337,7 @@ public:
 		NetworkContext network_ctx; // hidden activations; empty for fused contexts
 		uint32_t x_plane_f = 0;
 		bool fused = false;         // produced by fused_encode(): backward() goes through the fused MLP kernel
+		ArenaBuf image;             // the network's fragment images, if the encoding's forward kernel built them on the way (MlpPrepJob)
 	};
 
 	// cpp_api.cu:84-95.  Without input gradients the forward pass keeps nothing but the encoded batch: backward() recomputes the
@@ -1391,6 +1396,11 @@ public:
 		}();
 		return v;
 	}
+	// TCNN_AMD_SIDE_JOBS=0: k_mlp_prep stays a launch of its own (A/B runs; read per step so that tests cover both)
+	static bool side_jobs_enabled() {
+		const char* e = getenv("TCNN_AMD_SIDE_JOBS");
+		return !(e && e[0] == '0');
+	}
 	bool fused_step_supported(uint32_t n) const { return use_fused_step() && mlp_train_fused_supported(m_network->desc(), n); }
 	// the register-resident fused kernel (k_train_regs.hip) writes dL_doutput / L as compact [n][dims] matrices (TrainContext::compact)
 	bool fused_compact_context_supported(uint32_t n) const { return use_fused_step() && mlp_train_regs_supported(m_network->desc(), n) && m_network->padded_output_width() == 16; }
@@ -1406,20 +1416,27 @@ public:
 		// ~5 us each, independent of the encoding kernels) on a side stream was measured and lost 13-15 us per step on every
 		// workload: a cross-stream event dependency costs more here than the kernels it hides (the same happened with Adam).
 		if (profile) profile->mark(stream, StepProfile::Encode, false);
-		fused_encode(stream, *ctx, n, input, params, dL_dinput != nullptr, mode != GradientMode::Ignore);
+		fused_encode(stream, *ctx, n, input, params, dL_dinput != nullptr, mode != GradientMode::Ignore, side_jobs_enabled());
 		if (profile) profile->mark(stream, StepProfile::Encode, true);
 		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, compact_context, dL_dinput, params, gradients, mode, profile);
 		return ctx;
 	}
 
 	// first half of the fused step: the encoding, as level planes where the encoding can produce them
-	void fused_encode(hipStream_t stream, Ctx& ctx, uint32_t n, MatView input, const void* params, bool prepare_input_gradients, bool prepare_param_gradients) {
+	void fused_encode(hipStream_t stream, Ctx& ctx, uint32_t n, MatView input, const void* params, bool prepare_input_gradients, bool prepare_param_gradients, bool prep_image = false) {
 		const _Float16* p = (const _Float16*)params;
 		const uint32_t n_net = (uint32_t)m_network->n_params();
 		ctx.network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
 		// grids hand the encoded batch over as level planes (XCD-aware forward kernel, scatter filter produced on the way)
 		ctx.x_plane_f = prepare_input_gradients ? 0 : m_encoding->forward_plane_features(n);
-		if (ctx.x_plane_f) ctx.encoding_ctx = m_encoding->forward_planes(stream, n, input, p + n_net, ctx.network_input.data(), prepare_param_gradients);
+		if (ctx.x_plane_f && prep_image) { // the forward kernel also builds the network's fragment images (k_mlp_prep as a side job)
+			ctx.image = ArenaBuf{stream, mlp_image_bytes(m_network->desc())};
+			MlpPrepJob job;
+			job.desc = m_network->desc();
+			job.params = params;
+			job.image = ctx.image.data();
+			ctx.encoding_ctx = m_encoding->forward_planes(stream, n, input, p + n_net, ctx.network_input.data(), prepare_param_gradients, &job);
+		} else if (ctx.x_plane_f) ctx.encoding_ctx = m_encoding->forward_planes(stream, n, input, p + n_net, ctx.network_input.data(), prepare_param_gradients);
 		else ctx.encoding_ctx = m_encoding->forward(stream, n, input, p + n_net, ctx.network_input.data(), prepare_input_gradients, prepare_param_gradients);
 		ctx.fused = true;
 	}
@@ -1441,7 +1458,9 @@ public:
 		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, records ? (size_t)n * m_encoding->scatter_record_planes() * 16 : (size_t)n * m_encoding->padded_output_width() * 2};
 		ctx.encoding_ctx.dy_records = records;
 
-		ArenaBuf image = m_network->prepare(stream, params, true);
+		ArenaBuf prepared;
+		if (!ctx.image) prepared = m_network->prepare(stream, params, true);
+		const ArenaBuf& image = ctx.image ? ctx.image : prepared;
 		const MlpDesc& d = m_network->desc();
 		ArenaBuf slabs;
 		uint32_t n_slabs = 0;
@@ -1454,6 +1473,9 @@ public:
 		mlp_train_fused(stream, d, image.data(), n, ctx.network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L, compact_context,
 		                dL_dnetwork_input.data(), plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u, slabs.as<float>(), n_net);
 		if (profile) profile->mark(stream, StepProfile::MlpKernel, true);
+		// (Carrying the slab reduction on the grid scatter's launch the way k_mlp_prep rides on the forward kernel was built and
+		// measured: its workgroups each take a whole CU's LDS slot for a few microseconds, in front of the task list they delay the
+		// long coarse-level tasks, behind it they wait for a slot -- the scatter grew by 5.4 / 6.5 us for the 4.4 us launch saved.)
 		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
 		if (need_dx) {
 			if (profile) profile->mark(stream, StepProfile::EncodingBackward, false);

@@ -87,8 +87,10 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_
 bool grid_planes_supported(const GridMeta& meta, uint32_t n);
 uint32_t grid_planes_spt(const GridMeta& meta);        // samples per thread of the kernel shape used for this grid
 void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd);
+// prep_job (optional, mlp_side_jobs.h; passed to the kernel by value): the kernel also builds the MLP's fragment images
+struct MlpPrepJob;
 void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
-                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits);
+                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits, const MlpPrepJob* prep_job = nullptr);
 // reference-shaped gradient scatter with global float atomics (fp32 grids, F == 1, tables too large for the LDS scheme).
 // grad: T[n_params] accumulated in place (caller zeroes it).  For F == 1 && !fp32 the caller passes an fp32 scratch as `grad`.
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32_grad, uint32_t n, MatView x, const void* dL_dy, bool dy_fp32, uint32_t dy_stride, void* grad);
