@@ -179,6 +179,11 @@ uint32_t tcnn_trainer_optimizer_step_count(tcnn_trainer_t t);     /* optimizer->
  * steps profiled since the last call, and their number. */
 int  tcnn_trainer_profile_next_step(tcnn_trainer_t t);
 int  tcnn_trainer_profile_collect(tcnn_trainer_t t, tcnn_stream_t stream, float* ms_per_piece /* [4] */, uint32_t* n_steps);
+/* Introspection (no counterpart in the reference): how many parameters of the last training_step() had their optimizer update
+ * applied by the gradient kernels themselves (k_grid_scatter's flush) instead of by the optimizer kernel; 0 when the step ran
+ * the optimizer the usual way (the default; TCNN_AMD_ADAM_IN_FLUSH=1 asks for the fused form, which needs plain Adam, GradientMode
+ * Overwrite, run_optimizer=true and a grid whose scatter runs in record form). */
+size_t tcnn_trainer_params_updated_in_flush(tcnn_trainer_t t);
 
 #ifdef __cplusplus
 }

@@ -459,6 +459,39 @@ def test_torch_module_pads_batch(tcnn, oracle):
     assert torch.isfinite(m.params.grad).all()
 
 
+def test_torch_module_working_copy_follows_the_master(tcnn, oracle):
+    """The half copy of the fp32 master parameters is kept between calls and rebuilt whenever the master changes: in-place
+    updates (an optimizer step), `load_state_dict`, and a replaced `.data`.  Gradients still arrive at the fp32 master."""
+    import torch
+
+    m = tcnn.NetworkWithInputEncoding(2, 3, CONFIG_C3B["encoding"], CONFIG_C3B["network"])
+    x = torch.rand(512, 2, device="cuda")
+
+    def fresh():
+        return tcnn.modules._Evaluate.apply(x, m.params.detach().half(), m.native_tcnn_module, m.loss_scale)[:, :3]
+
+    with torch.no_grad():
+        y0 = m(x)
+        copy0 = m._working_copy
+        assert torch.equal(m(x), y0) and m._working_copy is copy0  # reused
+    opt = torch.optim.SGD(m.parameters(), lr=1.0)
+    m(x).float().square().sum().backward()
+    assert m.params.grad.dtype == torch.float32 and m.params.grad.abs().sum() > 0
+    opt.step()
+    with torch.no_grad():
+        y1 = m(x)
+        assert m._working_copy is not copy0 and torch.equal(y1, fresh()) and not torch.equal(y1, y0)
+        state = {k: v.clone() for k, v in m.state_dict().items()}
+        state["params"].mul_(0.5)
+        m.load_state_dict(state)
+        assert torch.equal(m(x), fresh())
+        m.params.data = m.params.data * 2.0
+        assert torch.equal(m(x), fresh())
+    # two graphs alive at once, built from the same kept copy
+    a, b = m(x), m(x)
+    (a.float().sum() + 2 * b.float().sum()).backward()
+
+
 def test_gradient_accumulate_mode(tcnn, oracle):
     """GradientMode::Accumulate: a second backward adds to the existing gradient buffer (fully_fused_mlp.cu:769, grid.h:857)."""
     n = 1024
@@ -507,6 +540,43 @@ def test_training_step_variants_agree_bitwise(tcnn, oracle, cfg, n_in, monkeypat
     assert np.array_equal(g[n_net:], base_g[n_net:])
     a, b = _f32(g[:n_net]), _f32(base_g[:n_net])
     assert float(np.linalg.norm(a - b)) <= 2e-3 * float(np.linalg.norm(b))
+
+
+CONFIG_3D_F2 = dict(CONFIG_C3B, encoding={"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 18, "base_resolution": 8, "per_level_scale": 2.0})
+
+
+@pytest.mark.parametrize("cfg,n_in,n", [(CONFIG_C3B, 2, 4096), (CONFIG_C3A, 2, 16384), (CONFIG_3D_F2, 3, 8192)])
+def test_adam_in_the_scatter_flush_is_bit_identical(tcnn, oracle, cfg, n_in, n, monkeypatch):
+    """adam.h:48-119 applied by k_grid_scatter to the chunk a workgroup owns as it flushes it (AdamInFlush) vs one k_adam after the
+    gradient kernels (the default; TCNN_AMD_ADAM_IN_FLUSH=1 selects the fused form): the same function on the same gradients -- weights (fp32 master and half), both
+    moments and the per-parameter step counts must agree bit for bit over several steps, including parameters whose gradient
+    is zero in some steps (their step count stays behind, adam.h:76-79), and across the scatter plan's re-cut after step 2."""
+    import msgpack
+
+    batches = [oracle.synthetic_batch(n, n_in, 3, seed=20 + i) for i in range(5)]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(n_in, 3, cfg, seed=1337)
+        for x, t in batches:
+            ctx = tr.training_step(_t(x), _t(t))
+        state = msgpack.unpackb(tr.serialize(True), raw=False)
+        for k in env:
+            monkeypatch.delenv(k)
+        if not env or cfg is not CONFIG_C3B:  # C3B's small tables end up shared between workgroups once the plan is tuned: nothing to fuse then
+            assert (tr.params_updated_in_flush() > 0) == bool(env), "which kernel applied the update is not what this run asked for"
+        return _bits(tr.params()), tr.params_full_precision().cpu().numpy().view(np.uint32), state["optimizer"], _bits(tr.param_gradients())
+
+    half_a, fp_a, opt_a, g_a = run({"TCNN_AMD_ADAM_IN_FLUSH": "1"})
+    half_b, fp_b, opt_b, g_b = run({})
+    assert np.array_equal(g_a, g_b)
+    assert np.array_equal(fp_a, fp_b) and np.array_equal(half_a, half_b)
+    assert opt_a["current_step"] == opt_b["current_step"] == len(batches)
+    for key in ("first_moments_binary", "second_moments_binary", "param_steps_binary"):
+        assert opt_a[key] == opt_b[key], key
+    steps = np.frombuffer(opt_a["param_steps_binary"], dtype=np.uint32)
+    assert steps.max() == len(batches) and steps.min() < len(batches)  # some parameters missed updates: the skip is exercised
 
 
 def test_wide_inference_forms_agree(tcnn, oracle, monkeypatch):

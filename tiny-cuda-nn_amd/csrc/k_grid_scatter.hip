@@ -24,6 +24,7 @@
 //     their exact partial sums are merged with 64-bit integer atomics in a small scratch table and rounded by
 //     k_grid_scatter_finalize.
 #include "grid_fixed.h"
+#include "adam_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -54,12 +55,18 @@ constexpr uint32_t SCATTER_MAX_CHUNKS = GRID_FILTER_MAX_CHUNKS; // bit planes pe
 
 // REC: dL_dy holds 16-byte records {D coordinates, gradient halves} written by the fused MLP kernel
 // (mlp_device.h store_dx_record; float4 [level][n], or [level / 2][n] where two levels fit one record): one gather per hit instead of two -- gathers cost ~2 clk per lane per CU whatever their width.
-template <int D, int F, bool REC>
+//
+// ADAM: a sole owner also applies the optimizer's update to its chunk as it flushes (AdamInFlush, tcnn_common.h): the gradient is
+// final there, so adam.h:48-119 runs on it at once -- same function, same inputs, same bits as k_adam run afterwards.  What this
+// buys is one launch and the 2 B/param re-read of the gradient, not the overlap one might hope for; measured on C3a (DESIGN.md
+// "Adam in the scatter"): a CU streams a chunk's 590 KB of optimizer state in 18 us whatever the other CUs do -- ~32 GB/s, its
+// share of the HBM -- which is what the same bytes cost in k_adam, and while it does that its accumulators sit idle.
+template <int D, int F, bool REC, bool ADAM>
 __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	const GridMeta* __restrict__ meta, const GridScatterTask* __restrict__ tasks, const uint32_t n, const MatView x,
 	const half_t* __restrict__ dL_dy, const uint32_t dy_stride_sample, const uint32_t dy_stride_level, half_t* __restrict__ grad,
 	const unsigned long long* __restrict__ chunk_bits, unsigned long long* __restrict__ scratch, const int accumulate_mode,
-	unsigned long long* __restrict__ dbg_times
+	unsigned long long* __restrict__ dbg_times, const AdamInFlush adam
 ) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	long long* acc = (long long*)smem; // [n_entries][F]
@@ -370,6 +377,80 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 			const long long v = acc[i];
 			if (v != 0) atomicAdd(sc + i, (unsigned long long)v);
 		}
+	} else if (ADAM && adam.w_fp) {
+		// sole owner, optimizer step included (the host checked that the chunk is a whole number of aligned quads of parameters)
+		typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+		const size_t p0 = ((size_t)lv.offset + task.entry_begin) * F;
+		float* __restrict__ wf_p = adam.w_fp + p0;
+		float* __restrict__ m1_p = adam.m1 + p0;
+		float* __restrict__ m2_p = adam.m2 + p0;
+		uint32_t* __restrict__ st_p = adam.steps + p0;
+		half_t* __restrict__ wh_p = (half_t*)adam.w_half + p0;
+		// Parameters that missed an update carry their own step count and look their debiasing factor up (adam_device.h): one
+		// gather per parameter, and gathers are what a CU has least of (~1.7 clocks per lane).  The most recent steps of the table
+		// -- all that parameters touched in the last few thousand steps ask for -- are kept in LDS, in the space of the compaction
+		// queues, which are dead by now.
+		constexpr uint32_t WINDOW = SCATTER_WAVES * SCATTER_QUEUE_IDS;
+		float* window = (float*)(smem + SCATTER_ACC_BYTES);
+		const uint32_t common = adam.args.common_step;
+		const uint32_t window_base = common + 1 > WINDOW ? common + 1 - WINDOW : 0; // window[i] = table[window_base + i], up to table[common]
+		for (uint32_t i = tid; i < WINDOW; i += SCATTER_THREADS) if (window_base + i <= common) window[i] = adam.debias_table[window_base + i];
+		__syncthreads();
+		const float debias = window[common - window_base];
+		const auto debias_of = [&](const uint32_t t) { return t >= window_base ? window[t - window_base] : adam.debias_table[t]; };
+		constexpr int Q = 4; // quads per thread in flight
+		const uint32_t n_quads = n_vals / 4;
+		for (uint32_t q0 = tid; q0 < n_quads; q0 += Q * SCATTER_THREADS) {
+			h4 gq[Q], old[Q];
+			bool live[Q], has_old[Q];
+			float4 wf[Q], a1[Q], a2[Q];
+			uint4 st[Q];
+#pragma unroll
+			for (int k = 0; k < Q; ++k) {
+				const uint32_t q = q0 + k * SCATTER_THREADS;
+				live[k] = q < n_quads;
+				has_old[k] = false;
+				if (live[k]) {
+					gq[k] = h4{fixed_to_half_fast(acc[4 * q]), fixed_to_half_fast(acc[4 * q + 1]), fixed_to_half_fast(acc[4 * q + 2]), fixed_to_half_fast(acc[4 * q + 3])};
+					*(h4*)(g + 4 * (size_t)q) = gq[k];
+					const bool z0 = gq[k][0] == (half_t)0.0f, z1 = gq[k][1] == (half_t)0.0f, z2 = gq[k][2] == (half_t)0.0f, z3 = gq[k][3] == (half_t)0.0f;
+					live[k] = !(z0 && z1 && z2 && z3); // adam.h:76-79: a grid parameter with a zero gradient is left alone -- nothing else of it is read
+					has_old[k] = live[k] && (z0 || z1 || z2 || z3);
+				}
+				if (live[k]) {
+					wf[k] = *(const float4*)(wf_p + 4 * (size_t)q);
+					a1[k] = *(const float4*)(m1_p + 4 * (size_t)q);
+					a2[k] = *(const float4*)(m2_p + 4 * (size_t)q);
+					st[k] = *(const uint4*)(st_p + 4 * (size_t)q);
+					if (has_old[k]) old[k] = *(const h4*)(wh_p + 4 * (size_t)q);
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < Q; ++k) {
+				if (!live[k]) continue;
+				const size_t i4 = 4 * (size_t)(q0 + k * SCATTER_THREADS);
+				half_t wh[4];
+				bool up[4];
+				adam_one(adam.args, debias_of, debias, false, gq[k][0], wf[k].x, wh[0], a1[k].x, a2[k].x, st[k].x, up[0]);
+				adam_one(adam.args, debias_of, debias, false, gq[k][1], wf[k].y, wh[1], a1[k].y, a2[k].y, st[k].y, up[1]);
+				adam_one(adam.args, debias_of, debias, false, gq[k][2], wf[k].z, wh[2], a1[k].z, a2[k].z, st[k].z, up[2]);
+				adam_one(adam.args, debias_of, debias, false, gq[k][3], wf[k].w, wh[3], a1[k].w, a2[k].w, st[k].w, up[3]);
+				*(float4*)(wf_p + i4) = wf[k];
+				*(float4*)(m1_p + i4) = a1[k];
+				*(float4*)(m2_p + i4) = a2[k];
+				*(uint4*)(st_p + i4) = st[k];
+				// parameters that were not updated keep their half value, whatever it is: quads with a zero gradient somewhere
+				// brought their old halves along, so that the quad is stored whole
+				if (up[0] && up[1] && up[2] && up[3]) {
+					*(h4*)(wh_p + i4) = h4{wh[0], wh[1], wh[2], wh[3]};
+				} else if (has_old[k]) {
+					*(h4*)(wh_p + i4) = h4{up[0] ? wh[0] : old[k][0], up[1] ? wh[1] : old[k][1], up[2] ? wh[2] : old[k][2], up[3] ? wh[3] : old[k][3]};
+				} else { // a non-zero half gradient that became zero when the loss scale was divided out
+#pragma unroll
+					for (int e = 0; e < 4; ++e) if (up[e]) wh_p[i4 + e] = wh[e];
+				}
+			}
+		}
 	} else {
 		// sole owner: round once and store (two values per 4-byte store; n_vals is even because F >= 2)
 		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -422,12 +503,16 @@ __global__ void __launch_bounds__(256) k_grid_mask_to_bits(const GridMeta* __res
 // timestamps (slots 0..3: start / after zeroing / after accumulation / end, 100 MHz clock) -- input of the plan tuner
 thread_local unsigned long long* g_task_times = nullptr;
 
-template <int D, int F, bool REC = false>
+template <int D, int F, bool REC = false, bool ADAM = false>
 void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x, const void* dy, uint32_t dss, uint32_t dsl,
-                    void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate) {
+                    void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate, const AdamInFlush* adam = nullptr) {
+	if constexpr (REC && !ADAM) {
+		if (adam) return launch_scatter<D, F, REC, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate, adam);
+	}
+	CHECK_THROW(ADAM || !adam);
 	static bool configured = false;
 	if (!configured) { // more than 64 KiB of dynamic LDS has to be opted into once per kernel
-		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_grid_scatter<D, F, REC>, hipFuncAttributeMaxDynamicSharedMemorySize, SCATTER_LDS_BYTES));
+		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_grid_scatter<D, F, REC, ADAM>, hipFuncAttributeMaxDynamicSharedMemorySize, SCATTER_LDS_BYTES));
 		configured = true;
 	}
 	// development aid: TCNN_AMD_SCATTER_TIMING=1 prints per-task phase times (100 MHz constant clock) for the 3rd launch
@@ -435,8 +520,8 @@ void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* ta
 	static int timing_left = 3;
 	unsigned long long* dbg = nullptr;
 	if (timing && timing_left > 0 && !g_task_times) HIP_CHECK_THROW(hipMalloc(&dbg, (size_t)n_tasks * 8 * 8));
-	hipLaunchKernelGGL((k_grid_scatter<D, F, REC>), dim3(n_tasks), dim3(SCATTER_THREADS), SCATTER_LDS_BYTES, s, dm, tasks, n, x, (const half_t*)dy, dss, dsl, (half_t*)grad, chunk_bits,
-	                   scratch, accumulate ? 1 : 0, g_task_times ? g_task_times : dbg);
+	hipLaunchKernelGGL((k_grid_scatter<D, F, REC, ADAM>), dim3(n_tasks), dim3(SCATTER_THREADS), SCATTER_LDS_BYTES, s, dm, tasks, n, x, (const half_t*)dy, dss, dsl, (half_t*)grad, chunk_bits,
+	                   scratch, accumulate ? 1 : 0, g_task_times ? g_task_times : dbg, adam ? *adam : AdamInFlush{});
 	HIP_CHECK_THROW(hipGetLastError());
 	if (dbg) {
 		std::vector<unsigned long long> h((size_t)n_tasks * 8);
@@ -459,16 +544,18 @@ void launch_scatter(hipStream_t s, const GridMeta* dm, const GridScatterTask* ta
 
 template <int D>
 void dispatch_scatter(hipStream_t s, uint32_t F, const GridMeta* dm, const GridScatterTask* tasks, uint32_t n_tasks, uint32_t n, MatView x,
-                      const void* dy, uint32_t dss, uint32_t dsl, void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate, bool records) {
+                      const void* dy, uint32_t dss, uint32_t dsl, void* grad, const unsigned long long* chunk_bits, unsigned long long* scratch, bool accumulate, bool records,
+                      const AdamInFlush* adam) {
 	if (records) {
 		if constexpr (D == 2) {
-			if (F == 2) return launch_scatter<D, 2, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
-			if (F == 4) return launch_scatter<D, 4, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
+			if (F == 2) return launch_scatter<D, 2, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate, adam);
+			if (F == 4) return launch_scatter<D, 4, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate, adam);
 		} else if constexpr (D == 3) {
-			if (F == 2) return launch_scatter<D, 2, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
+			if (F == 2) return launch_scatter<D, 2, true>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate, adam);
 		}
 		throw std::runtime_error{"grid_backward_lds: scatter records need 4 D + 2 F <= 16"};
 	}
+	CHECK_THROW(!adam); // only the record forms carry the optimizer step (grid_scatter_adam_ranges)
 	switch (F) {
 		case 2: return launch_scatter<D, 2>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
 		case 4: return launch_scatter<D, 4>(s, dm, tasks, n_tasks, n, x, dy, dss, dsl, grad, chunk_bits, scratch, accumulate);
@@ -692,10 +779,31 @@ std::vector<float> grid_scatter_level_costs(const GridMeta& meta, const std::vec
 	return level_us;
 }
 
+// The parameter ranges (relative to the encoding's first parameter) whose optimizer step a launch with an AdamInFlush performs:
+// the chunks with a single owner.  Empty when this plan cannot carry the step (a chunk that is not a whole number of aligned quads).
+ParamRanges grid_scatter_adam_ranges(const GridMeta& meta, const std::vector<GridScatterTask>& tasks, bool dy_records) {
+	ParamRanges r;
+	if (!dy_records) return r;
+	const size_t F = meta.n_features_per_level;
+	for (const GridScatterTask& t : tasks) {
+		if (t.n_entries == 0 || t.flush_atomic) continue;
+		const size_t begin = ((size_t)meta.levels[t.level].offset + t.entry_begin) * F, end = begin + (size_t)t.n_entries * F;
+		if (begin % 4 || end % 4) return ParamRanges{};
+		r.emplace_back(begin, end);
+	}
+	std::sort(r.begin(), r.end());
+	ParamRanges merged;
+	for (const auto& x : r) {
+		if (!merged.empty() && merged.back().second == x.first) merged.back().second = x.second;
+		else merged.push_back(x);
+	}
+	return merged;
+}
+
 void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
                        const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records,
-                       uint64_t* task_times) {
+                       uint64_t* task_times, const AdamInFlush* adam) {
 	if (n_tasks == 0) return;
 	const unsigned long long* bits = (const unsigned long long*)chunk_bits;
 	unsigned long long* sc = (unsigned long long*)scratch;
@@ -705,9 +813,9 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
 		~TimesGuard() { g_task_times = nullptr; }
 	} guard{task_times};
 	switch (meta.n_pos_dims) {
-		case 2: dispatch_scatter<2>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
-		case 3: dispatch_scatter<3>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
-		case 4: dispatch_scatter<4>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records); break;
+		case 2: dispatch_scatter<2>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records, adam); break;
+		case 3: dispatch_scatter<3>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records, adam); break;
+		case 4: dispatch_scatter<4>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records, adam); break;
 		default: throw std::runtime_error{"GridEncoding: number of input dims must be 2 or 3."};
 	}
 	if (n_ranges > 0) {

@@ -10,6 +10,7 @@
 //   random.h:40-55               generate_random_kernel               -> k_random_uniform
 //   common_device.h:990-1014     trim_and_cast / cast / cast_from     -> k_trim_and_cast / k_cast_*
 #include "tcnn_common.h"
+#include "adam_device.h"
 
 #include <hip/hip_fp16.h>
 
@@ -256,14 +257,6 @@ __global__ void __launch_bounds__(256) k_reduce_stage2(const uint32_t n_partials
 }
 
 // ---- Adam, adam.h:48-119.  4 parameters per thread, 16-byte accesses; 36 B/param of HBM traffic is the floor.
-struct AdamArgs {
-	float relative_weight_decay, absolute_weight_decay, weight_clipping_magnitude, loss_scale, learning_rate, non_matrix_learning_rate_factor;
-	float beta1, beta2, epsilon, lower_lr_bound, upper_lr_bound, l2_reg;
-	uint32_t optimize_matrix_params, optimize_non_matrix_params;
-	float inv_loss_scale;
-	uint32_t inv_loss_scale_exact;
-	uint32_t common_step; // the optimizer's own step count: the per-parameter count of every parameter that was updated in every step
-};
 
 // debiasing factor of adam.h:97-98
 __device__ inline float adam_debias(const float beta1, const float beta2, uint32_t step) { return sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step)); }
@@ -274,37 +267,6 @@ __device__ inline float adam_debias(const float beta1, const float beta2, uint32
 __global__ void __launch_bounds__(256) k_adam_debias_table(const float beta1, const float beta2, const uint32_t from, const uint32_t to, float* __restrict__ table) {
 	const uint32_t t = from + blockIdx.x * blockDim.x + threadIdx.x;
 	if (t < to) table[t] = adam_debias(beta1, beta2, t);
-}
-
-// One parameter, branch-free (selects instead of early returns, so that a wave whose lanes disagree about "skipped" does not
-// execute the body twice).  common_debias = debias_table[common_step]; parameters with their own step count look theirs up.
-// `updated` reports whether adam.h:76-84 lets this parameter through.
-__device__ inline void adam_one(const AdamArgs& a, const float* __restrict__ debias_table, const float common_debias, const bool is_matrix, const half_t g_h, float& w_fp, half_t& w_h,
-                                float& m1, float& m2, uint32_t& step, bool& updated) {
-	// loss_scale is a power of two in practice (128): the reciprocal multiply is then exact, i.e. identical to the division
-	float gradient = a.inv_loss_scale_exact ? (float)g_h * a.inv_loss_scale : (float)g_h / a.loss_scale;
-	updated = is_matrix ? a.optimize_matrix_params != 0 : (a.optimize_non_matrix_params != 0 && gradient != 0);
-	const float weight_fp = w_fp;
-	if (is_matrix) gradient += a.l2_reg * weight_fp;
-	const float gradient_sq = gradient * gradient;
-	const float first_moment = a.beta1 * m1 + (1 - a.beta1) * gradient;
-	const float second_moment = a.beta2 * m2 + (1 - a.beta2) * gradient_sq;
-	float learning_rate = a.learning_rate;
-	if (!is_matrix) learning_rate *= a.non_matrix_learning_rate_factor;
-	const uint32_t current_step = step + 1;
-	float debias = common_debias;
-	if (updated && current_step != a.common_step) debias = debias_table[min(current_step, a.common_step)]; // a parameter never has more steps than the optimizer
-	learning_rate *= debias;
-	const float effective_learning_rate = fminf(fmaxf(learning_rate / (sqrtf(second_moment) + a.epsilon), a.lower_lr_bound), a.upper_lr_bound);
-	// weight_decay(rel * lr, abs * lr, w), common_device.h:870-873
-	const float decayed_weight = (1 - a.relative_weight_decay * learning_rate) * weight_fp - copysignf(a.absolute_weight_decay * learning_rate, weight_fp);
-	float new_weight = decayed_weight - effective_learning_rate * first_moment;
-	if (a.weight_clipping_magnitude != 0.0f) new_weight = fminf(fmaxf(new_weight, -a.weight_clipping_magnitude), a.weight_clipping_magnitude);
-	w_fp = updated ? new_weight : weight_fp;
-	w_h = (half_t)new_weight; // stored only if updated
-	m1 = updated ? first_moment : m1;
-	m2 = updated ? second_moment : m2;
-	step = updated ? current_step : step;
 }
 
 constexpr int ADAM_Q = 1; // quads (of 4 parameters) per thread, one block-width apart (measured: 1 -> 82 us, 2 -> 84 us, 4 -> 91 us on C3a; occupancy wins)
@@ -318,6 +280,7 @@ __global__ void __launch_bounds__(256) k_adam(
 ) {
 	const size_t base = (size_t)blockIdx.x * (256 * 4 * ADAM_Q) + threadIdx.x * 4;
 	const float debias = debias_table[a.common_step];
+	const auto from_table = [&](const uint32_t t) { return debias_table[t]; };
 	// phase 1: the gradients of all quads (8 B each).  Grid (non-matrix) quads whose 4 gradients are all zero are skipped
 	// without touching the other 32 B/param (adam.h:76-79 returns before reading anything else).
 	h4 gv[ADAM_Q];
@@ -354,10 +317,10 @@ __global__ void __launch_bounds__(256) k_adam(
 			half_t wh[4];
 			bool up[4];
 			const bool quad_matrix = i4 < n_matrix;
-			adam_one(a, debias_table, debias,QUAD_UNIFORM ? quad_matrix : i4 + 0 < n_matrix, gv[q][0], wf[q].x, wh[0], a1[q].x, a2[q].x, st[q].x, up[0]);
-			adam_one(a, debias_table, debias,QUAD_UNIFORM ? quad_matrix : i4 + 1 < n_matrix, gv[q][1], wf[q].y, wh[1], a1[q].y, a2[q].y, st[q].y, up[1]);
-			adam_one(a, debias_table, debias,QUAD_UNIFORM ? quad_matrix : i4 + 2 < n_matrix, gv[q][2], wf[q].z, wh[2], a1[q].z, a2[q].z, st[q].z, up[2]);
-			adam_one(a, debias_table, debias,QUAD_UNIFORM ? quad_matrix : i4 + 3 < n_matrix, gv[q][3], wf[q].w, wh[3], a1[q].w, a2[q].w, st[q].w, up[3]);
+			adam_one(a, from_table, debias, QUAD_UNIFORM ? quad_matrix : i4 + 0 < n_matrix, gv[q][0], wf[q].x, wh[0], a1[q].x, a2[q].x, st[q].x, up[0]);
+			adam_one(a, from_table, debias, QUAD_UNIFORM ? quad_matrix : i4 + 1 < n_matrix, gv[q][1], wf[q].y, wh[1], a1[q].y, a2[q].y, st[q].y, up[1]);
+			adam_one(a, from_table, debias, QUAD_UNIFORM ? quad_matrix : i4 + 2 < n_matrix, gv[q][2], wf[q].z, wh[2], a1[q].z, a2[q].z, st[q].z, up[2]);
+			adam_one(a, from_table, debias, QUAD_UNIFORM ? quad_matrix : i4 + 3 < n_matrix, gv[q][3], wf[q].w, wh[3], a1[q].w, a2[q].w, st[q].w, up[3]);
 			*(float4*)(w_fp + i4) = wf[q];
 			*(float4*)(m1 + i4) = a1[q];
 			*(float4*)(m2 + i4) = a2[q];
@@ -372,7 +335,7 @@ __global__ void __launch_bounds__(256) k_adam(
 			for (size_t i = i4; i < n; ++i) {
 				bool up;
 				half_t wh;
-				adam_one(a, debias_table, debias,i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
+				adam_one(a, from_table, debias, i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
 				if (up) w[i] = wh;
 			}
 		}
@@ -389,9 +352,10 @@ __global__ void __launch_bounds__(256) k_adam_scalar(
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const float debias = debias_table[a.common_step];
+	const auto from_table = [&](const uint32_t t) { return debias_table[t]; };
 	bool up;
 	half_t wh;
-	adam_one(a, debias_table, debias, i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
+	adam_one(a, from_table, debias,  i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
 	if (up) w[i] = wh;
 }
 
@@ -529,9 +493,7 @@ void reduce_sum(hipStream_t stream, size_t n, const float* values, float* partia
 	hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(256), 0, stream, blocks, partials, result_dev);
 }
 
-void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
-               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps, const float* debias_table) {
-	if (n == 0) return;
+AdamArgs make_adam_args(const AdamHyper& h, float loss_scale, uint32_t current_step) {
 	AdamArgs a;
 	a.relative_weight_decay = h.relative_decay;
 	a.absolute_weight_decay = h.absolute_decay;
@@ -555,6 +517,13 @@ void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix
 	int exponent = 0;
 	a.inv_loss_scale_exact = (std::frexp(loss_scale, &exponent) == 0.5f && loss_scale >= 1.0f / 65536 && loss_scale <= 65536.0f) ? 1 : 0;
 	a.inv_loss_scale = 1.0f / loss_scale;
+	return a;
+}
+
+void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
+               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps, const float* debias_table) {
+	if (n == 0) return;
+	const AdamArgs a = make_adam_args(h, loss_scale, current_step);
 	// the quad kernel reads float4 / uint4 / half4: every base pointer must allow that
 	const auto aligned = [](const void* p, size_t bytes) { return ((uintptr_t)p & (bytes - 1)) == 0; };
 	if (!(aligned(w_fp, 16) && aligned(m1, 16) && aligned(m2, 16) && aligned(steps, 16) && aligned(w_half, 8) && aligned(g_half, 8))) {

@@ -208,6 +208,11 @@ struct EncodingContext {
 	ArenaBuf chunk_mask;  // grid only: uint64 [L][32][n/64] bit planes, which samples touch which scatter chunk (filter for the LDS scatter)
 	uint32_t n = 0;
 	mutable bool dy_records = false; // the level planes handed to backward() hold 16-byte scatter records {coordinates, gradients} (mlp_train_fused); set by the caller of backward()
+	// Set by the caller of backward() for a step whose optimizer update may ride on the gradient kernel (AdamInFlush, arrays
+	// indexed from this encoding's first parameter).  An encoding that takes the offer reports in adam_done which of its
+	// parameters it has updated; whatever is not listed there is still the optimizer's to do.
+	mutable const AdamInFlush* adam = nullptr;
+	mutable ParamRanges adam_done;
 	std::vector<EncodingContext> nested; // Composite: one context per nested encoding
 };
 
@@ -473,9 +478,15 @@ public:
 					times.memset(0);
 				}
 				const uint32_t dy_stride_sample = dy_planes ? F : padded_output_width(), dy_stride_level = dy_planes ? n * F : F;
+				const AdamInFlush* adam = nullptr;
+				ctx.adam_done.clear();
+				if (ctx.adam && mode == GradientMode::Overwrite) {
+					if (dy_planes && ctx.dy_records) ctx.adam_done = plan.adam_ranges;
+					if (!ctx.adam_done.empty()) adam = ctx.adam;
+				}
 				grid_backward_lds(stream, m_meta, dev_meta(), plan.dev_tasks.as<GridScatterTask>(), plan.n_tasks, plan.dev_ranges.as<GridScatterRange>(), plan.n_ranges,
 				                  plan.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, mask,
-				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, tune ? times.as<uint64_t>() : nullptr);
+				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, tune ? times.as<uint64_t>() : nullptr, adam);
 				if (m_any_binned) { // levels cut into more than 64 chunks (k_grid_bin.hip)
 					CHECK_THROW(!(dy_planes && ctx.dy_records));
 					ArenaBuf workspace{stream, grid_bin_workspace_bytes(m_meta, n)};
@@ -561,6 +572,7 @@ public:
 		uint32_t n_tasks = 0, n_ranges = 0;
 		uint32_t launches = 0;
 		bool tuned = false;
+		ParamRanges adam_ranges; // what a launch of this plan in record form updates itself when it is handed an AdamInFlush
 	};
 	// TCNN_AMD_SCATTER_TUNE=0 keeps the untuned task list (A/B runs)
 	static bool scatter_tuning_enabled() { // read per call so that tests can cover both forms in one process
@@ -574,6 +586,7 @@ public:
 		grid_scatter_plan(m_meta, n, plan.host_tasks, ranges, scratch_elems, measured_level_us);
 		plan.n_tasks = (uint32_t)plan.host_tasks.size();
 		plan.n_ranges = (uint32_t)ranges.size();
+		plan.adam_ranges = grid_scatter_adam_ranges(m_meta, plan.host_tasks, true);
 		plan.dev_tasks.resize(plan.host_tasks.size() * sizeof(GridScatterTask));
 		if (!plan.host_tasks.empty()) HIP_CHECK_THROW(hipMemcpy(plan.dev_tasks.data(), plan.host_tasks.data(), plan.host_tasks.size() * sizeof(GridScatterTask), hipMemcpyHostToDevice));
 		plan.dev_ranges.resize(ranges.size() * sizeof(GridScatterRange));
@@ -1409,7 +1422,7 @@ public:
 	// forward() -> loss_evaluate() -> backward(), activations never leave the CU.  out / dL_dout / L: [n][padded_out].
 	std::unique_ptr<ModelContext> fused_step(hipStream_t stream, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
 	                                         LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, MatViewMut* dL_dinput, const void* params,
-	                                         void* gradients, GradientMode mode, StepProfile* profile = nullptr) {
+	                                         void* gradients, GradientMode mode, StepProfile* profile = nullptr, const AdamInFlush* adam = nullptr, ParamRanges* adam_done = nullptr) {
 		check_batch(n);
 		auto ctx = std::make_unique<Ctx>();
 		// Everything in order on the caller's stream.  Running the two small kernels around the MLP kernel (k_mlp_prep, k_wgrad_reduce,
@@ -1418,7 +1431,8 @@ public:
 		if (profile) profile->mark(stream, StepProfile::Encode, false);
 		fused_encode(stream, *ctx, n, input, params, dL_dinput != nullptr, mode != GradientMode::Ignore, side_jobs_enabled());
 		if (profile) profile->mark(stream, StepProfile::Encode, true);
-		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, compact_context, dL_dinput, params, gradients, mode, profile);
+		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, compact_context, dL_dinput, params, gradients, mode, profile,
+		                      adam, adam_done);
 		return ctx;
 	}
 
@@ -1445,7 +1459,7 @@ public:
 	// the slab reduction and the encoding's backward pass.  target == nullptr requires external_dL_dy.
 	void fused_mlp_and_scatter(hipStream_t stream, const Ctx& ctx, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
 	                           LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, MatViewMut* dL_dinput, const void* params, void* gradients,
-	                           GradientMode mode, StepProfile* profile = nullptr) {
+	                           GradientMode mode, StepProfile* profile = nullptr, const AdamInFlush* adam = nullptr, ParamRanges* adam_done = nullptr) {
 		const _Float16* p = (const _Float16*)params;
 		_Float16* g = (_Float16*)gradients;
 		const uint32_t n_net = (uint32_t)m_network->n_params();
@@ -1479,7 +1493,18 @@ public:
 		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
 		if (need_dx) {
 			if (profile) profile->mark(stream, StepProfile::EncodingBackward, false);
+			// the optimizer's offer to have its update applied by the gradient kernel, re-based to the encoding's parameters
+			AdamInFlush enc_adam;
+			if (adam && adam_done) {
+				enc_adam = adam->advanced(n_net);
+				ctx.encoding_ctx.adam = &enc_adam;
+			}
 			m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + n_net, g ? g + n_net : nullptr, mode, plane_f > 0);
+			ctx.encoding_ctx.adam = nullptr;
+			if (adam_done) {
+				adam_done->clear();
+				for (const auto& r : ctx.encoding_ctx.adam_done) adam_done->emplace_back(r.first + n_net, r.second + n_net);
+			}
 			if (profile) profile->mark(stream, StepProfile::EncodingBackward, true);
 		}
 	}
@@ -1584,6 +1609,13 @@ public:
 	virtual ~Optimizer() {}
 	virtual void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) = 0;
 	virtual void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) = 0;
+	// A step in two parts, for gradient kernels that can apply the update to the parameters they own (AdamInFlush): begin_split_step
+	// starts the step and describes it (false: this optimizer cannot be split, nothing has happened -- call step()); finish_split_step
+	// updates every parameter outside `done`.  Together they equal step() bit for bit.
+	virtual bool begin_split_step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, AdamInFlush& out) { return false; }
+	virtual void finish_split_step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients, const ParamRanges& done) {
+		throw std::runtime_error{"Optimizer: finish_split_step without begin_split_step"};
+	}
 	virtual float learning_rate() const = 0;
 	virtual void set_learning_rate(float val) = 0;
 	virtual uint32_t step_count() const = 0;
@@ -1654,6 +1686,34 @@ public:
 		ensure_debias_table(stream);
 		adam_step(stream, m_h, m_n_weights, m_n_matrix, loss_scale, m_current_step, weights_full_precision, weights, gradients,
 		          m_first_moments.as<float>(), m_second_moments.as<float>(), m_param_steps.as<uint32_t>(), m_debias.as<float>());
+	}
+
+	bool begin_split_step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, AdamInFlush& out) override {
+		++m_current_step;
+		ensure_debias_table(stream);
+		out.args = make_adam_args(m_h, loss_scale, m_current_step);
+		out.w_fp = weights_full_precision;
+		out.w_half = weights;
+		out.m1 = m_first_moments.as<float>();
+		out.m2 = m_second_moments.as<float>();
+		out.steps = m_param_steps.as<uint32_t>();
+		out.debias_table = m_debias.as<float>();
+		return true;
+	}
+	void finish_split_step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients, const ParamRanges& done) override {
+		size_t begin = 0;
+		auto update = [&](size_t b, size_t e) { // parameters [b, e) the usual way; the matrix weights are the first m_n_matrix of the vector
+			if (e <= b) return;
+			const size_t n_matrix = m_n_matrix > b ? std::min(m_n_matrix - b, e - b) : 0;
+			adam_step(stream, m_h, e - b, n_matrix, loss_scale, m_current_step, weights_full_precision + b, (char*)weights + 2 * b, (const char*)gradients + 2 * b,
+			          m_first_moments.as<float>() + b, m_second_moments.as<float>() + b, m_param_steps.as<uint32_t>() + b, m_debias.as<float>());
+		};
+		for (const auto& r : done) {
+			CHECK_THROW(r.first >= begin && r.second <= m_n_weights);
+			update(begin, r.first);
+			begin = r.second;
+		}
+		update(begin, m_n_weights);
 	}
 
 	// debias factors for steps [0, m_debias_filled), computed ahead in blocks of 4096 steps; refilled when the betas change
@@ -2119,6 +2179,14 @@ public:
 		m_model->backward(stream, *ctx.model_ctx, n, input, ctx.output.data(), ctx.dL_doutput_ptr, dL_dinput, use_inference_params ? params_inference() : m_params.data(), m_grads.data(), mode);
 	}
 
+	size_t params_updated_in_flush() const { return m_params_updated_in_flush; }
+	// TCNN_AMD_ADAM_IN_FLUSH=1: the optimizer's update is applied by the gradient kernels where they can carry it.  Off by default:
+	// bit-identical and measured equal in time on C3a (0.229 / 0.230 vs 0.230 / 0.225 ms per step; DESIGN.md "Adam in the scatter").
+	static bool adam_in_flush_enabled() { // read per step so that tests can cover both forms in one process
+		const char* e = getenv("TCNN_AMD_ADAM_IN_FLUSH");
+		return e && e[0] == '1';
+	}
+
 	void optimizer_step(hipStream_t stream, float loss_scale) { // trainer.h:155-157
 		m_optimizer->step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data());
 	}
@@ -2153,14 +2221,24 @@ public:
 					ctx->dL_doutput_ptr = ctx->dL_doutput.data();
 				}
 			}
+			m_params_updated_in_flush = 0;
 			m_profile.begin_step();
+			// TCNN_AMD_ADAM_IN_FLUSH=1: the optimizer's update rides on the gradient kernels where they can carry it (k_grid_scatter:
+			// the owner of a chunk updates its parameters as it flushes); what they did not take is done afterwards.
+			AdamInFlush adam;
+			ParamRanges adam_done;
+			const bool split = run_optimizer && mode == GradientMode::Overwrite && adam_in_flush_enabled() &&
+			                   m_optimizer->begin_split_step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), adam);
 			ctx->model_ctx = m_model->fused_step(stream, n, input, target, data_pdf, external_dL_dy, m_loss, loss_scale, ctx->output.data(),
 			                                     ctx->compact ? ctx->compact_dL_doutput.data() : ctx->dL_doutput.data(),
 			                                     ctx->compact ? ctx->compact_L.as<float>() : ctx->L.as<float>(), ctx->compact, dL_dinput, m_params.data(), m_grads.data(), mode,
-			                                     &m_profile);
+			                                     &m_profile, split ? &adam : nullptr, split ? &adam_done : nullptr);
 			if (run_optimizer) {
 				m_profile.mark(stream, StepProfile::Optimizer, false);
-				optimizer_step(stream, loss_scale);
+				m_params_updated_in_flush = 0;
+				for (const auto& r : adam_done) m_params_updated_in_flush += r.second - r.first;
+				if (split) m_optimizer->finish_split_step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data(), adam_done);
+				else optimizer_step(stream, loss_scale);
 				m_profile.mark(stream, StepProfile::Optimizer, true);
 			}
 			m_profile.end_step();
@@ -2169,6 +2247,7 @@ public:
 			ctx = forward(stream, loss_scale, n, input, target, data_pdf, use_inference_params, dL_dinput != nullptr, external_dL_dy);
 			backward(stream, *ctx, n, input, dL_dinput, use_inference_params, mode);
 		}
+		m_params_updated_in_flush = 0;
 		if (run_optimizer) optimizer_step(stream, loss_scale);
 		return ctx;
 	}
@@ -2274,6 +2353,7 @@ private:
 	Pcg32 m_rng;
 	DeviceBuf m_params_fp, m_params, m_grads, m_scalar;
 	StepProfile m_profile;
+	size_t m_params_updated_in_flush = 0;
 };
 
 } // namespace tcnn_amd

@@ -105,6 +105,8 @@ struct GridScatterTask {
 	uint32_t pad;
 };
 struct GridScatterRange { size_t grad_begin; uint32_t n_elems; uint32_t scratch_begin; uint32_t pad; }; // shared chunks, for the finalize pass
+struct AdamInFlush;                                          // below, with the optimizer kernels
+typedef std::vector<std::pair<size_t, size_t>> ParamRanges; // sorted, disjoint [begin, end) of the parameter vector
 constexpr uint32_t GRID_FILTER_MAX_CHUNKS = 64;     // chunks per level the sample filter can describe (bit planes per level)
 uint32_t grid_scatter_max_chunks();                 // = GRID_FILTER_MAX_CHUNKS
 void grid_scatter_setup_levels(GridMeta& meta);     // fills GridLevel::scatter_* (how each level's table is cut into chunks)
@@ -123,7 +125,10 @@ void grid_mask_to_bits(hipStream_t stream, const GridMeta& meta, const GridMeta*
 void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
                        const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records = false,
-                       uint64_t* task_times = nullptr); // task_times (optional): device uint64[n_tasks][8], per-task timestamps for the plan tuner
+                       uint64_t* task_times = nullptr, // task_times (optional): device uint64[n_tasks][8], per-task timestamps for the plan tuner
+                       const AdamInFlush* adam = nullptr); // adam (optional, record form only): arrays indexed like grad; see grid_scatter_adam_ranges
+// the parameter ranges (relative to grad) a launch of `tasks` with `adam` updates itself; empty = this plan cannot carry the optimizer step
+ParamRanges grid_scatter_adam_ranges(const GridMeta& meta, const std::vector<GridScatterTask>& tasks, bool dy_records);
 // dy_records: dL_dy is float4 [grid_scatter_record_planes()][n] scatter records {coordinates, gradient halves} (mlp_device.h
 // store_dx_record; D = 2 with F = 2 packs two levels into one record); x is then not read
 bool grid_scatter_records_supported(const GridMeta& meta);
@@ -250,6 +255,33 @@ struct AdamHyper {
 	float learning_rate = 1e-3f, beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-8f, l2_reg = 1e-8f;
 	float relative_decay = 0.0f, absolute_decay = 0.0f, clipping_magnitude = 0.0f, non_matrix_learning_rate_factor = 1.0f;
 	bool adabound = false, optimize_matrix_params = true, optimize_non_matrix_params = true;
+};
+// kernel-side form of the hyperparameters of one step (k_misc.hip make_adam_args)
+struct AdamArgs {
+	float relative_weight_decay, absolute_weight_decay, weight_clipping_magnitude, loss_scale, learning_rate, non_matrix_learning_rate_factor;
+	float beta1, beta2, epsilon, lower_lr_bound, upper_lr_bound, l2_reg;
+	uint32_t optimize_matrix_params, optimize_non_matrix_params;
+	float inv_loss_scale;
+	uint32_t inv_loss_scale_exact;
+	uint32_t common_step; // the optimizer's own step count: the per-parameter count of every parameter that was updated in every step
+};
+AdamArgs make_adam_args(const AdamHyper& h, float loss_scale, uint32_t current_step);
+// Adam applied by a gradient kernel: the owner of a chunk of the gradient has its final value in LDS when it flushes and updates
+// those parameters on the spot (k_grid_scatter.hip) -- the 34 B/param of optimizer state stream under the latency-bound phases of
+// the other workgroups instead of in a kernel of their own.  Arrays are indexed like the gradient array the kernel writes.
+struct AdamInFlush {
+	AdamArgs args;
+	float* w_fp = nullptr;
+	void* w_half = nullptr;
+	float* m1 = nullptr;
+	float* m2 = nullptr;
+	uint32_t* steps = nullptr;
+	const float* debias_table = nullptr;
+	AdamInFlush advanced(size_t n) const { // the same arrays seen from parameter n on
+		AdamInFlush r = *this;
+		r.w_fp += n; r.w_half = (char*)w_half + 2 * n; r.m1 += n; r.m2 += n; r.steps += n;
+		return r;
+	}
 };
 void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
                float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps, const float* debias_table);

@@ -94,6 +94,10 @@ class Trainer:
     def profile_next_step(self):
         _C.check(_C.lib.tcnn_trainer_profile_next_step(self._h))
 
+    def params_updated_in_flush(self):
+        """parameters whose optimizer update the last training_step's gradient kernels applied themselves (0: the usual k_adam)"""
+        return int(_C.lib.tcnn_trainer_params_updated_in_flush(self._h))
+
     def profile_collect(self, stream=None):
         """-> ({piece: mean milliseconds per profiled step}, number of profiled steps)"""
         ms = (C.c_float * 4)()
