@@ -25,6 +25,7 @@
 //     k_grid_scatter_finalize.
 #include "grid_fixed.h"
 #include "adam_device.h"
+#include "mlp_side_jobs.h"
 
 #include <algorithm>
 #include <cmath>
@@ -464,10 +465,20 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 	}
 }
 
-// shared (split) chunks: scratch holds the exact integer sums; round, store, and leave the scratch zeroed for the next step
-__global__ void __launch_bounds__(256) k_grid_scatter_finalize(const GridScatterRange* __restrict__ ranges, unsigned long long* __restrict__ scratch, half_t* __restrict__ grad, const int accumulate_mode) {
-	const GridScatterRange r = ranges[blockIdx.y];
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < r.n_elems; i += gridDim.x * blockDim.x) {
+// shared (split) chunks: scratch holds the exact integer sums; round, store, and leave the scratch zeroed for the next step.
+// Blocks [0, n_reduce_blocks) carry the MLP's slab reduction (mlp_side_jobs.h) instead -- the step's two small reductions in one launch.
+constexpr uint32_t FINALIZE_THREADS = SLAB_REDUCE_ELEMS * SLAB_REDUCE_GROUPS; // 1024: what mlp_reduce_block wants
+constexpr uint32_t FINALIZE_BLOCKS_PER_RANGE = 64;
+__global__ void __launch_bounds__(FINALIZE_THREADS) k_grid_scatter_finalize(const GridScatterRange* __restrict__ ranges, unsigned long long* __restrict__ scratch, half_t* __restrict__ grad, const int accumulate_mode,
+                                                                           const uint32_t n_reduce_blocks, const MlpReduceJob job) {
+	__shared__ float part[SLAB_REDUCE_GROUPS * SLAB_REDUCE_ELEMS];
+	if (blockIdx.x < n_reduce_blocks) {
+		mlp_reduce_block(part, blockIdx.x, threadIdx.x, job.n_elems, job.n_elems, job.n_elems, job.n_slabs, job.slabs, (_Float16*)job.grad, job.accumulate);
+		return;
+	}
+	const uint32_t b = blockIdx.x - n_reduce_blocks;
+	const GridScatterRange r = ranges[b / FINALIZE_BLOCKS_PER_RANGE];
+	for (uint32_t i = (b % FINALIZE_BLOCKS_PER_RANGE) * FINALIZE_THREADS + threadIdx.x; i < r.n_elems; i += FINALIZE_BLOCKS_PER_RANGE * FINALIZE_THREADS) {
 		long long s = (long long)scratch[r.scratch_begin + i];
 		scratch[r.scratch_begin + i] = 0;
 		if (accumulate_mode) s += half_to_fixed(grad[r.grad_begin + i]);
@@ -803,7 +814,7 @@ ParamRanges grid_scatter_adam_ranges(const GridMeta& meta, const std::vector<Gri
 void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
                        const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records,
-                       uint64_t* task_times, const AdamInFlush* adam) {
+                       uint64_t* task_times, const AdamInFlush* adam, const MlpReduceJob* reduce_job) {
 	if (n_tasks == 0) return;
 	const unsigned long long* bits = (const unsigned long long*)chunk_bits;
 	unsigned long long* sc = (unsigned long long*)scratch;
@@ -819,8 +830,10 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
 		default: throw std::runtime_error{"GridEncoding: number of input dims must be 2 or 3."};
 	}
 	if (n_ranges > 0) {
-		hipLaunchKernelGGL(k_grid_scatter_finalize, dim3(256, n_ranges), dim3(256), 0, stream, dev_ranges, sc, (half_t*)grad,
-		                   accumulate ? 1 : 0);
+		const uint32_t n_reduce_blocks = reduce_job ? div_round_up(reduce_job->n_elems, (uint32_t)SLAB_REDUCE_ELEMS) : 0;
+		hipLaunchKernelGGL(k_grid_scatter_finalize, dim3(n_reduce_blocks + n_ranges * FINALIZE_BLOCKS_PER_RANGE), dim3(FINALIZE_THREADS), 0, stream, dev_ranges, sc, (half_t*)grad,
+		                   accumulate ? 1 : 0, n_reduce_blocks, reduce_job ? *reduce_job : MlpReduceJob{});
+		if (reduce_job) reduce_job->taken = true;
 	}
 }
 

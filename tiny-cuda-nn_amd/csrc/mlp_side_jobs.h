@@ -3,7 +3,8 @@
 //   * mlp_prep_element: one element of the fragment images (k_mlp.hip, k_mlp_prep) -- carried by k_grid_fwd_planes, which it does
 //     not depend on (measured on C3a: the 4.6 us launch ahead of the encoding's forward kernel is gone, that kernel is no slower);
 //   * mlp_reduce_block: one block of the fixed-order slab reduction of the weight gradients (k_wgrad_reduce).  Carried on the grid
-//     scatter it did not pay (model.h, fused_mlp_and_scatter): it stays a launch.
+//     scatter itself it did not pay (model.h, fused_mlp_and_scatter); it rides on the scatter's small finalize launch instead
+//     (MlpReduceJob, k_grid_scatter_finalize): the two ~4.5 us reductions of a step are one launch.
 #pragma once
 
 #include "tcnn_common.h"
@@ -82,5 +83,14 @@ __device__ inline void mlp_reduce_block(float* part, const uint32_t block, const
 		*g = (_Float16)s;
 	}
 }
+
+// side job of the grid scatter's finalize launch: grad[i] (=|+=) sum over the slabs, for the MLP's n_elems weights
+struct MlpReduceJob {
+	uint32_t n_elems = 0, n_slabs = 0;
+	const float* slabs = nullptr;
+	void* grad = nullptr; // half
+	int accumulate = 0;
+	mutable bool taken = false; // set by the launch that carried the job
+};
 
 } // namespace tcnn_amd

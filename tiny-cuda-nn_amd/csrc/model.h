@@ -213,6 +213,8 @@ struct EncodingContext {
 	// parameters it has updated; whatever is not listed there is still the optimizer's to do.
 	mutable const AdamInFlush* adam = nullptr;
 	mutable ParamRanges adam_done;
+	// likewise: a small job the backward pass may carry on one of its launches (MlpReduceJob::taken reports it)
+	mutable const MlpReduceJob* reduce_job = nullptr;
 	std::vector<EncodingContext> nested; // Composite: one context per nested encoding
 };
 
@@ -486,7 +488,7 @@ public:
 				}
 				grid_backward_lds(stream, m_meta, dev_meta(), plan.dev_tasks.as<GridScatterTask>(), plan.n_tasks, plan.dev_ranges.as<GridScatterRange>(), plan.n_ranges,
 				                  plan.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, mask,
-				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, tune ? times.as<uint64_t>() : nullptr, adam);
+				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, tune ? times.as<uint64_t>() : nullptr, adam, ctx.reduce_job);
 				if (m_any_binned) { // levels cut into more than 64 chunks (k_grid_bin.hip)
 					CHECK_THROW(!(dy_planes && ctx.dy_records));
 					ArenaBuf workspace{stream, grid_bin_workspace_bytes(m_meta, n)};
@@ -1490,7 +1492,18 @@ public:
 		// (Carrying the slab reduction on the grid scatter's launch the way k_mlp_prep rides on the forward kernel was built and
 		// measured: its workgroups each take a whole CU's LDS slot for a few microseconds, in front of the task list they delay the
 		// long coarse-level tasks, behind it they wait for a slot -- the scatter grew by 5.4 / 6.5 us for the 4.4 us launch saved.)
-		if (mode != GradientMode::Ignore) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
+		// The slab reduction rides on the scatter's finalize launch when the encoding's backward pass has one (two ~4.5 us launches
+		// become one); otherwise, or with TCNN_AMD_SIDE_JOBS=0, it is a launch of its own.
+		MlpReduceJob reduce_job;
+		if (mode != GradientMode::Ignore) {
+			reduce_job.n_elems = n_net;
+			reduce_job.n_slabs = n_slabs;
+			reduce_job.slabs = slabs.as<float>();
+			reduce_job.grad = g;
+			reduce_job.accumulate = mode == GradientMode::Accumulate ? 1 : 0;
+			if (!(need_dx && side_jobs_enabled())) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
+			else ctx.encoding_ctx.reduce_job = &reduce_job;
+		}
 		if (need_dx) {
 			if (profile) profile->mark(stream, StepProfile::EncodingBackward, false);
 			// the optimizer's offer to have its update applied by the gradient kernel, re-based to the encoding's parameters
@@ -1501,6 +1514,10 @@ public:
 			}
 			m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + n_net, g ? g + n_net : nullptr, mode, plane_f > 0);
 			ctx.encoding_ctx.adam = nullptr;
+			if (ctx.encoding_ctx.reduce_job) {
+				ctx.encoding_ctx.reduce_job = nullptr;
+				if (!reduce_job.taken) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
+			}
 			if (adam_done) {
 				adam_done->clear();
 				for (const auto& r : ctx.encoding_ctx.adam_done) adam_done->emplace_back(r.first + n_net, r.second + n_net);

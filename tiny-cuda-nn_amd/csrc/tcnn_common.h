@@ -106,6 +106,7 @@ struct GridScatterTask {
 };
 struct GridScatterRange { size_t grad_begin; uint32_t n_elems; uint32_t scratch_begin; uint32_t pad; }; // shared chunks, for the finalize pass
 struct AdamInFlush;                                          // below, with the optimizer kernels
+struct MlpReduceJob;                                         // mlp_side_jobs.h
 typedef std::vector<std::pair<size_t, size_t>> ParamRanges; // sorted, disjoint [begin, end) of the parameter vector
 constexpr uint32_t GRID_FILTER_MAX_CHUNKS = 64;     // chunks per level the sample filter can describe (bit planes per level)
 uint32_t grid_scatter_max_chunks();                 // = GRID_FILTER_MAX_CHUNKS
@@ -126,7 +127,8 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
                        const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
                        const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const uint64_t* chunk_bits, bool accumulate, bool dy_records = false,
                        uint64_t* task_times = nullptr, // task_times (optional): device uint64[n_tasks][8], per-task timestamps for the plan tuner
-                       const AdamInFlush* adam = nullptr); // adam (optional, record form only): arrays indexed like grad; see grid_scatter_adam_ranges
+                       const AdamInFlush* adam = nullptr, // adam (optional, record form only): arrays indexed like grad; see grid_scatter_adam_ranges
+                       const MlpReduceJob* reduce_job = nullptr); // (optional) carried by the finalize launch when there is one; ->taken says so
 // the parameter ranges (relative to grad) a launch of `tasks` with `adam` updates itself; empty = this plan cannot carry the optimizer step
 ParamRanges grid_scatter_adam_ranges(const GridMeta& meta, const std::vector<GridScatterTask>& tasks, bool dy_records);
 // dy_records: dL_dy is float4 [grid_scatter_record_planes()][n] scatter records {coordinates, gradient halves} (mlp_device.h
