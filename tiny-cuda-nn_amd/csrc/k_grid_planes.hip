@@ -237,7 +237,11 @@ uint32_t max_scatter_chunks(const GridMeta& meta) {
 } // namespace
 
 // samples per thread of the kernel shape used for this grid (see k_grid_fwd_planes)
-uint32_t grid_planes_spt(const GridMeta& meta) { return max_scatter_chunks(meta) <= (uint32_t)FP_MAX_CHUNKS ? 8u : 2u; }
+uint32_t grid_planes_spt(const GridMeta& meta) {
+	static const uint32_t forced = getenv("TCNN_AMD_FWD_SPT") ? (uint32_t)atoi(getenv("TCNN_AMD_FWD_SPT")) : 0u; // development knob: 4
+	if (forced == 4 && max_scatter_chunks(meta) <= (uint32_t)FP_MAX_CHUNKS) return 4u;
+	return max_scatter_chunks(meta) <= (uint32_t)FP_MAX_CHUNKS ? 8u : 2u;
+}
 
 bool grid_planes_supported(const GridMeta& meta, uint32_t n) {
 	const uint32_t F = meta.n_features_per_level;
@@ -300,7 +304,7 @@ void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMet
 		default: return launch_planes<D, 8, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job); \
 	}
 #define TCNN_PLANES(D) \
-	if (grid_planes_spt(meta) == 8) { TCNN_PLANES_F(D, 8) } else { TCNN_PLANES_F(D, 2) }
+	if (grid_planes_spt(meta) == 8) { TCNN_PLANES_F(D, 8) } else if (grid_planes_spt(meta) == 4) { TCNN_PLANES_F(D, 4) } else { TCNN_PLANES_F(D, 2) }
 	if (meta.n_pos_dims == 2) { TCNN_PLANES(2) } else { TCNN_PLANES(3) }
 #undef TCNN_PLANES
 #undef TCNN_PLANES_F
