@@ -624,7 +624,9 @@ bool mlp_train_regs_supported(const MlpDesc& d, uint32_t n) {
 
 uint32_t mlp_train_regs_grid(const MlpDesc& d, uint32_t n) {
 	(void)d;
-	return std::max(1u, std::min(256u, div_round_up(n / 16, (uint32_t)REGS_NW)));
+	uint32_t cap = 256;
+	if (const char* e = getenv("TCNN_AMD_MLP_GRID")) cap = std::max(1, atoi(e)); // development knob (how the trip time depends on the number of busy CUs: it does not)
+	return std::max(1u, std::min(cap, div_round_up(n / 16, (uint32_t)REGS_NW)));
 }
 
 void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
