@@ -27,7 +27,8 @@ constexpr int FP_MAX_CHUNKS = GRID_FILTER_MAX_CHUNKS; // bit planes per level: l
 constexpr int FP_PER_LANE = FP_MAX_CHUNKS / 64;       // chunks whose words one lane carries out (chunk = lane + 64 j)
 
 // FP_SPT = samples per thread = consecutive 64-sample groups per wave; a work item is FP_THREADS * FP_SPT samples of one level.
-// Two shapes: 8 (32 gathers in flight per thread), and 2 for the big 3-D grids whose 8 corners x 4 features would not fit the registers.
+// Shapes: 4 (16 gathers in flight per thread; 8 is kept for A/B runs), and 2 for the big 3-D grids whose 8 corners x 4 features would
+// not fit the registers.
 template <int D, int F, int FP_SPT>
 __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 	const GridMeta* __restrict__ meta, const uint32_t* __restrict__ work, const uint32_t max_items, const uint32_t blocks_per_xcd, const uint32_t n, const MatView x,
@@ -238,9 +239,11 @@ uint32_t max_scatter_chunks(const GridMeta& meta) {
 
 // samples per thread of the kernel shape used for this grid (see k_grid_fwd_planes)
 uint32_t grid_planes_spt(const GridMeta& meta) {
-	static const uint32_t forced = getenv("TCNN_AMD_FWD_SPT") ? (uint32_t)atoi(getenv("TCNN_AMD_FWD_SPT")) : 0u; // development knob: 4
-	if (forced == 4 && max_scatter_chunks(meta) <= (uint32_t)FP_MAX_CHUNKS) return 4u;
-	return max_scatter_chunks(meta) <= (uint32_t)FP_MAX_CHUNKS ? 8u : 2u;
+	// 4 samples per thread (16 gathers in flight, half the registers, twice the waves per CU) measured against 8 on C3a, four runs
+	// each: 56.1-56.9 us against 58.7-59.2.  TCNN_AMD_FWD_SPT=8 keeps the old shape (A/B runs).
+	static const uint32_t forced = getenv("TCNN_AMD_FWD_SPT") ? (uint32_t)atoi(getenv("TCNN_AMD_FWD_SPT")) : 0u;
+	if (max_scatter_chunks(meta) > (uint32_t)FP_MAX_CHUNKS) return 2u;
+	return forced == 8 ? 8u : 4u;
 }
 
 bool grid_planes_supported(const GridMeta& meta, uint32_t n) {
