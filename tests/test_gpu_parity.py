@@ -253,6 +253,13 @@ def test_oneblob_forward(tcnn, oracle, n_bins):
     enc = tcnn.Encoding(3, cfg)
     ref = oracle.create_encoding(3, cfg, alignment=0)
     x = oracle.Pcg32(42).uniform_strided(1024 * 3).reshape(1024, 3)
+    # the ends of the unit interval, bin edges and their float neighbours, and inputs outside [0, 1] (the kernel that evaluates
+    # only the bins around x must hand those to the general form): every output bit as the definition gives it
+    edges = np.arange(0, n_bins + 1, dtype=np.float32) / n_bins
+    special = np.concatenate([edges, np.nextafter(edges, np.float32(2)), np.nextafter(edges, np.float32(-1)),
+                              np.float32([-0.0, -0.25, -1.0, -1.5, 1.25, 2.0, 5.0, -7.5, 0.5 / n_bins, 1 - 0.5 / n_bins])]).astype(np.float32)
+    x[: special.size, 0] = special
+    x[: special.size, 1] = special[::-1]
     want, _ = ref.forward(x)
     got = enc(_t(x))
     assert np.array_equal(_bits(got), want)

@@ -95,6 +95,75 @@ __global__ void __launch_bounds__(256) k_oneblob_fwd8(const uint32_t n, const ui
 	*(vec8*)(out + (size_t)i * out_stride + j0) = v;
 }
 
+// The same, 8 consecutive bins per thread, for rows that are mostly zeros.  The quartic kernel has radius 1 / n_bins, so for an
+// input in [0, 1] only the bins within one bin of x (and of its wrap-around images x +- 1, which fall on the same bins modulo
+// n_bins) see anything but saturated cdf values; every other bin is a difference of equal integers, exactly +0.  The n_bins / 8
+// threads of a row (consecutive lanes of one wave) share the work on the five bins floor(x n_bins) - 2 .. + 2 -- evaluated in the
+// definition form, same operations, same bits -- exchange them with lane shuffles, and every thread stores its 8 bins: 30 cdf
+// evaluations per row instead of 27 per 8 bins (k_oneblob_fwd8 was ALU-bound: 14.5 of C2's 60 us), dense 1 KB stores per wave.
+// Inputs outside [0, 1] take the general form.  The threads behind the last row write the padding columns (ones, oneblob.h:207-209).
+template <typename T, int CPR> // CPR = n_bins / 8 = threads per row, a power of two <= 64
+__global__ void __launch_bounds__(256) k_oneblob_fwd_sparse(const uint32_t n, const uint32_t n_dims, const uint32_t log2_bins, const MatView x, T* __restrict__ out, const uint32_t out_stride) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	typedef T vec8 __attribute__((ext_vector_type(8)));
+	const uint32_t n_bins = 1u << log2_bins;
+	constexpr uint32_t cpr = CPR;
+	const uint32_t row_threads = n * n_dims * cpr;
+	if (gid >= row_threads) {
+		const uint32_t pad_chunks = (out_stride - n_dims * n_bins) >> 3;
+		const uint32_t p = gid - row_threads;
+		if (pad_chunks == 0 || p >= n * pad_chunks) return;
+		const uint32_t i = p / pad_chunks, pc = p - i * pad_chunks;
+		vec8 ones;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) ones[k] = (T)1.0f;
+		*(vec8*)(out + (size_t)i * out_stride + n_dims * n_bins + 8 * pc) = ones;
+		return;
+	}
+	const uint32_t r = gid / cpr, j = gid - r * cpr; // row, chunk of 8 bins inside it
+	const uint32_t i = r / n_dims, dim = r - i * n_dims;
+	const uint32_t b0 = 8 * j;
+	const float xv = x.data[(size_t)i * x.stride_sample + (size_t)dim * x.stride_dim];
+	const float nb = (float)n_bins;
+	auto edge = [&](const uint32_t bin) {
+		const float lb = scalbnf((float)(bin & (n_bins - 1)), -(int)log2_bins);
+		return quartic_cdf(lb - xv, nb) + quartic_cdf(lb - xv - 1.0f, nb) + quartic_cdf(lb - xv + 1.0f, nb);
+	};
+	vec8 v;
+	if (!(xv >= 0.0f && xv <= 1.0f)) { // general form (k_oneblob_fwd8); the threads of a row agree about this branch
+		float e[9];
+#pragma unroll
+		for (int k = 0; k < 9; ++k) e[k] = edge(b0 + k);
+		if (b0 + 8 == n_bins) e[8] += 1;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = (T)(e[k + 1] - e[k]);
+	} else {
+		const uint32_t centre = (uint32_t)(int)floorf(xv * nb) + n_bins - 2u; // window bin o is (centre + o) mod n_bins, o = 0..4: distinct since n_bins >= 8
+		// thread j evaluates the window bins j, j + CPR, ... (every thread the same number of them: a surplus thread repeats bin 4)
+		constexpr int PER = (5 + CPR - 1) / CPR;
+		float mine[PER];
+#pragma unroll
+		for (int t = 0; t < PER; ++t) {
+			const uint32_t o = min(j + (uint32_t)t * cpr, 4u);
+			const uint32_t bin = (centre + o) & (n_bins - 1);
+			const float l = edge(bin);
+			float rr = edge(bin + 1);
+			if (bin == n_bins - 1) rr += 1; // the last bin's right edge is bin 0's left edge + 1
+			mine[t] = rr - l;
+		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = (T)0.0f;
+#pragma unroll
+		for (int o = 0; o < 5; ++o) {
+			const float val = CPR == 1 ? mine[o / CPR] : __shfl(mine[o / CPR], o % CPR, CPR);
+			const uint32_t d = ((centre + o) & (n_bins - 1)) - b0;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) v[k] = d == (uint32_t)k ? (T)val : v[k];
+		}
+	}
+	*(vec8*)(out + (size_t)i * out_stride + (size_t)dim * n_bins + b0) = v;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(128) k_oneblob_bwd_input(const uint32_t n, const uint32_t n_dims, const uint32_t log2_bins, const MatView x, const T* __restrict__ dL_dy, const uint32_t dy_stride, const MatViewMut dL_dx) {
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,6 +512,22 @@ void oneblob_forward(hipStream_t stream, bool fp32, uint32_t n, uint32_t n_dims,
 	if (total == 0) return;
 	CHECK_THROW(total < (1ull << 32));
 	const uint32_t lb = log2_exact(n_bins);
+	if (n_bins % 8 == 0 && n_bins <= 512 && out_stride % 8 == 0) { // rows of at most 64 threads
+		const uint64_t threads = total / 8; // one per 8 outputs, the rows first, then the padding columns
+		const dim3 grid(blocks_for(threads, 256));
+#define TCNN_ONEBLOB_SPARSE(CPR_) \
+		case CPR_: \
+			if (fp32) hipLaunchKernelGGL((k_oneblob_fwd_sparse<float, CPR_>), grid, dim3(256), 0, stream, n, n_dims, lb, x, (float*)out, out_stride); \
+			else hipLaunchKernelGGL((k_oneblob_fwd_sparse<half_t, CPR_>), grid, dim3(256), 0, stream, n, n_dims, lb, x, (half_t*)out, out_stride); \
+			break;
+		switch (n_bins / 8) {
+			TCNN_ONEBLOB_SPARSE(1) TCNN_ONEBLOB_SPARSE(2) TCNN_ONEBLOB_SPARSE(4) TCNN_ONEBLOB_SPARSE(8)
+			TCNN_ONEBLOB_SPARSE(16) TCNN_ONEBLOB_SPARSE(32) TCNN_ONEBLOB_SPARSE(64)
+			default: CHECK_THROW(false);
+		}
+#undef TCNN_ONEBLOB_SPARSE
+		return;
+	}
 	if (n_bins % 8 == 0 && out_stride % 8 == 0) {
 		const uint64_t threads = total / 8;
 		if (fp32) hipLaunchKernelGGL(k_oneblob_fwd8<float>, dim3(blocks_for(threads, 256)), dim3(256), 0, stream, n, n_dims, lb, x, (float*)out, out_stride);
