@@ -440,6 +440,32 @@ def test_inference_matches_forward(tcnn, oracle):
     assert np.array_equal(got_soa.cpu().numpy().T, got.cpu().numpy())
 
 
+@pytest.mark.parametrize("n_bins", [32, 64, 128])
+def test_oneblob_inside_the_mlp_kernel_is_bit_identical(tcnn, oracle, monkeypatch, n_bins):
+    """network->inference() with a OneBlob encoding: the MLP kernel evaluates the encoding inside its input load (only the five
+    bins around x per dimension, shared between the lanes of a sample) -- the same half features, hence the same output bits as
+    the encoding's own kernel followed by the MLP kernel (TCNN_AMD_FUSE_ONEBLOB=0), and the oracle's values within 1e-2.
+    Inputs outside [0, 1], at the ends and on bin edges included; AoS and SoA input."""
+    n = 2048
+    cfg = dict(CONFIG_C2, encoding={"otype": "OneBlob", "n_bins": n_bins})
+    tr = tcnn.Trainer(2, 3, cfg, seed=1337)
+    ref = oracle.Trainer(2, 3, cfg, seed=1337)
+    x, _ = oracle.synthetic_batch(n, 2, 3, seed=5)
+    edges = np.arange(0, n_bins + 1, dtype=np.float32) / n_bins
+    special = np.concatenate([edges, np.nextafter(edges, np.float32(2)), np.nextafter(edges, np.float32(-1)),
+                              np.float32([-0.0, -0.25, -1.0, 1.25, 2.0, 5.0, -7.5])]).astype(np.float32)
+    x[: special.size, 0] = special
+    x[: special.size, 1] = special[::-1]
+    fused = tr.inference(_t(x))
+    fused_soa = tr.inference(_t(np.ascontiguousarray(x.T)), input_layout=0)
+    monkeypatch.setenv("TCNN_AMD_FUSE_ONEBLOB", "0")
+    plain = tr.inference(_t(x))
+    monkeypatch.delenv("TCNN_AMD_FUSE_ONEBLOB")
+    assert np.array_equal(fused.cpu().numpy().view(np.uint32), plain.cpu().numpy().view(np.uint32))
+    assert np.array_equal(fused_soa.cpu().numpy().view(np.uint32), plain.cpu().numpy().view(np.uint32))
+    assert rel_err(fused.cpu().numpy(), ref.inference(x)) < 1e-2
+
+
 def test_batch_size_granularity_error(tcnn):
     """object.h:130: batch sizes must be multiples of 256 -> error, surfaced as RuntimeError like pybind11 does."""
     import torch

@@ -11,6 +11,7 @@
 //   common_device.h:990-1014     trim_and_cast / cast / cast_from     -> k_trim_and_cast / k_cast_*
 #include "tcnn_common.h"
 #include "adam_device.h"
+#include "oneblob_device.h"
 
 #include <hip/hip_fp16.h>
 
@@ -23,20 +24,6 @@ namespace {
 typedef _Float16 half_t;
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-// ---- quartic kernel, common_device.h:905-920
-__device__ inline float quartic(float x, float inv_radius) {
-	const float u = x * inv_radius;
-	const float tmp = fmaxf(1 - u * u, 0.0f);
-	return ((float)15 / 16) * tmp * tmp;
-}
-__device__ inline float quartic_cdf_deriv(float x, float inv_radius) { return quartic(x, inv_radius) * inv_radius; }
-__device__ inline float quartic_cdf(float x, float inv_radius) {
-	const float u = x * inv_radius;
-	const float u2 = u * u;
-	const float u4 = u2 * u2;
-	return fmaxf(0.0f, fminf(1.0f, ((float)15 / 16) * u * (1 - ((float)2 / 3) * u2 + ((float)1 / 5) * u4) + 0.5f));
-}
 
 // OneBlob, definition form of oneblob.h:47-67: bin k = C(l_{k+1}) - C(l_k), C(l) = cdf(l-x) + cdf(l-x-1) + cdf(l-x+1),
 // the last bin's right edge is bin 0's left edge + 1 (wrap-around).  One thread per output element (AoS).

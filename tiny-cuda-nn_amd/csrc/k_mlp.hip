@@ -22,6 +22,7 @@
 //   Layer 0 reads its B operand from memory ([n][in] half, 16 bytes per lane) in natural order k = 32 s + 8 q + j.
 #include "mlp_device.h"
 #include "mlp_side_jobs.h"
+#include "oneblob_device.h"
 
 namespace tcnn_amd {
 namespace {
@@ -53,6 +54,8 @@ struct FwdArgs {
 	MatView x_f32;        // data == nullptr: not used
 	uint32_t x_f32_dims;
 	float x_scale, x_offset;
+	// fused OneBlob encoding (oneblob.h:47-67): x_f32 holds the coordinates, feature dim * n_bins + bin; 0 = off
+	uint32_t oneblob_log2;
 	// fused trim_and_cast (common_device.h:990-1002): float output of the first out_f32_dims outputs
 	MatViewMut out_f32;   // data == nullptr: not used
 	uint32_t out_f32_dims;
@@ -120,7 +123,8 @@ __device__ inline void activate_pack(const f4 (&acc)[T][NB], h8 (&hf)[KS][NB], u
 // with ds_read_b128 -- for wide, deep networks (C4: 108 KB of fragments) whose image falls out of the 32 KB L1, where every
 // MFMA otherwise waits on a 1 KB fetch from L2.  Used for inference with NB = 4 column blocks per wave (one fragment read
 // feeds 4 MFMAs) and 8 waves per workgroup (2 per SIMD: one wave's activation VALU work under the other's MFMAs).
-template <int W, int NB, int ACT, bool IMG_LDS = false, int THREADS = 256>
+// OB: the input is the OneBlob encoding of a.x_f32, evaluated in the layer-0 loop (a.oneblob_log2; instantiated for widths 64 and 128).
+template <int W, int NB, int ACT, bool IMG_LDS = false, int THREADS = 256, bool OB = false>
 __global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
@@ -157,13 +161,66 @@ __global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdA
 		{
 			const uint32_t ks0 = d.layers[0].ks_fwd;
 			const uint32_t img = d.layers[0].fwd_off;
+			// fused OneBlob (n_bins >= 32: the four quarters of a k-step are four 8-bin chunks of ONE dimension's row).  Per sample
+			// and dimension only the five bins around x differ from +0 (oneblob_device.h); the four lanes (c, 0..3) of a sample share
+			// their evaluation (lane q: bins q and min(q + 4, 4)), exchange them with lane shuffles at the first k-step of the
+			// dimension and keep them for its other k-steps.
+			uint32_t ob_first[OB ? NB : 1];
+			float ob_win[OB ? NB : 1][5], ob_x[OB ? NB : 1];
 			for (uint32_t s = 0; s < ks0; ++s) {
 				h8 bf[NB];
 				const uint32_t k0 = 32 * s + 8 * q;
+				if constexpr (OB) {
+					const uint32_t n_bins = 1u << a.oneblob_log2;
+					const uint32_t dim = (32 * s) >> a.oneblob_log2; // wave-uniform
+					if (dim >= a.x_f32_dims) { // padding columns: ones
+#pragma unroll
+						for (int b = 0; b < NB; ++b) bf[b] = h8{1, 1, 1, 1, 1, 1, 1, 1};
+					} else {
+						if (((32 * s) & (n_bins - 1)) == 0) { // first k-step of this dimension
+#pragma unroll
+							for (int b = 0; b < NB; ++b) {
+								const uint32_t sample = s0 + 16 * b + c;
+								const float xv = a.x_f32.data[(size_t)sample * a.x_f32.stride_sample + (size_t)dim * a.x_f32.stride_dim];
+								ob_x[b] = xv;
+								ob_first[b] = oneblob_window_first(xv, a.oneblob_log2);
+								const float m0 = oneblob_bin(xv, (ob_first[b] + q) & (n_bins - 1), a.oneblob_log2);
+								const float m1 = oneblob_bin(xv, (ob_first[b] + 4) & (n_bins - 1), a.oneblob_log2);
+#pragma unroll
+								for (int o = 0; o < 4; ++o) ob_win[b][o] = __shfl(m0, (int)(c + 16 * o), 64);
+								ob_win[b][4] = m1;
+							}
+						}
+						const uint32_t b0 = k0 & (n_bins - 1);
+#pragma unroll
+						for (int b = 0; b < NB; ++b) {
+							h8 v;
+							if (oneblob_in_unit_interval(ob_x[b])) {
+#pragma unroll
+								for (int k = 0; k < 8; ++k) v[k] = (half_t)0.0f;
+#pragma unroll
+								for (int o = 0; o < 5; ++o) {
+									const uint32_t dd = ((ob_first[b] + o) & (n_bins - 1)) - b0;
+#pragma unroll
+									for (int k = 0; k < 8; ++k) v[k] = dd == (uint32_t)k ? (half_t)ob_win[b][o] : v[k];
+								}
+							} else { // general form: the chunk's 9 edges
+								float e[9];
+#pragma unroll
+								for (int k = 0; k < 9; ++k) e[k] = oneblob_edge(ob_x[b], b0 + k, a.oneblob_log2);
+								if (b0 + 8 == n_bins) e[8] += 1;
+#pragma unroll
+								for (int k = 0; k < 8; ++k) v[k] = (half_t)(e[k + 1] - e[k]);
+							}
+							bf[b] = v;
+						}
+					}
+				} else {
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					if (k0 < in_w) bf[b] = load_mlp_input(a, in_w, s0 + 16 * b + c, k0);
 					else bf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+				}
 				}
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
@@ -486,6 +543,12 @@ inline uint32_t wgrad_grid(uint32_t n) {
 }
 
 template <int W, int NB>
+void launch_fwd_oneblob(hipStream_t stream, const MlpDesc& d, const FwdArgs& a, uint32_t grid) {
+	if (d.activation == (uint32_t)Activation::ReLU) hipLaunchKernelGGL((k_mlp_fwd<W, NB, (int)Activation::ReLU, false, 256, true>), dim3(grid), dim3(256), 0, stream, d, a);
+	else hipLaunchKernelGGL((k_mlp_fwd<W, NB, -1, false, 256, true>), dim3(grid), dim3(256), 0, stream, d, a);
+}
+
+template <int W, int NB>
 void launch_fwd_act(hipStream_t stream, const MlpDesc& d, const FwdArgs& a, uint32_t grid) {
 	if (d.activation == (uint32_t)Activation::ReLU) hipLaunchKernelGGL((k_mlp_fwd<W, NB, (int)Activation::ReLU>), dim3(grid), dim3(256), 0, stream, d, a);
 	else if (d.activation == (uint32_t)Activation::None) hipLaunchKernelGGL((k_mlp_fwd<W, NB, (int)Activation::None>), dim3(grid), dim3(256), 0, stream, d, a);
@@ -533,7 +596,16 @@ void mlp_forward_io(hipStream_t stream, const MlpDesc& d, const void* image, uin
 	CHECK_THROW(io.out_half != nullptr || io.out_f32.data != nullptr);
 	if (n == 0) return;
 	FwdArgs a{(const half_t*)io.x_half, (half_t*)io.out_half, (half_t*)hidden, (const h8*)image, n, io.x_plane_features,
-	          io.x_f32, io.x_f32_dims, io.x_scale, io.x_offset, io.out_f32, io.out_f32_dims};
+	          io.x_f32, io.x_f32_dims, io.x_scale, io.x_offset, 0u, io.out_f32, io.out_f32_dims};
+	if (io.x_oneblob_bins) {
+		CHECK_THROW(io.x_f32.data != nullptr && io.x_oneblob_bins >= 32 && (io.x_oneblob_bins & (io.x_oneblob_bins - 1)) == 0);
+		while ((1u << a.oneblob_log2) < io.x_oneblob_bins) ++a.oneblob_log2;
+	}
+	if (a.oneblob_log2) {
+		if (d.width == 64) return launch_fwd_oneblob<64, nb_for_width(64)>(stream, d, a, mlp_grid(n, nb_for_width(64)));
+		if (d.width == 128) return launch_fwd_oneblob<128, nb_for_width(128)>(stream, d, a, mlp_grid(n, nb_for_width(128)));
+		throw std::runtime_error{"mlp_forward_io: the fused OneBlob input needs a 64- or 128-wide network"};
+	}
 	// wide inference: fragment image in LDS, 4 column blocks per wave, persistent workgroups of 8 waves (see k_mlp_fwd)
 	const uint32_t image_bytes = d.n_frags_fwd * 1024;
 	const char* lds_env = getenv("TCNN_AMD_MLP_FWD_LDS"); // "0": the L2-resident form (A/B runs; read per call so that tests cover both)

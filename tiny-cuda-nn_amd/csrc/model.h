@@ -250,6 +250,8 @@ public:
 	virtual uint32_t level_plane_features(bool need_dL_dx, GradientMode mode) const { return 0; }
 	// true: the encoding is half(x * scale + offset) padded with ones -- cheap enough to apply inside the consumer's load
 	virtual bool as_identity(float& scale, float& offset) const { return false; }
+	// n_bins if this is a half-precision OneBlob encoding the MLP kernels can evaluate inside their input load (MlpIo::x_oneblob_bins), else 0
+	virtual uint32_t as_oneblob() const { return 0; }
 	// true: backward() (with level planes allowed) prefers 16-byte records {coordinates, gradients} per (level, sample)
 	virtual bool scatter_records_usable(MatView x) const { return false; }
 	virtual uint32_t scatter_record_planes() const { return 0; } // 16-byte records per sample when scatter_records_usable()
@@ -647,6 +649,10 @@ public:
 	}
 	uint32_t input_width() const override { return m_n_dims; }
 	uint32_t output_width() const override { return m_n_dims * m_n_bins; }
+	uint32_t as_oneblob() const override { // TCNN_AMD_FUSE_ONEBLOB=0: always the encoding's own kernel (A/B runs, tests)
+		const char* e = getenv("TCNN_AMD_FUSE_ONEBLOB");
+		return (!m_fp32 && m_n_bins >= 32 && !(e && e[0] == '0')) ? m_n_bins : 0;
+	}
 	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
 		if (out && padded_output_width() > 0) oneblob_forward(stream, m_fp32, n, m_n_dims, m_n_bins, x, out, padded_output_width());
 		return {};
@@ -1336,6 +1342,10 @@ public:
 			io.x_f32_dims = m_encoding->input_width();
 			io.x_scale = scale;
 			io.x_offset = offset;
+		} else if (m_encoding->as_oneblob() && m_encoding->padded_output_width() == m_network->input_width() && (m_network->desc().width == 64 || m_network->desc().width == 128)) {
+			io.x_f32 = input;
+			io.x_f32_dims = m_encoding->input_width();
+			io.x_oneblob_bins = m_encoding->as_oneblob();
 		} else {
 			network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
 			io.x_half = network_input.data();

@@ -193,7 +193,8 @@ void mlp_prepare_weights(hipStream_t stream, const MlpDesc& d, const void* param
 void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, void* out, void* hidden);
 // The same kernel with its input / output conversions fused in (inference path):
 //   input : x_half AoS [n][in_width], or level planes [in_width / F][n][F] (x_plane_features = F), or -- x_f32.data != nullptr --
-//           the float matrix itself with the Identity encoding applied on the fly ((half)(x * scale + offset), padding = 1);
+//           the float matrix itself with the Identity encoding applied on the fly ((half)(x * scale + offset), padding = 1), or
+//           with the OneBlob encoding applied on the fly (x_oneblob_bins);
 //   output: out_half [n][out_width] and / or out_f32: the first out_f32_dims outputs as floats (trim_and_cast, object.cu:61-67).
 struct MlpIo {
 	const void* x_half;
@@ -201,6 +202,7 @@ struct MlpIo {
 	MatView x_f32;
 	uint32_t x_f32_dims;
 	float x_scale, x_offset;
+	uint32_t x_oneblob_bins; // > 0 (a power of two >= 32): x_f32 holds coordinates and the network's input is their OneBlob encoding, evaluated in the kernel
 	void* out_half;
 	MatViewMut out_f32;
 	uint32_t out_f32_dims;
