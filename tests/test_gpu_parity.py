@@ -466,6 +466,31 @@ def test_oneblob_inside_the_mlp_kernel_is_bit_identical(tcnn, oracle, monkeypatc
     assert rel_err(fused.cpu().numpy(), ref.inference(x)) < 1e-2
 
 
+def test_oneblob_inside_the_training_kernel_is_bit_identical(tcnn, oracle, monkeypatch):
+    """training_step() of C2 (OneBlob 64 bins -> 64 x 2 FullyFusedMLP): the fused MLP kernel evaluates the encoding itself instead of
+    reading an encoded batch -- same features, same arithmetic after them: outputs, loss matrices, gradients and the parameters
+    after three optimizer steps are bit-identical to the run with the encoding's own kernel (TCNN_AMD_FUSE_ONEBLOB=0)."""
+    n = 8192
+    batches = [oracle.synthetic_batch(n, 2, 3, seed=30 + i) for i in range(3)]
+    batches[0][0][:4, 0] = np.float32([0.0, 1.0, -0.5, 1.5])  # the ends of the unit interval and inputs outside it
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, CONFIG_C2, seed=1337)
+        for x, t in batches:
+            ctx = tr.training_step(_t(x), _t(t))
+        res = (_bits(ctx.output()), ctx.L().cpu().numpy().view(np.uint32), _bits(ctx.dL_doutput()), _bits(tr.param_gradients()), _bits(tr.params()))
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
+
+    fused, plain = run({}), run({"TCNN_AMD_FUSE_ONEBLOB": "0"})
+    for a, b in zip(fused, plain):
+        assert np.array_equal(a, b)
+    assert np.any(fused[3] != 0)
+
+
 def test_batch_size_granularity_error(tcnn):
     """object.h:130: batch sizes must be multiples of 256 -> error, surfaced as RuntimeError like pybind11 does."""
     import torch

@@ -20,6 +20,7 @@
 //   At the end every workgroup writes one fp32 slab of partial weight gradients; k_wgrad_reduce sums the slabs in a fixed
 //   order (bitwise reproducible, no atomics) and rounds to fp16.
 #include "mlp_device.h"
+#include "oneblob_device.h"
 
 namespace tcnn_amd {
 namespace {
@@ -52,6 +53,8 @@ struct TrainArgs {
 	const float* rec_x;     // dL_dx as 16-byte scatter records (mlp_device.h store_dx_record): the samples' coordinates, AoS [n][rec_dims]
 	uint32_t rec_dims;
 	uint32_t x_plane_f;     // 0: x is AoS [n][in_width]; F: x is level planes [in_width / F][n][F] (k_grid_planes.hip)
+	MatView ob_x;           // OB kernels: the coordinates whose OneBlob encoding is the network's input (x is not read)
+	uint32_t ob_dims, ob_log2;
 	unsigned long long* dbg; // development aid (TCNN_AMD_MLP_TIMING): shader clocks per phase, summed over workgroup 0 / wave 0's trips
 };
 
@@ -70,7 +73,8 @@ struct TrainArgs {
 // REGW ("weights in registers"): a 64-wide network with two hidden layers, <= 32 inputs and 16 outputs has 14 forward and
 // 16 backward weight fragments -- 120 VGPRs per lane.  Held in registers for the whole kernel, every MFMA of a trip takes its
 // A operand from a register instead of waiting on a 1 KB LDS (or L2) fetch, and the fragment images need no LDS space.
-template <int W, int NB, int NW, int MAXT, int ACT, bool PW = false, bool REGW = false>
+// OB: the input is the OneBlob encoding of a.ob_x, evaluated in the layer-0 loop (see k_mlp_fwd in k_mlp.hip for the scheme)
+template <int W, int NB, int NW, int MAXT, int ACT, bool PW = false, bool REGW = false, bool OB = false>
 __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const TrainArgs a) {
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
@@ -215,9 +219,58 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 		{
 			const uint32_t ks0 = d.layers[0].ks_fwd;
 			const h8* img = img_f + (size_t)d.layers[0].fwd_off * 64;
+			uint32_t ob_first[OB ? NB : 1];
+			float ob_win[OB ? NB : 1][5], ob_xv[OB ? NB : 1];
 			for (uint32_t s = 0; s < ks0; ++s) {
 				h8 bf[NB];
 				const uint32_t k0 = 32 * s + 8 * q;
+				if constexpr (OB) { // n_bins >= 32: the four quarters of a k-step are four 8-bin chunks of one dimension's row
+					const uint32_t n_bins = 1u << a.ob_log2;
+					const uint32_t dim = (32 * s) >> a.ob_log2; // wave-uniform
+					if (dim < a.ob_dims && ((32 * s) & (n_bins - 1)) == 0) { // first k-step of this dimension: the five bins around x, shared by the sample's four lanes
+#pragma unroll
+						for (int b = 0; b < NB; ++b) {
+							const float xv = a.ob_x.data[(size_t)(s0 + 16 * b + c) * a.ob_x.stride_sample + (size_t)dim * a.ob_x.stride_dim];
+							ob_xv[b] = xv;
+							ob_first[b] = oneblob_window_first(xv, a.ob_log2);
+							const float m0 = oneblob_bin(xv, (ob_first[b] + q) & (n_bins - 1), a.ob_log2);
+							const float m1 = oneblob_bin(xv, (ob_first[b] + 4) & (n_bins - 1), a.ob_log2);
+#pragma unroll
+							for (int o = 0; o < 4; ++o) ob_win[b][o] = __shfl(m0, (int)(c + 16 * o), 64);
+							ob_win[b][4] = m1;
+						}
+					}
+					const uint32_t b0 = k0 & (n_bins - 1);
+#pragma unroll
+					for (int b = 0; b < NB; ++b) {
+						h8 v;
+						if (dim >= a.ob_dims) { // padding columns: ones
+							v = h8{1, 1, 1, 1, 1, 1, 1, 1};
+						} else if (oneblob_in_unit_interval(ob_xv[b])) {
+#pragma unroll
+							for (int k = 0; k < 8; ++k) v[k] = (half_t)0.0f;
+#pragma unroll
+							for (int o = 0; o < 5; ++o) {
+								const uint32_t dd = ((ob_first[b] + o) & (n_bins - 1)) - b0;
+#pragma unroll
+								for (int k = 0; k < 8; ++k) v[k] = dd == (uint32_t)k ? (half_t)ob_win[b][o] : v[k];
+							}
+						} else { // general form: the chunk's 9 edges
+							float e[9];
+#pragma unroll
+							for (int k = 0; k < 9; ++k) e[k] = oneblob_edge(ob_xv[b], b0 + k, a.ob_log2);
+							if (b0 + 8 == n_bins) e[8] += 1;
+#pragma unroll
+							for (int k = 0; k < 8; ++k) v[k] = (half_t)(e[k + 1] - e[k]);
+						}
+						if (k0 < in_w) {
+							bf[b] = v;
+							*(h8*)(lds + xs_off + (row0 + 16 * b + c) * xs_stride + k0) = v;
+						} else {
+							bf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+						}
+					}
+				} else {
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					if (k0 < in_w) {
@@ -226,6 +279,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 					} else {
 						bf[b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
 					}
+				}
 				}
 #pragma unroll
 				for (int t = 0; t < T; ++t) {
@@ -447,7 +501,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 		{ // request the next trip's input now (see `pre` above)
 			const uint32_t next = trip + gridDim.x;
 			have_pre = next < n_trips;
-			if (have_pre && 8 * q < in_w) {
+			if (!OB && have_pre && 8 * q < in_w) {
 #pragma unroll
 				for (int b = 0; b < NB; ++b) pre[b] = load_x(next * S + row0 + 16 * b + c, 8 * q);
 			}
@@ -722,6 +776,17 @@ void dispatch_train(hipStream_t stream, const MlpDesc& d, const TrainArgs& a, co
 		else go(k_mlp_train<64, 1, 8, 8, -1, false, true>);
 		return;
 	}
+	if (a.ob_log2) { // the OneBlob input is evaluated in the kernel: one shape (C2's)
+		CHECK_THROW((int)d.width == 64 && cfg.nb == 1 && cfg.nw == 8 && cfg.maxt == 8 && !cfg.pw && !cfg.regw);
+		auto go = [&](auto kernel) {
+			HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes));
+			hipLaunchKernelGGL(kernel, dim3(grid), dim3(8 * 64), cfg.lds_bytes, stream, d, a);
+			HIP_CHECK_THROW(hipGetLastError());
+		};
+		if (d.activation == (uint32_t)Activation::ReLU) go(k_mlp_train<64, 1, 8, 8, (int)Activation::ReLU, false, false, true>);
+		else go(k_mlp_train<64, 1, 8, 8, -1, false, false, true>);
+		return;
+	}
 #define TCNN_TRAIN_CASE(W_, NB_, NW_, MAXT_) \
 	if ((int)d.width == W_ && cfg.nb == NB_ && cfg.nw == NW_ && cfg.maxt == MAXT_) return launch_train<W_, NB_, NW_, MAXT_>(stream, d, a, grid, cfg.lds_bytes);
 	TCNN_TRAIN_CASE(64, 1, 8, 8)
@@ -737,6 +802,12 @@ void dispatch_train(hipStream_t stream, const MlpDesc& d, const TrainArgs& a, co
 }
 
 } // namespace
+
+bool mlp_train_fused_oneblob_supported(const MlpDesc& d, uint32_t n, uint32_t n_bins) {
+	if (n_bins < 32 || (n_bins & (n_bins - 1)) != 0 || mlp_train_regs_supported(d, n)) return false;
+	const TrainConfig cfg = pick_config(d);
+	return cfg.ok && n % cfg.s == 0 && n > 0 && d.width == 64 && cfg.nb == 1 && cfg.nw == 8 && cfg.maxt == 8 && !cfg.pw && !cfg.regw;
+}
 
 bool mlp_train_fused_supported(const MlpDesc& d, uint32_t n) {
 	if (mlp_train_regs_supported(d, n)) return true;
@@ -756,7 +827,8 @@ uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n) {
 
 void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, void* dL_dx,
-                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params) {
+                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params, const MlpOneBlobInput* oneblob) {
+	CHECK_THROW(!oneblob || mlp_train_fused_oneblob_supported(d, n, oneblob->n_bins));
 	if (mlp_train_regs_supported(d, n) && slabs != nullptr) { // without weight gradients (GradientMode::Ignore): the kernels below
 		CHECK_THROW(compact_context || external_dL_dy);
 		return mlp_train_regs(stream, d, image, n, x, x_plane_features, target, data_pdf, external_dL_dy, dims, loss, loss_scale, out, dL_dout, L, dL_dx, dx_plane_features,
@@ -766,7 +838,12 @@ void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, ui
 	const TrainConfig cfg = pick_config(d);
 	CHECK_THROW(cfg.ok && n % cfg.s == 0);
 	TrainArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)dL_dout, L, (half_t*)dL_dx, slabs, (const h8*)image,
-	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u, dx_record_x, dx_record_dims, x_plane_features, nullptr};
+	            n, dims, (uint32_t)loss, loss_scale, dx_plane_features, n_params, cfg.image_in_lds ? 1u : 0u, dx_record_x, dx_record_dims, x_plane_features, MatView{}, 0u, 0u, nullptr};
+	if (oneblob) {
+		a.ob_x = oneblob->x;
+		a.ob_dims = oneblob->n_dims;
+		while ((1u << a.ob_log2) < oneblob->n_bins) ++a.ob_log2;
+	}
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
 	static int timing_left = 5;
 	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&a.dbg, 64));

@@ -1362,6 +1362,7 @@ public:
 		NetworkContext network_ctx; // hidden activations; empty for fused contexts
 		uint32_t x_plane_f = 0;
 		bool fused = false;         // produced by fused_encode(): backward() goes through the fused MLP kernel
+		uint32_t oneblob_bins = 0;  // > 0: no encoded batch was written -- the MLP kernels evaluate the OneBlob encoding of the input themselves
 		ArenaBuf image;             // the network's fragment images, if the encoding's forward kernel built them on the way (MlpPrepJob)
 	};
 
@@ -1376,8 +1377,14 @@ public:
 		if (!prepare_input_gradients && fused_step_supported(n)) {
 			fused_encode(stream, *ctx, n, input, params, false, true);
 			MlpIo io{};
-			io.x_half = ctx->network_input.data();
-			io.x_plane_features = ctx->x_plane_f;
+			if (ctx->oneblob_bins) {
+				io.x_f32 = input;
+				io.x_f32_dims = m_encoding->input_width();
+				io.x_oneblob_bins = ctx->oneblob_bins;
+			} else {
+				io.x_half = ctx->network_input.data();
+				io.x_plane_features = ctx->x_plane_f;
+			}
 			io.out_half = output;
 			m_network->inference_io(stream, n, io, p);
 			return ctx;
@@ -1452,6 +1459,13 @@ public:
 	void fused_encode(hipStream_t stream, Ctx& ctx, uint32_t n, MatView input, const void* params, bool prepare_input_gradients, bool prepare_param_gradients, bool prep_image = false) {
 		const _Float16* p = (const _Float16*)params;
 		const uint32_t n_net = (uint32_t)m_network->n_params();
+		// a OneBlob encoding is evaluated by the MLP kernels inside their input load where they can (k_mlp.hip, k_train.hip)
+		if (!prepare_input_gradients && m_encoding->as_oneblob() && m_encoding->padded_output_width() == m_network->input_width() &&
+		    mlp_train_fused_oneblob_supported(m_network->desc(), n, m_encoding->as_oneblob())) {
+			ctx.oneblob_bins = m_encoding->as_oneblob();
+			ctx.fused = true;
+			return;
+		}
 		ctx.network_input = ArenaBuf{stream, (size_t)n * m_encoding->padded_output_width() * 2};
 		// grids hand the encoded batch over as level planes (XCD-aware forward kernel, scatter filter produced on the way)
 		ctx.x_plane_f = prepare_input_gradients ? 0 : m_encoding->forward_plane_features(n);
@@ -1495,9 +1509,11 @@ public:
 			n_slabs = mlp_train_fused_grid(d, n);
 			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
 		}
+		const MlpOneBlobInput oneblob_input{input, m_encoding->input_width(), ctx.oneblob_bins};
 		if (profile) profile->mark(stream, StepProfile::MlpKernel, false);
 		mlp_train_fused(stream, d, image.data(), n, ctx.network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L, compact_context,
-		                dL_dnetwork_input.data(), plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u, slabs.as<float>(), n_net);
+		                dL_dnetwork_input.data(), plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u, slabs.as<float>(), n_net,
+		                ctx.oneblob_bins ? &oneblob_input : nullptr);
 		if (profile) profile->mark(stream, StepProfile::MlpKernel, true);
 		// (Carrying the slab reduction on the grid scatter's launch the way k_mlp_prep rides on the forward kernel was built and
 		// measured: its workgroups each take a whole CU's LDS slot for a few microseconds, in front of the task list they delay the

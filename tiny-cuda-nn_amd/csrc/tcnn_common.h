@@ -196,6 +196,7 @@ void mlp_forward(hipStream_t stream, const MlpDesc& d, const void* image, uint32
 //           the float matrix itself with the Identity encoding applied on the fly ((half)(x * scale + offset), padding = 1), or
 //           with the OneBlob encoding applied on the fly (x_oneblob_bins);
 //   output: out_half [n][out_width] and / or out_f32: the first out_f32_dims outputs as floats (trim_and_cast, object.cu:61-67).
+struct MlpOneBlobInput { MatView x; uint32_t n_dims, n_bins; }; // coordinates [n][n_dims] (any layout), n_bins a power of two >= 32
 struct MlpIo {
 	const void* x_half;
 	uint32_t x_plane_features;
@@ -227,7 +228,10 @@ uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n); // workgroups = num
 // with two levels per record (mlp_device.h store_dx_record); needs 4 dims + 2 F <= 16.
 void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, void* dL_dx,
-                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params);
+                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params, const MlpOneBlobInput* oneblob = nullptr);
+// oneblob (optional; x is then not read): the network's input is the OneBlob encoding of these coordinates, evaluated inside the kernel
+// (mlp_train_fused_oneblob_supported says whether this network / batch has such a kernel)
+bool mlp_train_fused_oneblob_supported(const MlpDesc& d, uint32_t n, uint32_t n_bins);
 // ---- the same step for (16 | 32) -> 64 -> [64 ->] 16 networks with everything in registers (k_train_regs.hip): no LDS images, no
 // barriers, transposes on the matrix cores.  mlp_train_fused* dispatch to it when it applies (TCNN_AMD_MLP_REGS=0: never).
 // Writes dL_dout and L as compact matrices [n][dims] (96 of the 256 bytes per sample the padded ones would add to the kernel's
