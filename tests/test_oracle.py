@@ -217,6 +217,28 @@ def test_oneblob_properties(oracle):
     assert np.all(np.abs(peak - np.floor(x[:, 0] * 64)) <= 1)
 
 
+@pytest.mark.parametrize("n_bins", [8, 16, 32, 64, 128, 256])
+def test_oneblob_rows_are_zero_outside_five_bins(oracle, n_bins):
+    """What the GPU kernels that evaluate only the bins around x rely on (k_oneblob_fwd_sparse, the fused input of k_mlp_fwd /
+    k_mlp_train): for x in [0, 1] every bin outside floor(x n_bins) - 2 .. + 2 (modulo n_bins) is exactly +0 in the definition
+    form -- the quartic kernel's radius is one bin and the wrap-around images fall on the same bins -- whereas inputs outside the
+    unit interval can put a 1 into the last bin (the wrap term)."""
+    enc = oracle.create_encoding(1, {"otype": "OneBlob", "n_bins": n_bins}, alignment=0)
+    edges = np.arange(0, n_bins + 1, dtype=np.float32) / n_bins
+    x = np.concatenate([oracle.Pcg32(9).uniform_strided(4096), edges, np.nextafter(edges, np.float32(2))[:-1], np.nextafter(edges, np.float32(-1))[1:]]).astype(np.float32)
+    x = x[(x >= 0) & (x <= 1)].reshape(-1, 1)
+    bits, _ = enc.forward(x)
+    rows = bits.reshape(len(x), n_bins)
+    first = (np.floor(x[:, 0] * np.float32(n_bins)).astype(np.int64) - 2) % n_bins
+    window = (first[:, None] + np.arange(5)[None, :]) % n_bins
+    outside = np.ones_like(rows, dtype=bool)
+    np.put_along_axis(outside, window, False, axis=1)
+    assert np.all(rows[outside] == 0)  # +0.0: all sixteen bits clear
+    assert np.all((rows != 0).sum(axis=1) >= 1)
+    far, _ = enc.forward(np.float32([[5.0], [-7.5]]))
+    assert np.any(far.reshape(2, n_bins) != 0)
+
+
 def test_mlp_forward_backward_against_numpy(oracle):
     cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2, "n_input_dims": 32, "n_output_dims": 3}
     net = oracle.Mlp(cfg)
