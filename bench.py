@@ -143,7 +143,7 @@ def run_c4(args):
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-ADAM_BYTES_PER_PARAM = 36  # half grad r 2 + fp32 w/m/v r+w 24 + u32 step r+w 8 + half w write 2
+ADAM_BYTES_PER_PARAM = 32  # half grad r 2 + fp32 w/m/v r+w 24 + step count r+w 4 (kept as uint16 below 65 535 steps; SURVEY 8(d) counts 8 for uint32: 36) + half w write 2
 
 
 def cpu_baseline(name, budget_s=15.0):
@@ -314,7 +314,7 @@ def main():
         traffic, traffic_src = pmc_traffic(kernel, args.workload if not args.batch else "")
         adam_bytes = ADAM_BYTES_PER_PARAM * n_params
         adam_gbs = adam_bytes / (pieces["optimizer"] * 1e-3) / 1e9 if pieces["optimizer"] > 0 else 0.0
-        # compulsory HBM bytes of a step: Adam's 36 B per parameter, the half gradient table written and the half table read once
+        # compulsory HBM bytes of a step: Adam's ADAM_BYTES_PER_PARAM per parameter, the half gradient table written and the half table read once
         # more by the forward pass, and per sample the inputs (4 n_in), targets (4 n_out) and the half outputs (2 x 16)
         grid_params = max(n_params - 7168, 0) if args.workload in ("c3a", "c3b") else n_params
         floor_bytes = adam_bytes + 2 * grid_params + batch * (4 * n_in + 4 * n_out + 32)

@@ -637,6 +637,54 @@ def test_adam_in_the_scatter_flush_is_bit_identical(tcnn, oracle, cfg, n_in, n, 
     assert steps.max() == len(batches) and steps.min() < len(batches)  # some parameters missed updates: the skip is exercised
 
 
+def test_adam_step_counts_are_kept_narrow_and_widened_losslessly(tcnn, oracle, monkeypatch):
+    """The per-parameter update counts live as uint16 while the optimizer's own step count is below 65 535 and are widened to uint32
+    before one could overflow (AdamOptimizer::ensure_step_width): weights, moments and the counts a snapshot reports are bit-identical
+    to a run with uint32 counts from the start (TCNN_AMD_ADAM_STEPS32=1) -- right after construction, and across the widening
+    (snapshot restored at step 65 532, six more steps)."""
+    import msgpack
+
+    n = 4096
+    batches = [oracle.synthetic_batch(n, 2, 3, seed=40 + i) for i in range(6)]
+
+    def snapshot_at(tr, step):
+        state = msgpack.unpackb(tr.serialize(True), raw=False)
+        opt = state["optimizer"]
+        counts = np.frombuffer(opt["param_steps_binary"], dtype=np.uint32)
+        assert counts.max() <= opt["current_step"]
+        opt["param_steps_binary"] = (counts + np.uint32(step - opt["current_step"])).astype(np.uint32).tobytes()
+        opt["current_step"] = step
+        return msgpack.packb(state, use_bin_type=True)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, CONFIG_C3B, seed=1337)
+        for x, t in batches[:3]:
+            ctx = tr.training_step(_t(x), _t(t))
+        early = msgpack.unpackb(tr.serialize(True), raw=False)
+        tr.deserialize(snapshot_at(tr, 65532))
+        for x, t in batches:
+            ctx = tr.training_step(_t(x), _t(t))
+        late = msgpack.unpackb(tr.serialize(True), raw=False)
+        params = _bits(tr.params())
+        for k in env:
+            monkeypatch.delenv(k)
+        del ctx
+        return early, late, params
+
+    e16, l16, p16 = run({})
+    e32, l32, p32 = run({"TCNN_AMD_ADAM_STEPS32": "1"})
+    assert np.array_equal(p16, p32)
+    for a, b in ((e16, e32), (l16, l32)):
+        assert a["params_binary"] == b["params_binary"]
+        for key in ("current_step", "first_moments_binary", "second_moments_binary", "param_steps_binary"):
+            assert a["optimizer"][key] == b["optimizer"][key], key
+    assert l16["optimizer"]["current_step"] == 65538
+    counts = np.frombuffer(l16["optimizer"]["param_steps_binary"], dtype=np.uint32)
+    assert counts.max() == 65538 and counts.min() < 65538  # beyond uint16, and parameters that missed updates keep their own count
+
+
 def test_wide_inference_forms_agree(tcnn, oracle, monkeypatch):
     """BASELINE config 4 (FullyFusedMLP 128 x 4, 32 -> 16): the LDS-resident-weights form used for large batches computes the
     same per-sample MFMA sequence as the L2-resident form -- bit-identical outputs -- and both match the oracle."""

@@ -385,7 +385,8 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 		float* __restrict__ wf_p = adam.w_fp + p0;
 		float* __restrict__ m1_p = adam.m1 + p0;
 		float* __restrict__ m2_p = adam.m2 + p0;
-		uint32_t* __restrict__ st_p = adam.steps + p0;
+		uint32_t* __restrict__ st_p = (uint32_t*)adam.steps + p0; // uint16 counts (adam.steps16): addressed through st16_p
+		uint16_t* __restrict__ st16_p = (uint16_t*)adam.steps + p0;
 		half_t* __restrict__ wh_p = (half_t*)adam.w_half + p0;
 		// Parameters that missed an update carry their own step count and look their debiasing factor up (adam_device.h): one
 		// gather per parameter, and gathers are what a CU has least of (~1.7 clocks per lane).  The most recent steps of the table
@@ -422,7 +423,13 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 					wf[k] = *(const float4*)(wf_p + 4 * (size_t)q);
 					a1[k] = *(const float4*)(m1_p + 4 * (size_t)q);
 					a2[k] = *(const float4*)(m2_p + 4 * (size_t)q);
-					st[k] = *(const uint4*)(st_p + 4 * (size_t)q);
+					if (adam.steps16) {
+						typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+						const u16x4 sv = *(const u16x4*)(st16_p + 4 * (size_t)q);
+						st[k] = uint4{sv[0], sv[1], sv[2], sv[3]};
+					} else {
+						st[k] = *(const uint4*)(st_p + 4 * (size_t)q);
+					}
 					if (has_old[k]) old[k] = *(const h4*)(wh_p + 4 * (size_t)q);
 				}
 			}
@@ -439,7 +446,12 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_grid_scatter(
 				*(float4*)(wf_p + i4) = wf[k];
 				*(float4*)(m1_p + i4) = a1[k];
 				*(float4*)(m2_p + i4) = a2[k];
-				*(uint4*)(st_p + i4) = st[k];
+				if (adam.steps16) {
+					typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+					*(u16x4*)(st16_p + i4) = u16x4{(uint16_t)st[k].x, (uint16_t)st[k].y, (uint16_t)st[k].z, (uint16_t)st[k].w};
+				} else {
+					*(uint4*)(st_p + i4) = st[k];
+				}
 				// parameters that were not updated keep their half value, whatever it is: quads with a zero gradient somewhere
 				// brought their old halves along, so that the quad is stored whole
 				if (up[0] && up[1] && up[2] && up[3]) {

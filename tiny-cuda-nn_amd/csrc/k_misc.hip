@@ -328,10 +328,24 @@ __global__ void __launch_bounds__(256) k_adam_debias_table(const float beta1, co
 constexpr int ADAM_Q = 1; // quads (of 4 parameters) per thread, one block-width apart (measured: 1 -> 82 us, 2 -> 84 us, 4 -> 91 us on C3a; occupancy wins)
 
 // QUAD_UNIFORM: n_matrix is a multiple of 4, so the 4 parameters of a quad are all matrix weights or all not
-template <bool QUAD_UNIFORM>
+// STEP_T: uint32_t, or uint16_t while every count fits (AdamOptimizer widens the array before one could overflow)
+typedef uint16_t adam_u16x4 __attribute__((ext_vector_type(4)));
+template <typename STEP_T> __device__ inline uint4 adam_load_steps(const STEP_T* p) {
+	if constexpr (sizeof(STEP_T) == 2) {
+		const adam_u16x4 v = *(const adam_u16x4*)p;
+		return uint4{v[0], v[1], v[2], v[3]};
+	} else {
+		return *(const uint4*)p;
+	}
+}
+template <typename STEP_T> __device__ inline void adam_store_steps(STEP_T* p, const uint4 v) {
+	if constexpr (sizeof(STEP_T) == 2) *(adam_u16x4*)p = adam_u16x4{(uint16_t)v.x, (uint16_t)v.y, (uint16_t)v.z, (uint16_t)v.w};
+	else *(uint4*)p = v;
+}
+template <bool QUAD_UNIFORM, typename STEP_T>
 __global__ void __launch_bounds__(256) k_adam(
 	const AdamArgs a, const size_t n, const size_t n_matrix,
-	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps,
+	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, STEP_T* __restrict__ steps,
 	const float* __restrict__ debias_table
 ) {
 	const size_t base = (size_t)blockIdx.x * (256 * 4 * ADAM_Q) + threadIdx.x * 4;
@@ -363,7 +377,7 @@ __global__ void __launch_bounds__(256) k_adam(
 			wf[q] = *(const float4*)(w_fp + i4);
 			a1[q] = *(const float4*)(m1 + i4);
 			a2[q] = *(const float4*)(m2 + i4);
-			st[q] = *(const uint4*)(steps + i4);
+			st[q] = adam_load_steps(steps + i4);
 		}
 	}
 #pragma unroll
@@ -380,7 +394,7 @@ __global__ void __launch_bounds__(256) k_adam(
 			*(float4*)(w_fp + i4) = wf[q];
 			*(float4*)(m1 + i4) = a1[q];
 			*(float4*)(m2 + i4) = a2[q];
-			*(uint4*)(steps + i4) = st[q];
+			adam_store_steps(steps + i4, st[q]);
 			if (up[0] && up[1] && up[2] && up[3]) {
 				*(h4*)(w + i4) = h4{wh[0], wh[1], wh[2], wh[3]};
 			} else { // skipped parameters keep their half value, whatever it is: only the updated ones are stored
@@ -391,7 +405,9 @@ __global__ void __launch_bounds__(256) k_adam(
 			for (size_t i = i4; i < n; ++i) {
 				bool up;
 				half_t wh;
-				adam_one(a, from_table, debias, i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
+				uint32_t st1 = steps[i];
+				adam_one(a, from_table, debias, i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], st1, up);
+				steps[i] = (STEP_T)st1;
 				if (up) w[i] = wh;
 			}
 		}
@@ -400,9 +416,10 @@ __global__ void __launch_bounds__(256) k_adam(
 
 // One parameter per thread, no vector accesses: for parameter ranges that do not start on a 16-byte boundary (a Composite
 // optimizer hands its nested optimizers slices at arbitrary offsets, optimizers/composite.h:126-135)
+template <typename STEP_T>
 __global__ void __launch_bounds__(256) k_adam_scalar(
 	const AdamArgs a, const size_t n, const size_t n_matrix,
-	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, uint32_t* __restrict__ steps,
+	float* __restrict__ w_fp, half_t* __restrict__ w, const half_t* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, STEP_T* __restrict__ steps,
 	const float* __restrict__ debias_table
 ) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,7 +428,9 @@ __global__ void __launch_bounds__(256) k_adam_scalar(
 	const auto from_table = [&](const uint32_t t) { return debias_table[t]; };
 	bool up;
 	half_t wh;
-	adam_one(a, from_table, debias,  i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], steps[i], up);
+	uint32_t st1 = steps[i];
+	adam_one(a, from_table, debias,  i < n_matrix, g[i], w_fp[i], wh, m1[i], m2[i], st1, up);
+	steps[i] = (STEP_T)st1;
 	if (up) w[i] = wh;
 }
 
@@ -592,19 +611,36 @@ AdamArgs make_adam_args(const AdamHyper& h, float loss_scale, uint32_t current_s
 	return a;
 }
 
-void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
-               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps, const float* debias_table) {
-	if (n == 0) return;
-	const AdamArgs a = make_adam_args(h, loss_scale, current_step);
-	// the quad kernel reads float4 / uint4 / half4: every base pointer must allow that
+namespace {
+__global__ void __launch_bounds__(256) k_adam_widen_steps(const size_t n, const uint16_t* __restrict__ in, uint32_t* __restrict__ out) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = in[i];
+}
+template <typename STEP_T>
+void adam_launch(hipStream_t stream, const AdamArgs& a, size_t n, size_t n_matrix, float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, STEP_T* steps, const float* debias_table) {
+	// the quad kernel reads float4 / 4 step counts / half4: every base pointer must allow that
 	const auto aligned = [](const void* p, size_t bytes) { return ((uintptr_t)p & (bytes - 1)) == 0; };
-	if (!(aligned(w_fp, 16) && aligned(m1, 16) && aligned(m2, 16) && aligned(steps, 16) && aligned(w_half, 8) && aligned(g_half, 8))) {
-		hipLaunchKernelGGL(k_adam_scalar, dim3(blocks_for(n, 256)), dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
+	if (!(aligned(w_fp, 16) && aligned(m1, 16) && aligned(m2, 16) && aligned(steps, 4 * sizeof(STEP_T)) && aligned(w_half, 8) && aligned(g_half, 8))) {
+		hipLaunchKernelGGL(k_adam_scalar<STEP_T>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
 		return;
 	}
 	const dim3 grid(blocks_for((n + 3) / 4, 256 * ADAM_Q));
-	if (n_matrix % 4 == 0) hipLaunchKernelGGL(k_adam<true>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
-	else hipLaunchKernelGGL(k_adam<false>, grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
+	if (n_matrix % 4 == 0) hipLaunchKernelGGL((k_adam<true, STEP_T>), grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
+	else hipLaunchKernelGGL((k_adam<false, STEP_T>), grid, dim3(256), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (const half_t*)g_half, m1, m2, steps, debias_table);
+}
+} // namespace
+
+void adam_widen_steps(hipStream_t stream, size_t n, const void* steps16, void* steps32) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_adam_widen_steps, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, (const uint16_t*)steps16, (uint32_t*)steps32);
+}
+
+void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
+               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, void* steps, bool steps16, const float* debias_table) {
+	if (n == 0) return;
+	const AdamArgs a = make_adam_args(h, loss_scale, current_step);
+	if (steps16) adam_launch<uint16_t>(stream, a, n, n_matrix, w_fp, w_half, g_half, m1, m2, (uint16_t*)steps, debias_table);
+	else adam_launch<uint32_t>(stream, a, n, n_matrix, w_fp, w_half, g_half, m1, m2, (uint32_t*)steps, debias_table);
 }
 
 void adam_fill_debias_table(hipStream_t stream, float beta1, float beta2, uint32_t from, uint32_t to, float* table) {

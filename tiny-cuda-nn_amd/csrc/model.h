@@ -155,6 +155,15 @@ public:
 	~DeviceBuf() { if (m_ptr) (void)hipFree(m_ptr); }
 	DeviceBuf(const DeviceBuf&) = delete;
 	DeviceBuf& operator=(const DeviceBuf&) = delete;
+	DeviceBuf(DeviceBuf&& o) noexcept : m_ptr{o.m_ptr}, m_bytes{o.m_bytes} { o.m_ptr = nullptr; o.m_bytes = 0; }
+	DeviceBuf& operator=(DeviceBuf&& o) noexcept {
+		if (this != &o) {
+			if (m_ptr) (void)hipFree(m_ptr);
+			m_ptr = o.m_ptr; m_bytes = o.m_bytes;
+			o.m_ptr = nullptr; o.m_bytes = 0;
+		}
+		return *this;
+	}
 	void resize(size_t bytes) {
 		if (bytes == m_bytes) return;
 		if (m_ptr) { (void)hipFree(m_ptr); m_ptr = nullptr; }
@@ -1685,8 +1694,10 @@ public:
 		if (n_weights * sizeof(float) > m_first_moments.bytes()) {
 			m_first_moments.resize(n_weights * sizeof(float));
 			m_second_moments.resize(n_weights * sizeof(float));
-			m_param_steps.resize(n_weights * sizeof(uint32_t));
 		}
+		m_steps16 = narrow_steps_enabled();
+		m_param_steps.resize(0);
+		m_param_steps.resize(n_weights * step_bytes());
 		m_first_moments.memset(0);
 		m_second_moments.memset(0);
 		m_param_steps.memset(0);
@@ -1702,7 +1713,18 @@ public:
 		data["base_learning_rate"] = Json((float)m_h.learning_rate);
 		data["first_moments_binary"] = blob(m_first_moments, m_n_weights * sizeof(float));
 		data["second_moments_binary"] = blob(m_second_moments, m_n_weights * sizeof(float));
-		data["param_steps_binary"] = blob(m_param_steps, m_n_weights * sizeof(uint32_t));
+		if (m_steps16) { // the snapshot carries uint32 counts whatever is kept here
+			std::vector<uint16_t> narrow(m_n_weights);
+			if (m_n_weights) HIP_CHECK_THROW(hipMemcpy(narrow.data(), m_param_steps.data(), m_n_weights * sizeof(uint16_t), hipMemcpyDeviceToHost));
+			std::vector<uint8_t> wide(m_n_weights * sizeof(uint32_t));
+			for (size_t i = 0; i < m_n_weights; ++i) {
+				const uint32_t v = narrow[i];
+				std::memcpy(wide.data() + 4 * i, &v, 4);
+			}
+			data["param_steps_binary"] = Json::binary(std::move(wide));
+		} else {
+			data["param_steps_binary"] = blob(m_param_steps, m_n_weights * sizeof(uint32_t));
+		}
 		return data;
 	}
 	void deserialize(const Json& data, size_t n_weights) override {
@@ -1714,32 +1736,69 @@ public:
 		m_n_weights = n_weights;
 		load(m_first_moments, binary_of(data["first_moments_binary"]), sizeof(float));
 		load(m_second_moments, binary_of(data["second_moments_binary"]), sizeof(float));
+		m_current_step = (uint32_t)data["current_step"].as_double();
+		m_steps16 = narrow_steps_enabled() && m_current_step < NARROW_STEP_LIMIT;
 		if (data.contains("param_steps_binary")) {
-			load(m_param_steps, binary_of(data["param_steps_binary"]), sizeof(uint32_t));
+			const std::vector<uint8_t>& bytes = binary_of(data["param_steps_binary"]);
+			if (bytes.size() != n_weights * sizeof(uint32_t)) throw std::runtime_error{"Adam: snapshot state has the wrong size."};
+			std::vector<uint16_t> narrow(m_steps16 ? n_weights : 0);
+			for (size_t i = 0; m_steps16 && i < n_weights; ++i) {
+				uint32_t v;
+				std::memcpy(&v, bytes.data() + 4 * i, 4);
+				if (v >= NARROW_STEP_LIMIT) m_steps16 = false; // a count the narrow form cannot hold (a foreign snapshot): keep all 32 bits
+				else narrow[i] = (uint16_t)v;
+			}
+			m_param_steps.resize(0);
+			m_param_steps.resize(n_weights * step_bytes());
+			if (n_weights) HIP_CHECK_THROW(hipMemcpy(m_param_steps.data(), m_steps16 ? (const void*)narrow.data() : (const void*)bytes.data(), n_weights * step_bytes(), hipMemcpyHostToDevice));
 		} else {
-			m_param_steps.resize(n_weights * sizeof(uint32_t));
+			m_param_steps.resize(0);
+			m_param_steps.resize(n_weights * step_bytes());
 			m_param_steps.memset(0);
 		}
-		m_current_step = (uint32_t)data["current_step"].as_double();
 		m_h.learning_rate = (float)data["base_learning_rate"].as_double();
 	}
 
 	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override { // adam.h:150-188
 		++m_current_step;
 		ensure_debias_table(stream);
+		ensure_step_width(stream);
 		adam_step(stream, m_h, m_n_weights, m_n_matrix, loss_scale, m_current_step, weights_full_precision, weights, gradients,
-		          m_first_moments.as<float>(), m_second_moments.as<float>(), m_param_steps.as<uint32_t>(), m_debias.as<float>());
+		          m_first_moments.as<float>(), m_second_moments.as<float>(), m_param_steps.data(), m_steps16, m_debias.as<float>());
+	}
+
+	// The per-parameter update counts (this fork's adam.h:66-99: a parameter whose gradient is zero in a step is skipped, so it has
+	// a count of its own) are 4 of the 18 bytes per parameter a step reads and 4 of the 18 it writes.  No count exceeds the
+	// optimizer's own step count, so while that is below 2^16 - 1 the counts are kept as uint16 -- 34 -> 32 bytes moved per parameter
+	// by the HBM-bound kernel -- and widened in place of one step's time before one could overflow; snapshots carry uint32 either
+	// way.  TCNN_AMD_ADAM_STEPS32=1: uint32 from the start (A/B runs, tests).
+	static constexpr uint32_t NARROW_STEP_LIMIT = 65535;
+	static bool narrow_steps_enabled() {
+		const char* e = getenv("TCNN_AMD_ADAM_STEPS32");
+		return !(e && e[0] == '1');
+	}
+	size_t step_bytes() const { return m_steps16 ? sizeof(uint16_t) : sizeof(uint32_t); }
+	void ensure_step_width(hipStream_t stream) { // call with m_current_step = the step about to be applied
+		if (!m_steps16 || m_current_step < NARROW_STEP_LIMIT) return;
+		DeviceBuf wide;
+		wide.resize(m_n_weights * sizeof(uint32_t));
+		adam_widen_steps(stream, m_n_weights, m_param_steps.data(), wide.data());
+		HIP_CHECK_THROW(hipStreamSynchronize(stream)); // once in 65 535 steps: the narrow array is freed right after
+		m_param_steps = std::move(wide);
+		m_steps16 = false;
 	}
 
 	bool begin_split_step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, AdamInFlush& out) override {
 		++m_current_step;
 		ensure_debias_table(stream);
+		ensure_step_width(stream);
 		out.args = make_adam_args(m_h, loss_scale, m_current_step);
 		out.w_fp = weights_full_precision;
 		out.w_half = weights;
 		out.m1 = m_first_moments.as<float>();
 		out.m2 = m_second_moments.as<float>();
-		out.steps = m_param_steps.as<uint32_t>();
+		out.steps = m_param_steps.data();
+		out.steps16 = m_steps16 ? 1u : 0u;
 		out.debias_table = m_debias.as<float>();
 		return true;
 	}
@@ -1749,7 +1808,7 @@ public:
 			if (e <= b) return;
 			const size_t n_matrix = m_n_matrix > b ? std::min(m_n_matrix - b, e - b) : 0;
 			adam_step(stream, m_h, e - b, n_matrix, loss_scale, m_current_step, weights_full_precision + b, (char*)weights + 2 * b, (const char*)gradients + 2 * b,
-			          m_first_moments.as<float>() + b, m_second_moments.as<float>() + b, m_param_steps.as<uint32_t>() + b, m_debias.as<float>());
+			          m_first_moments.as<float>() + b, m_second_moments.as<float>() + b, (char*)m_param_steps.data() + b * step_bytes(), m_steps16, m_debias.as<float>());
 		};
 		for (const auto& r : done) {
 			CHECK_THROW(r.first >= begin && r.second <= m_n_weights);
@@ -1814,7 +1873,6 @@ public:
 	const AdamHyper& hyper() const { return m_h; }
 	float* first_moments() const { return m_first_moments.as<float>(); }
 	float* second_moments() const { return m_second_moments.as<float>(); }
-	uint32_t* param_steps() const { return m_param_steps.as<uint32_t>(); }
 	size_t n_matrix() const { return m_n_matrix; }
 
 private:
@@ -1824,6 +1882,7 @@ private:
 	uint32_t m_debias_filled = 0;
 	float m_debias_beta1 = -1.0f, m_debias_beta2 = -1.0f;
 	uint32_t m_current_step = 0;
+	bool m_steps16 = true; // width of m_param_steps, see ensure_step_width
 };
 
 // optimizers/sgd.h:44-150

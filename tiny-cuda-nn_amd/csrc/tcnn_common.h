@@ -283,16 +283,20 @@ struct AdamInFlush {
 	void* w_half = nullptr;
 	float* m1 = nullptr;
 	float* m2 = nullptr;
-	uint32_t* steps = nullptr;
+	void* steps = nullptr; // uint32, or uint16 if steps16
+	uint32_t steps16 = 0;
 	const float* debias_table = nullptr;
 	AdamInFlush advanced(size_t n) const { // the same arrays seen from parameter n on
 		AdamInFlush r = *this;
-		r.w_fp += n; r.w_half = (char*)w_half + 2 * n; r.m1 += n; r.m2 += n; r.steps += n;
+		r.w_fp += n; r.w_half = (char*)w_half + 2 * n; r.m1 += n; r.m2 += n; r.steps = (char*)steps + (steps16 ? 2 : 4) * n;
 		return r;
 	}
 };
+// steps: the per-parameter update counts, uint32 or -- steps16 -- uint16 (what the optimizer keeps while every count fits:
+// 4 of the 36 bytes per parameter the kernel moves are the counts' upper halves otherwise)
 void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
-               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, uint32_t* steps, const float* debias_table);
+               float* w_fp, void* w_half, const void* g_half, float* m1, float* m2, void* steps, bool steps16, const float* debias_table);
+void adam_widen_steps(hipStream_t stream, size_t n, const void* steps16, void* steps32); // uint16 -> uint32
 // debias_table[t] = sqrtf(1 - powf(beta2, t)) / (1 - powf(beta1, t)) (adam.h:97-98), evaluated on the device, for t in [from, to)
 void adam_fill_debias_table(hipStream_t stream, float beta1, float beta2, uint32_t from, uint32_t to, float* table);
 // dst[i][dst_col + j] = src[i][src_col + j] for j < width; elements of 2 or 4 bytes (Composite encoding)
