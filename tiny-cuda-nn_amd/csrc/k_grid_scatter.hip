@@ -675,25 +675,37 @@ static void tuned_splits(const GridMeta& meta, uint32_t n, const std::vector<flo
 		for (uint32_t l = 0; l < meta.n_levels; ++l) fprintf(stderr, " %.0f", level_us[l]);
 		fprintf(stderr, "\n");
 	}
-	uint32_t n_coarse_tasks = 0;
+	if (n_fine > 0) {
+		// With fine levels in the plan the long tasks have a budget: the CUs set aside for them minus one spare (one long task too
+		// many costs the fine tasks a whole round).  Inside it the splits minimise the LONGEST task: start from one task per chunk
+		// and keep splitting the level whose tasks are longest while the budget allows.  (Rounding level time / target time per
+		// level, as before, sat on a knife-edge: 1.5 % of measurement noise turned 299 / 65.7 -> 5 splits into 302 / 67.3 -> 4,
+		// i.e. 75 us tasks in a 70 us kernel, in every third run.)
+		const uint32_t budget = coarse_cus > 1 ? coarse_cus - 1 : 1;
+		uint32_t n_coarse_tasks = 0;
+		for (uint32_t l = 0; l < meta.n_levels; ++l) {
+			splits[l] = 1;
+			if (!is_fine(l) && !meta.levels[l].scatter_binned) n_coarse_tasks += meta.levels[l].scatter_n_chunks;
+		}
+		while (true) {
+			uint32_t longest = meta.n_levels;
+			double t_longest = 0;
+			for (uint32_t l = 0; l < meta.n_levels; ++l) {
+				if (is_fine(l) || meta.levels[l].scatter_binned) continue;
+				const double t = level_us[l] / (meta.levels[l].scatter_n_chunks * splits[l]);
+				if (t > t_longest) { t_longest = t; longest = l; }
+			}
+			// stop when the longest tasks cannot be cut further (budget, sample granularity) or are short enough not to matter
+			if (longest == meta.n_levels || splits[longest] >= max_splits || n_coarse_tasks + meta.levels[longest].scatter_n_chunks > budget || t_longest <= 0.25 * task_us) break;
+			++splits[longest];
+			n_coarse_tasks += meta.levels[longest].scatter_n_chunks;
+		}
+		return;
+	}
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
 		if (is_fine(l) || meta.levels[l].scatter_binned) { splits[l] = 1; continue; }
 		const double per_chunk_us = level_us[l] / meta.levels[l].scatter_n_chunks;
 		splits[l] = std::min(max_splits, std::max(1u, (uint32_t)(per_chunk_us / task_us + 0.5)));
-		n_coarse_tasks += splits[l] * meta.levels[l].scatter_n_chunks;
-	}
-	// never more long tasks than CUs set aside for them (minus one spare): one too many costs the fine tasks a whole round
-	while (n_fine > 0 && n_coarse_tasks + 1 > coarse_cus) {
-		uint32_t victim = meta.n_levels;
-		double shortest = 1e30;
-		for (uint32_t l = 0; l < meta.n_levels; ++l) {
-			if (is_fine(l) || splits[l] <= 1) continue;
-			const double t = level_us[l] / (meta.levels[l].scatter_n_chunks * splits[l]);
-			if (t < shortest) { shortest = t; victim = l; }
-		}
-		if (victim == meta.n_levels) break;
-		--splits[victim];
-		n_coarse_tasks -= meta.levels[victim].scatter_n_chunks;
 	}
 }
 
