@@ -601,11 +601,16 @@ void mlp_forward_io(hipStream_t stream, const MlpDesc& d, const void* image, uin
 		CHECK_THROW(io.x_f32.data != nullptr && io.x_oneblob_bins >= 32 && (io.x_oneblob_bins & (io.x_oneblob_bins - 1)) == 0);
 		while ((1u << a.oneblob_log2) < io.x_oneblob_bins) ++a.oneblob_log2;
 	}
+	// Small batches: with 4 column blocks per wave a batch of 2^14 rows is 256 waves -- 64 workgroups on 256 CUs, each wave walking its
+	// 64 rows through the whole network alone.  One block per wave spreads the same rows over four times as many waves.
+	const bool small = n / 64 < 4 * 256; // fewer than one workgroup of 4-block waves per CU
 	if (a.oneblob_log2) {
+		if (d.width == 64 && small) return launch_fwd_oneblob<64, 1>(stream, d, a, mlp_grid(n, 1));
 		if (d.width == 64) return launch_fwd_oneblob<64, nb_for_width(64)>(stream, d, a, mlp_grid(n, nb_for_width(64)));
 		if (d.width == 128) return launch_fwd_oneblob<128, nb_for_width(128)>(stream, d, a, mlp_grid(n, nb_for_width(128)));
 		throw std::runtime_error{"mlp_forward_io: the fused OneBlob input needs a 64- or 128-wide network"};
 	}
+	if (d.width == 64 && small && hidden == nullptr) return launch_fwd_act<64, 1>(stream, d, a, mlp_grid(n, 1));
 	// wide inference: fragment image in LDS, 4 column blocks per wave, persistent workgroups of 8 waves (see k_mlp_fwd)
 	const uint32_t image_bytes = d.n_frags_fwd * 1024;
 	const char* lds_env = getenv("TCNN_AMD_MLP_FWD_LDS"); // "0": the L2-resident form (A/B runs; read per call so that tests cover both)
