@@ -959,6 +959,111 @@ class Ema:
         return self.weights_ema
 
 
+class Average:
+    """optimizers/average.h:44-174: mean of the weights after each of the last n_samples steps (kept in half, updated in float)"""
+
+    def __init__(self, cfg):
+        self.nested = create_optimizer(_ci(cfg, "nested", {}))
+        self.n_samples = int(_ci(cfg, "n_samples", 128))
+
+    def allocate(self, n, layer_sizes):
+        self.nested.allocate(n, layer_sizes)
+        self.samples = np.zeros((self.n_samples, n), dtype=np.uint16)
+        self.average = np.zeros(n, dtype=np.uint16)
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        self.nested.step(loss_scale, w_fp, w_half, g_half)
+        cur = self.samples[self.step_count() % self.n_samples]  # average.h:118-124: the slot of the step just taken
+        # :56-58: (T)((float)avg + ((float)w - (float)cur) / n_samples), one float operation after the other
+        delta = (half_to_f32(w_half) - half_to_f32(cur)).astype(np.float32) / np.float32(self.n_samples)
+        self.average[:] = half_bits((half_to_f32(self.average) + delta.astype(np.float32)).astype(np.float32))
+        cur[:] = w_half
+
+    def learning_rate(self):
+        return self.nested.learning_rate()
+
+    def set_learning_rate(self, v):
+        self.nested.set_learning_rate(v)
+
+    def step_count(self):
+        return self.nested.step_count()
+
+    def custom_weights(self):
+        return self.average
+
+
+class Batched:
+    """optimizers/batched.h:44-162: the nested optimizer steps once per batch_size_multiplier calls on the mean gradient"""
+
+    def __init__(self, cfg):
+        self.nested = create_optimizer(_ci(cfg, "nested", {}))
+        self.multiplier = int(_ci(cfg, "batch_size_multiplier", 16))
+        self.current_step = 0
+
+    def allocate(self, n, layer_sizes):
+        self.nested.allocate(n, layer_sizes)
+        self.pool = np.zeros(n, dtype=np.float32)
+        self.pool_half = np.zeros(n, dtype=np.uint16)
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        if self.current_step % self.multiplier == 0:  # :56-58
+            self.pool[:] = 0
+        self.pool += half_to_f32(g_half) / np.float32(self.multiplier)  # :60
+        self.current_step += 1
+        if self.current_step % self.multiplier == 0:
+            self.pool_half[:] = half_bits(self.pool)
+            self.nested.step(loss_scale, w_fp, w_half, self.pool_half)
+
+    def learning_rate(self):
+        return self.nested.learning_rate()
+
+    def set_learning_rate(self, v):
+        self.nested.set_learning_rate(v)
+
+    def step_count(self):
+        return self.current_step
+
+    def custom_weights(self):
+        return self.nested.custom_weights()
+
+
+class Lookahead:
+    """optimizers/lookahead.h:44-168: slow weights <- slow (1 - alpha) + fast alpha every n_steps steps, fast weights restart there"""
+
+    def __init__(self, cfg):
+        self.nested = create_optimizer(_ci(cfg, "nested", {}))
+        self.alpha = np.float32(_ci(cfg, "alpha", 0.5))
+        self.n_steps = int(_ci(cfg, "n_steps", 16))
+
+    def allocate(self, n, layer_sizes):
+        self.nested.allocate(n, layer_sizes)
+        self.lookahead = np.zeros(n, dtype=np.uint16)
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        s = self.nested.step_count()
+        if s == 0:  # :81-83
+            self.lookahead[:] = w_half
+        if s % self.n_steps == 0:  # :85-93, lookahead_step :55-58
+            new = (half_to_f32(self.lookahead) * (np.float32(1.0) - self.alpha)).astype(np.float32) + (w_fp * self.alpha).astype(np.float32)
+            new = new.astype(np.float32)
+            w_fp[:] = new
+            self.lookahead[:] = half_bits(new)
+            w_half[:] = self.lookahead
+        self.nested.step(loss_scale, w_fp, w_half, g_half)
+
+    def learning_rate(self):
+        return self.nested.learning_rate()
+
+    def set_learning_rate(self, v):
+        self.nested.set_learning_rate(v)
+
+    def step_count(self):
+        return self.nested.step_count()
+
+    def custom_weights(self):
+        return self.lookahead
+
+
 def slice_layer_sizes(layer_sizes, offset):
     """optimizers/composite.h:44-74 (slice_weights) as it is meant: the layers that start at or after `offset`; a cut inside a
     layer is an error.  (The reference's loop advances the layer index BEFORE adding that layer's size, so it skips layer 0
@@ -1031,6 +1136,12 @@ def create_optimizer(cfg):
         return Ema(cfg)
     if name == "composite":
         return CompositeOptimizer(cfg)
+    if name == "average":
+        return Average(cfg)
+    if name == "batched":
+        return Batched(cfg)
+    if name == "lookahead":
+        return Lookahead(cfg)
     raise RuntimeError(f"Invalid optimizer type: {cfg.get('otype')}")
 
 

@@ -32,6 +32,7 @@ def test_oracle_optimizer_factory_and_schedule(oracle):
     assert np.all(np.abs(ema - oracle.half_to_f32(w_h)) < 0.1) and not np.array_equal(opt.weights_ema, w_h)
     with pytest.raises(RuntimeError, match="Invalid optimizer type"):
         oracle.create_optimizer({"otype": "Shampoo"})
+    assert type(oracle.create_optimizer({"otype": "Lookahead", "nested": {"otype": "Average", "nested": {"otype": "Batched"}}}).nested.nested).__name__ == "Batched"
 
 
 def _drive(tcnn, oracle, opt_cfg, steps=4):
@@ -183,6 +184,92 @@ def test_composite_optimizer_matches_oracle(tcnn, oracle):
     assert b.optimizer_step_count() == 4 and torch.equal(b.params_inference(), tr.params_inference())
     with pytest.raises(RuntimeError, match="Can't slice within a layer"):
         tcnn.Trainer(2, 3, {**CONFIG_C3B, "optimizer": _composite(n_net - 8, n - n_net + 8)})
+
+
+SGD = {"otype": "SGD", "learning_rate": 1e-2, "l2_reg": 1e-4}
+
+
+def test_oracle_wrapping_optimizers(oracle):
+    """Average / Batched / Lookahead (optimizers/{average,batched,lookahead}.h) on a 4-weight toy problem: closed-form checks of
+    the restatement itself."""
+    n, g1 = 4, None
+    w0 = np.float32([1.0, -2.0, 0.5, 0.25])
+    g1 = oracle.half_bits(np.full(n, 128.0, dtype=np.float32))  # gradient 1 after unscaling
+    plain = {"otype": "SGD", "learning_rate": 0.125, "l2_reg": 0.0}
+    # Batched: no nested step for k - 1 calls, then one step on the mean gradient
+    opt = oracle.create_optimizer({"otype": "Batched", "batch_size_multiplier": 4, "nested": plain})
+    opt.allocate(n, [(2, 2)])
+    w_fp, w_h = w0.copy(), oracle.half_bits(w0)
+    for i in range(4):
+        opt.step(128.0, w_fp, w_h, oracle.half_bits(np.full(n, 128.0 * (i + 1), dtype=np.float32)))
+        assert np.array_equal(w_fp, w0) == (i < 3)
+    assert np.allclose(w_fp, w0 - 0.125 * 2.5) and opt.step_count() == 4 and opt.nested.step_count() == 1
+    # Average: mean over the window of the weights after each step (zeros before the window fills)
+    opt = oracle.create_optimizer({"otype": "Average", "n_samples": 2, "nested": plain})
+    opt.allocate(n, [(2, 2)])
+    w_fp, w_h = w0.copy(), oracle.half_bits(w0)
+    seen = []
+    for i in range(3):
+        opt.step(128.0, w_fp, w_h, g1)
+        seen.append(oracle.half_to_f32(w_h).copy())
+    assert np.allclose(oracle.half_to_f32(opt.custom_weights()), (seen[1] + seen[2]) / 2, atol=2e-3)
+    # Lookahead: at steps 0, k, 2k the fast weights are pulled back onto the slow ones
+    opt = oracle.create_optimizer({"otype": "Lookahead", "alpha": 0.5, "n_steps": 2, "nested": plain})
+    opt.allocate(n, [(2, 2)])
+    w_fp, w_h = w0.copy(), oracle.half_bits(w0)
+    for i in range(3):
+        opt.step(128.0, w_fp, w_h, g1)
+    # steps 0, 1: w0 - 0.25; sync at step 2: slow = (w0 + w0 - 0.25) / 2 = w0 - 0.125, then one more step
+    assert np.allclose(w_fp, w0 - 0.125 - 0.125, atol=1e-6)
+    assert np.allclose(oracle.half_to_f32(opt.custom_weights()), w0 - 0.125, atol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt_cfg,steps", [
+    ({"otype": "Average", "n_samples": 3, "nested": SGD}, 5),
+    ({"otype": "Batched", "batch_size_multiplier": 3, "nested": SGD}, 7),
+    ({"otype": "Lookahead", "alpha": 0.25, "n_steps": 2, "nested": SGD}, 5),
+    ({"otype": "Average", "n_samples": 2, "nested": {"otype": "Lookahead", "alpha": 0.5, "n_steps": 3, "nested": {"otype": "Batched", "batch_size_multiplier": 2, "nested": SGD}}}, 8),
+])
+def test_wrapping_optimizers_match_oracle_bitwise(tcnn, oracle, opt_cfg, steps):
+    """With SGD inside (bit-exact against the oracle) the wrappers' own arithmetic is compared bit for bit: master weights, half
+    weights, inference weights (the average / the slow weights), step counts; and the snapshot round trip continues identically."""
+    from test_gpu_parity import _bits
+
+    ref, tr, _ = _drive(tcnn, oracle, opt_cfg, steps=steps)
+    assert np.array_equal(tr.params_full_precision().cpu().numpy().view(np.uint32), ref.params_fp.view(np.uint32))
+    assert np.array_equal(_bits(tr.params()), ref.params)
+    custom = ref.optimizer.custom_weights()
+    assert np.array_equal(_bits(tr.params_inference()), ref.params if custom is None else custom)
+    assert tr.optimizer_step_count() == ref.optimizer.step_count()
+    assert tr.hyperparams()["optimizer"]["otype"] == opt_cfg["otype"]
+    # snapshot -> fresh trainer.  A snapshot carries the INFERENCE weights as its parameters (trainer.h:281), so after a restore the
+    # training weights are the average / the slow weights; the optimizer state (window, pool, slow weights, counts) comes back as it was
+    from tinycudann import _C
+    from test_gpu_parity import CONFIG_C3B, _t
+
+    other = tcnn.Trainer(2, 3, {**CONFIG_C3B, "optimizer": opt_cfg}, seed=5)
+    other.deserialize(tr.serialize(serialize_optimizer=True))
+    assert np.array_equal(_bits(other.params_inference()), _bits(tr.params_inference()))
+    assert other.optimizer_step_count() == tr.optimizer_step_count()
+    # the restore is complete and deterministic: two trainers restored from the same bytes take the same next steps, and those
+    # stay close to the original's (whose fp32 master weights hold more bits than the half parameters a snapshot carries)
+    from test_gpu_parity import _f32
+
+    snap = tr.serialize(serialize_optimizer=True)
+    twin = tcnn.Trainer(2, 3, {**CONFIG_C3B, "optimizer": opt_cfg}, seed=6)
+    twin.deserialize(snap)
+    n = ref.model.n_params
+    for step in range(3):
+        g_h = oracle.half_bits(oracle.Pcg32(77 + step).uniform_strided(n, -4.0, 4.0))
+        gt = _t(g_h.view(np.float16))
+        for t in (tr, other, twin):
+            _C.memcpy_dtod(_C.lib.tcnn_trainer_param_gradients(t._h), gt.data_ptr(), n * 2)
+            t.optimizer_step()
+    assert np.array_equal(_bits(other.params()), _bits(twin.params())) and np.array_equal(_bits(other.params_inference()), _bits(twin.params_inference()))
+    assert other.optimizer_step_count() == tr.optimizer_step_count()
+    if custom is None:
+        assert np.max(np.abs(_f32(_bits(other.params())) - _f32(_bits(tr.params())))) <= 2e-3
 
 
 @pytest.mark.gpu

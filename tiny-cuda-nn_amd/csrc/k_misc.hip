@@ -672,6 +672,32 @@ __global__ void __launch_bounds__(256) k_ema(const size_t n, const float decay, 
 	if (tmp) tmp[i] = filtered;
 	weights_ema[i] = (half_t)filtered;
 }
+// optimizers/average.h:44-60: running mean of the last n_samples weight vectors; `current` is the slot the new weights replace
+__global__ void __launch_bounds__(256) k_average_step(const size_t n, const uint32_t n_samples, const half_t* __restrict__ weights, half_t* __restrict__ current, half_t* __restrict__ average) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const half_t weight = weights[i];
+	average[i] = (half_t)((float)average[i] + ((float)weight - (float)current[i]) / (float)n_samples);
+	current[i] = weight;
+}
+// optimizers/batched.h:44-61: pool (+)= gradient / batch_size_multiplier, restarted with the first gradient of a group
+__global__ void __launch_bounds__(256) k_batched_accumulate(const size_t n, const int first, const uint32_t multiplier, const half_t* __restrict__ gradients, float* __restrict__ pool) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float v = first ? 0.0f : pool[i];
+	v += (float)gradients[i] / (float)multiplier;
+	pool[i] = v;
+}
+// optimizers/lookahead.h:44-59: slow weights <- slow * (1 - alpha) + fast * alpha, and the fast weights restart from them
+__global__ void __launch_bounds__(256) k_lookahead_step(const size_t n, const float alpha, float* __restrict__ weights_fp, half_t* __restrict__ weights, half_t* __restrict__ lookahead) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float new_weight = (float)lookahead[i] * (1.0f - alpha) + weights_fp[i] * alpha;
+	weights_fp[i] = new_weight;
+	const half_t h = (half_t)new_weight;
+	lookahead[i] = h;
+	weights[i] = h;
+}
 } // namespace
 
 namespace {
@@ -698,6 +724,19 @@ void copy_columns(hipStream_t stream, size_t elem_bytes, uint32_t n, const void*
 void sgd_step(hipStream_t stream, size_t n, float loss_scale, float learning_rate, float l2_reg, float* weights_full_precision, void* weights, const void* gradients) {
 	if (n == 0) return;
 	hipLaunchKernelGGL(k_sgd, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, loss_scale, learning_rate, l2_reg, weights_full_precision, (half_t*)weights, (const half_t*)gradients);
+}
+
+void average_step(hipStream_t stream, size_t n, uint32_t n_samples, const void* weights, void* current_sample, void* average) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_average_step, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, n_samples, (const half_t*)weights, (half_t*)current_sample, (half_t*)average);
+}
+void batched_accumulate(hipStream_t stream, size_t n, bool first, uint32_t multiplier, const void* gradients, float* pool) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_batched_accumulate, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, first ? 1 : 0, multiplier, (const half_t*)gradients, pool);
+}
+void lookahead_step(hipStream_t stream, size_t n, float alpha, float* weights_full_precision, void* weights, void* weights_lookahead) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_lookahead_step, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, alpha, weights_full_precision, (half_t*)weights, (half_t*)weights_lookahead);
 }
 
 void ema_step(hipStream_t stream, size_t n, float decay, float debias_old, float debias_new, const void* weights, void* weights_ema, float* tmp) {

@@ -2057,6 +2057,206 @@ private:
 	DeviceBuf m_weights_ema, m_tmp;
 };
 
+// optimizers/average.h:62-174: the mean of the weights after each of the last n_samples steps, as inference weights
+class AverageOptimizer : public Optimizer {
+public:
+	explicit AverageOptimizer(const Json& params) {
+		m_nested = create_optimizer(params.value("nested", Json::object()));
+		update_hyperparams(params);
+	}
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) override { // :69-80
+		m_n_weights = n_weights;
+		m_layer_sizes = layer_sizes;
+		m_allocated = true;
+		m_nested->allocate(n_weights, layer_sizes);
+		m_weights_samples.resize(0);
+		m_weights_samples.resize(n_weights * m_n_samples * 2);
+		m_weights_samples.memset(0);
+		m_weights_average.resize(0);
+		m_weights_average.resize(n_weights * 2);
+		m_weights_average.memset(0);
+	}
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override { // :82-92
+		m_nested->step(stream, loss_scale, weights_full_precision, weights, gradients);
+		char* current = (char*)m_weights_samples.data() + (size_t)(step_count() % m_n_samples) * m_n_weights * 2; // the slot of the step just taken
+		average_step(stream, m_n_weights, m_n_samples, weights, current, m_weights_average.data());
+	}
+	float learning_rate() const override { return m_nested->learning_rate(); }
+	void set_learning_rate(float val) override { m_nested->set_learning_rate(val); }
+	uint32_t step_count() const override { return m_nested->step_count(); }
+	size_t n_weights() const override { return m_nested->n_weights(); }
+	void* custom_weights() const override { return m_weights_average.data(); }
+	void update_hyperparams(const Json& p) override { // :131-142: a new window length starts the window over
+		if (!p.is_object()) return;
+		if (p.contains("n_samples")) {
+			m_n_samples = (uint32_t)p["n_samples"].as_double();
+			if (m_n_samples == 0) throw std::runtime_error{"AverageOptimizer: n_samples must be positive"};
+			if (m_allocated) allocate(m_n_weights, m_layer_sizes);
+		}
+		if (p.contains("nested")) m_nested->update_hyperparams(p["nested"]);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "Average";
+		j["nested"] = m_nested->hyperparams();
+		j["n_samples"] = m_n_samples;
+		return j;
+	}
+	Json serialize() const override {
+		Json data = Json::object();
+		data["nested"] = m_nested->serialize();
+		data["weights_samples_binary"] = device_to_binary(m_weights_samples.data(), m_n_weights * m_n_samples * 2);
+		data["weights_average_binary"] = device_to_binary(m_weights_average.data(), m_n_weights * 2);
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights) override {
+		const std::vector<uint8_t> samples = binary_of(data["weights_samples_binary"]), average = binary_of(data["weights_average_binary"]);
+		if (average.size() != n_weights * 2 || samples.size() != n_weights * 2 * m_n_samples) throw std::runtime_error{"Average: snapshot state has the wrong size."};
+		m_n_weights = n_weights;
+		m_weights_samples.resize(samples.size());
+		m_weights_average.resize(average.size());
+		if (!samples.empty()) HIP_CHECK_THROW(hipMemcpy(m_weights_samples.data(), samples.data(), samples.size(), hipMemcpyHostToDevice));
+		if (!average.empty()) HIP_CHECK_THROW(hipMemcpy(m_weights_average.data(), average.data(), average.size(), hipMemcpyHostToDevice));
+		m_nested->deserialize(data["nested"], n_weights);
+	}
+private:
+	uint32_t m_n_samples = 128;
+	size_t m_n_weights = 0;
+	bool m_allocated = false;
+	std::vector<std::pair<uint32_t, uint32_t>> m_layer_sizes;
+	std::unique_ptr<Optimizer> m_nested;
+	DeviceBuf m_weights_samples, m_weights_average;
+};
+
+// optimizers/batched.h:63-162: the nested optimizer steps once per batch_size_multiplier calls, on the mean of their gradients
+class BatchedOptimizer : public Optimizer {
+public:
+	explicit BatchedOptimizer(const Json& params) {
+		m_nested = create_optimizer(params.value("nested", Json::object()));
+		update_hyperparams(params);
+	}
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) override {
+		m_nested->allocate(n_weights, layer_sizes);
+		m_averaged_gradients.resize(n_weights * sizeof(float));
+		m_averaged_gradients_half.resize(n_weights * 2);
+		m_averaged_gradients.memset(0);
+		m_averaged_gradients_half.memset(0);
+	}
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override { // :77-89
+		batched_accumulate(stream, n_weights(), m_current_step % m_batch_size_multiplier == 0, m_batch_size_multiplier, gradients, m_averaged_gradients.as<float>());
+		++m_current_step;
+		if (m_current_step % m_batch_size_multiplier == 0) {
+			cast_float_to_half(stream, n_weights(), m_averaged_gradients.as<float>(), m_averaged_gradients_half.data());
+			m_nested->step(stream, loss_scale, weights_full_precision, weights, m_averaged_gradients_half.data());
+		}
+	}
+	float learning_rate() const override { return m_nested->learning_rate(); }
+	void set_learning_rate(float val) override { m_nested->set_learning_rate(val); }
+	uint32_t step_count() const override { return m_current_step; }
+	size_t n_weights() const override { return m_nested->n_weights(); }
+	void* custom_weights() const override { return m_nested->custom_weights(); }
+	void weights_restored(hipStream_t stream, const void* weights) override { m_nested->weights_restored(stream, weights); }
+	void update_hyperparams(const Json& p) override {
+		if (!p.is_object()) return;
+		if (p.contains("batch_size_multiplier")) {
+			m_batch_size_multiplier = (uint32_t)p["batch_size_multiplier"].as_double();
+			if (m_batch_size_multiplier == 0) throw std::runtime_error{"BatchedOptimizer: batch_size_multiplier must be positive"};
+		}
+		if (p.contains("nested")) m_nested->update_hyperparams(p["nested"]);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "Batched";
+		j["nested"] = m_nested->hyperparams();
+		j["batch_size_multiplier"] = m_batch_size_multiplier;
+		return j;
+	}
+	Json serialize() const override {
+		Json data = Json::object();
+		data["nested"] = m_nested->serialize();
+		data["averaged_gradients_binary"] = device_to_binary(m_averaged_gradients.data(), n_weights() * sizeof(float));
+		data["averaged_gradients_half_binary"] = device_to_binary(m_averaged_gradients_half.data(), n_weights() * 2);
+		data["current_step"] = Json((uint32_t)m_current_step);
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights) override {
+		const std::vector<uint8_t> pool = binary_of(data["averaged_gradients_binary"]), half = binary_of(data["averaged_gradients_half_binary"]);
+		if (pool.size() != n_weights * sizeof(float) || half.size() != n_weights * 2) throw std::runtime_error{"Batched: snapshot state has the wrong size."};
+		m_current_step = (uint32_t)data["current_step"].as_double();
+		m_averaged_gradients.resize(pool.size());
+		m_averaged_gradients_half.resize(half.size());
+		if (!pool.empty()) HIP_CHECK_THROW(hipMemcpy(m_averaged_gradients.data(), pool.data(), pool.size(), hipMemcpyHostToDevice));
+		if (!half.empty()) HIP_CHECK_THROW(hipMemcpy(m_averaged_gradients_half.data(), half.data(), half.size(), hipMemcpyHostToDevice));
+		m_nested->deserialize(data["nested"], n_weights);
+	}
+private:
+	uint32_t m_batch_size_multiplier = 16, m_current_step = 0;
+	std::unique_ptr<Optimizer> m_nested;
+	DeviceBuf m_averaged_gradients, m_averaged_gradients_half;
+};
+
+// optimizers/lookahead.h:61-168: every n_steps steps the slow weights move a fraction alpha towards the fast ones, which restart
+// from them; the slow weights are the inference weights
+class LookaheadOptimizer : public Optimizer {
+public:
+	explicit LookaheadOptimizer(const Json& params) {
+		m_nested = create_optimizer(params.value("nested", Json::object()));
+		update_hyperparams(params);
+	}
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) override {
+		m_nested->allocate(n_weights, layer_sizes);
+		if (n_weights * 2 <= m_weights_lookahead.bytes()) return;
+		m_weights_lookahead.resize(n_weights * 2);
+		m_weights_lookahead.memset(0);
+	}
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override { // :78-98
+		const uint32_t current_step = m_nested->step_count();
+		if (current_step == 0) HIP_CHECK_THROW(hipMemcpyAsync(m_weights_lookahead.data(), weights, n_weights() * 2, hipMemcpyDeviceToDevice, stream));
+		if (current_step % m_n_steps == 0) lookahead_step(stream, n_weights(), m_alpha, weights_full_precision, weights, m_weights_lookahead.data());
+		m_nested->step(stream, loss_scale, weights_full_precision, weights, gradients);
+	}
+	float learning_rate() const override { return m_nested->learning_rate(); }
+	void set_learning_rate(float val) override { m_nested->set_learning_rate(val); }
+	uint32_t step_count() const override { return m_nested->step_count(); }
+	size_t n_weights() const override { return m_nested->n_weights(); }
+	void* custom_weights() const override { return m_weights_lookahead.data(); }
+	void update_hyperparams(const Json& p) override {
+		if (!p.is_object()) return;
+		if (p.contains("alpha")) m_alpha = (float)p["alpha"].as_double();
+		if (p.contains("n_steps")) {
+			m_n_steps = (uint32_t)p["n_steps"].as_double();
+			if (m_n_steps == 0) throw std::runtime_error{"LookaheadOptimizer: n_steps must be positive"};
+		}
+		if (p.contains("nested")) m_nested->update_hyperparams(p["nested"]);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "Lookahead";
+		j["nested"] = m_nested->hyperparams();
+		j["alpha"] = m_alpha;
+		j["n_steps"] = m_n_steps;
+		return j;
+	}
+	Json serialize() const override {
+		Json data = Json::object();
+		data["nested"] = m_nested->serialize();
+		data["weights_lookahead_binary"] = device_to_binary(m_weights_lookahead.data(), n_weights() * 2);
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights) override {
+		const std::vector<uint8_t> bytes = binary_of(data["weights_lookahead_binary"]);
+		if (bytes.size() != n_weights * 2) throw std::runtime_error{"Lookahead: snapshot state has the wrong size."};
+		m_weights_lookahead.resize(bytes.size());
+		if (!bytes.empty()) HIP_CHECK_THROW(hipMemcpy(m_weights_lookahead.data(), bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+		m_nested->deserialize(data["nested"], n_weights);
+	}
+private:
+	float m_alpha = 0.5f;
+	uint32_t m_n_steps = 16;
+	std::unique_ptr<Optimizer> m_nested;
+	DeviceBuf m_weights_lookahead;
+};
+
 // optimizers/composite.h:44-74 (slice_weights) as it is meant: the layers that start at or after `offset`; a cut inside a layer
 // is an error.  (The reference's loop advances the layer index before adding that layer's size: it skips layer 0 and runs one
 // past the end of the list for any offset > 0 -- undefined behaviour there, the intended slice here.)
@@ -2179,7 +2379,10 @@ inline std::unique_ptr<Optimizer> create_optimizer(const Json& params) {
 	if (equals_case_insensitive(otype, "ExponentialDecay")) return std::unique_ptr<Optimizer>{new ExponentialDecayOptimizer{params}};
 	if (equals_case_insensitive(otype, "Ema")) return std::unique_ptr<Optimizer>{new EmaOptimizer{params}};
 	if (equals_case_insensitive(otype, "Composite")) return std::unique_ptr<Optimizer>{new CompositeOptimizer{params}};
-	throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam, SGD, ExponentialDecay, Ema, Composite)"};
+	if (equals_case_insensitive(otype, "Average")) return std::unique_ptr<Optimizer>{new AverageOptimizer{params}};
+	if (equals_case_insensitive(otype, "Batched")) return std::unique_ptr<Optimizer>{new BatchedOptimizer{params}};
+	if (equals_case_insensitive(otype, "Lookahead")) return std::unique_ptr<Optimizer>{new LookaheadOptimizer{params}};
+	throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam, SGD, ExponentialDecay, Ema, Composite, Average, Batched, Lookahead)"};
 }
 
 // ------------------------------------------------------------------------------------------------------------------

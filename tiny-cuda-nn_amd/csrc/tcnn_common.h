@@ -304,6 +304,10 @@ void copy_columns(hipStream_t stream, size_t elem_bytes, uint32_t n, const void*
 // optimizers/sgd.h:44-72 and optimizers/ema.h:44-78 (half parameters)
 void sgd_step(hipStream_t stream, size_t n, float loss_scale, float learning_rate, float l2_reg, float* weights_full_precision, void* weights, const void* gradients);
 void ema_step(hipStream_t stream, size_t n, float decay, float debias_old, float debias_new, const void* weights, void* weights_ema, float* tmp);
+// optimizers/average.h:44-60, batched.h:44-61, lookahead.h:44-59 (half parameters)
+void average_step(hipStream_t stream, size_t n, uint32_t n_samples, const void* weights, void* current_sample, void* average);
+void batched_accumulate(hipStream_t stream, size_t n, bool first, uint32_t multiplier, const void* gradients, float* pool);
+void lookahead_step(hipStream_t stream, size_t n, float alpha, float* weights_full_precision, void* weights, void* weights_lookahead);
 
 // random.h:40-70: strided uniform fill from a pcg32 state; advances (state, inc) on the host copy by n
 void generate_random_uniform(hipStream_t stream, uint64_t* state_inc_host, size_t n, float* out, float lower, float upper);
