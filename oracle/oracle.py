@@ -959,6 +959,58 @@ class Ema:
         return self.weights_ema
 
 
+class Novograd:
+    """optimizers/novograd.h:44-261: one second moment per layer (from the sum of the layer's squared gradients); only the weight
+    matrices are walked (:132-166), parameters behind them are not touched"""
+
+    def __init__(self, cfg):
+        self.lr = np.float32(_ci(cfg, "learning_rate", 1e-3))
+        self.beta1 = np.float32(_ci(cfg, "beta1", 0.9))
+        self.beta2 = np.float32(_ci(cfg, "beta2", 0.999))
+        self.epsilon = np.float32(_ci(cfg, "epsilon", 1e-8))
+        self.relative_decay = np.float32(_ci(cfg, "relative_decay", 0.0))
+        self.absolute_decay = np.float32(_ci(cfg, "absolute_decay", 0.0))
+        self.current_step = 0
+
+    def allocate(self, n, layer_sizes):
+        self.layers = [int(r) * int(c) for r, c in layer_sizes]
+        self.first = np.zeros(n, dtype=np.float32)
+        self.second = np.zeros(len(self.layers), dtype=np.float32)
+
+    def step(self, loss_scale, w_fp, w_half, g_half):
+        self.current_step += 1
+        ls = np.float32(loss_scale)
+        beta1 = np.float32(0) if self.current_step == 1 else self.beta1  # :152, :162: exact values on the first step
+        beta2 = np.float32(0) if self.current_step == 1 else self.beta2
+        one = np.float32(1)
+        off = 0
+        for i, size in enumerate(self.layers):
+            g = half_to_f32(g_half[off:off + size])
+            norm = np.float32(np.sum((g * g).astype(np.float32), dtype=np.float32))  # reduce_sum: fp32, order unspecified
+            self.second[i] = beta2 * self.second[i] + (one - beta2) * norm / ls / ls  # :85
+            grad = (g / ls).astype(np.float32)
+            first = (beta1 * self.first[off:off + size] + (one - beta1) * grad / (np.sqrt(self.second[i]).astype(np.float32) + self.epsilon)).astype(np.float32)
+            self.first[off:off + size] = first
+            w = w_fp[off:off + size]
+            decayed = ((one - self.relative_decay * self.lr) * w - np.copysign(self.absolute_decay * self.lr, w)).astype(np.float32)
+            new = (decayed - self.lr * first).astype(np.float32)
+            w_fp[off:off + size] = new
+            w_half[off:off + size] = half_bits(new)
+            off += size
+
+    def learning_rate(self):
+        return self.lr
+
+    def set_learning_rate(self, v):
+        self.lr = np.float32(v)
+
+    def step_count(self):
+        return self.current_step
+
+    def custom_weights(self):
+        return None
+
+
 class Average:
     """optimizers/average.h:44-174: mean of the weights after each of the last n_samples steps (kept in half, updated in float)"""
 
@@ -1142,6 +1194,8 @@ def create_optimizer(cfg):
         return Batched(cfg)
     if name == "lookahead":
         return Lookahead(cfg)
+    if name == "novograd":
+        return Novograd(cfg)
     raise RuntimeError(f"Invalid optimizer type: {cfg.get('otype')}")
 
 

@@ -273,6 +273,31 @@ def test_wrapping_optimizers_match_oracle_bitwise(tcnn, oracle, opt_cfg, steps):
 
 
 @pytest.mark.gpu
+def test_novograd_matches_oracle(tcnn, oracle):
+    """optimizers/novograd.h: per-layer second moments (the sum of a layer's squared gradients is an fp32 reduction whose order is
+    not specified: compared within 1e-5 of the largest update), only the weight matrices move, snapshot keys as in the reference."""
+    msgpack = pytest.importorskip("msgpack")
+    from test_gpu_parity import _bits
+
+    cfg = {"otype": "Novograd", "learning_rate": 1e-2, "beta1": 0.9, "beta2": 0.99, "epsilon": 1e-8, "relative_decay": 0.01, "absolute_decay": 1e-4}
+    ref, tr, p0 = _drive(tcnn, oracle, cfg, steps=4)
+    n_net = ref.model.network.n_params
+    got = tr.params_full_precision().cpu().numpy()
+    upd = float(np.max(np.abs(ref.params_fp[:n_net] - p0[:n_net])))
+    assert upd > 0 and float(np.max(np.abs(got[:n_net] - ref.params_fp[:n_net]))) <= 1e-5 * upd + 1e-9
+    assert np.array_equal(got[n_net:].view(np.uint32), p0[n_net:].view(np.uint32))  # the grid's entries are not walked
+    assert np.mean(_bits(tr.params())[:n_net] == ref.params[:n_net]) > 0.999
+    assert tr.optimizer_step_count() == 4 and tr.hyperparams()["optimizer"]["otype"] == "Novograd"
+    opt = msgpack.unpackb(tr.serialize(serialize_optimizer=True), raw=False)["optimizer"]
+    assert set(opt) == {"current_step", "base_learning_rate", "first_moments_binary", "per_layer_second_moments_binary"}
+    second = np.frombuffer(opt["per_layer_second_moments_binary"], dtype=np.float32)
+    assert second.shape == ref.optimizer.second.shape and np.allclose(second, ref.optimizer.second, rtol=1e-5)
+    other = tcnn.Trainer(2, 3, {**__import__("test_gpu_parity").CONFIG_C3B, "optimizer": cfg}, seed=9)
+    other.deserialize(tr.serialize(serialize_optimizer=True))
+    assert other.optimizer_step_count() == 4 and np.array_equal(_bits(other.params()), _bits(tr.params()))
+
+
+@pytest.mark.gpu
 def test_unknown_optimizer_is_reported(tcnn):
     from test_gpu_parity import CONFIG_C3B
 

@@ -688,6 +688,38 @@ __global__ void __launch_bounds__(256) k_batched_accumulate(const size_t n, cons
 	v += (float)gradients[i] / (float)multiplier;
 	pool[i] = v;
 }
+// optimizers/novograd.h:44-94.  One workgroup per layer sums the squared gradients (fixed tree: reproducible) and folds the sum
+// into the layer's second moment, moment = beta2 moment + (1 - beta2) sum / loss_scale / loss_scale; then the element-wise step.
+__global__ void __launch_bounds__(1024) k_novo_second_moment(const size_t n, const float loss_scale, const float beta2, const half_t* __restrict__ gradients, float* __restrict__ moment) {
+	__shared__ float part[1024];
+	float acc = 0.0f;
+	for (size_t i = threadIdx.x; i < n; i += 1024) {
+		const float g = (float)gradients[i];
+		acc += g * g;
+	}
+	part[threadIdx.x] = acc;
+	__syncthreads();
+	for (uint32_t stride = 512; stride > 0; stride >>= 1) {
+		if (threadIdx.x < stride) part[threadIdx.x] += part[threadIdx.x + stride];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *moment = beta2 * *moment + (1 - beta2) * part[0] / loss_scale / loss_scale;
+}
+__global__ void __launch_bounds__(256) k_novo_step(const size_t n, const float relative_weight_decay, const float absolute_weight_decay, const float loss_scale, const float learning_rate,
+                                                   const float beta1, const float epsilon, float* __restrict__ weights_fp, half_t* __restrict__ weights, const half_t* __restrict__ gradients,
+                                                   float* __restrict__ first_moments, const float* __restrict__ layer_second_moment) {
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float weight_fp = weights_fp[i];
+	const float gradient = (float)gradients[i] / loss_scale;
+	const float first_moment = beta1 * first_moments[i] + (1 - beta1) * gradient / (sqrtf(*layer_second_moment) + epsilon);
+	first_moments[i] = first_moment;
+	// weight_decay(rel * lr, abs * lr, w), common_device.h:870-873
+	const float decayed_weight = (1 - relative_weight_decay * learning_rate) * weight_fp - copysignf(absolute_weight_decay * learning_rate, weight_fp);
+	const float new_weight = decayed_weight - learning_rate * first_moment;
+	weights_fp[i] = new_weight;
+	weights[i] = (half_t)new_weight;
+}
 // optimizers/lookahead.h:44-59: slow weights <- slow * (1 - alpha) + fast * alpha, and the fast weights restart from them
 __global__ void __launch_bounds__(256) k_lookahead_step(const size_t n, const float alpha, float* __restrict__ weights_fp, half_t* __restrict__ weights, half_t* __restrict__ lookahead) {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -733,6 +765,13 @@ void average_step(hipStream_t stream, size_t n, uint32_t n_samples, const void* 
 void batched_accumulate(hipStream_t stream, size_t n, bool first, uint32_t multiplier, const void* gradients, float* pool) {
 	if (n == 0) return;
 	hipLaunchKernelGGL(k_batched_accumulate, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, first ? 1 : 0, multiplier, (const half_t*)gradients, pool);
+}
+void novograd_layer_step(hipStream_t stream, size_t n, float relative_decay, float absolute_decay, float loss_scale, float learning_rate, float beta1, float beta2, float epsilon,
+                         float* weights_full_precision, void* weights, const void* gradients, float* first_moments, float* layer_second_moment) {
+	if (n == 0) return;
+	hipLaunchKernelGGL(k_novo_second_moment, dim3(1), dim3(1024), 0, stream, n, loss_scale, beta2, (const half_t*)gradients, layer_second_moment);
+	hipLaunchKernelGGL(k_novo_step, dim3(blocks_for(n, 256)), dim3(256), 0, stream, n, relative_decay, absolute_decay, loss_scale, learning_rate, beta1, epsilon, weights_full_precision,
+	                   (half_t*)weights, (const half_t*)gradients, first_moments, layer_second_moment);
 }
 void lookahead_step(hipStream_t stream, size_t n, float alpha, float* weights_full_precision, void* weights, void* weights_lookahead) {
 	if (n == 0) return;

@@ -2057,6 +2057,83 @@ private:
 	DeviceBuf m_weights_ema, m_tmp;
 };
 
+// optimizers/novograd.h:96-261: layer-wise second moments.  Only the weight MATRICES are optimized (the layer list is all it walks,
+// :132-166): parameters behind them -- grid entries -- are left alone, as in the reference.
+class NovogradOptimizer : public Optimizer {
+public:
+	explicit NovogradOptimizer(const Json& params) { update_hyperparams(params); }
+	void allocate(size_t n_weights, const std::vector<std::pair<uint32_t, uint32_t>>& layer_sizes) override { // :103-124
+		m_n_weights = n_weights;
+		m_layers.clear();
+		for (const auto& ls : layer_sizes) m_layers.push_back((size_t)ls.first * ls.second);
+		m_first_moments.resize(0);
+		m_first_moments.resize(n_weights * sizeof(float));
+		m_first_moments.memset(0);
+		m_per_layer_second_moments.resize(0);
+		m_per_layer_second_moments.resize(m_layers.size() * sizeof(float));
+		m_per_layer_second_moments.memset(0);
+	}
+	void step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients) override { // :126-167
+		++m_current_step;
+		size_t offset = 0;
+		for (size_t i = 0; i < m_layers.size(); ++i) {
+			novograd_layer_step(stream, m_layers[i], m_relative_decay, m_absolute_decay, loss_scale, m_learning_rate, m_current_step == 1 ? 0.0f : m_beta1, // exact values on the first step
+			                    m_current_step == 1 ? 0.0f : m_beta2, m_epsilon, weights_full_precision + offset, (char*)weights + 2 * offset, (const char*)gradients + 2 * offset,
+			                    m_first_moments.as<float>() + offset, m_per_layer_second_moments.as<float>() + i);
+			offset += m_layers[i];
+		}
+	}
+	float learning_rate() const override { return m_learning_rate; }
+	void set_learning_rate(float val) override { m_learning_rate = val; }
+	uint32_t step_count() const override { return m_current_step; }
+	size_t n_weights() const override { return m_n_weights; }
+	void update_hyperparams(const Json& p) override {
+		if (!p.is_object()) return;
+		if (p.contains("beta1")) m_beta1 = (float)p["beta1"].as_double();
+		if (p.contains("beta2")) m_beta2 = (float)p["beta2"].as_double();
+		if (p.contains("epsilon")) m_epsilon = (float)p["epsilon"].as_double();
+		if (p.contains("learning_rate")) m_learning_rate = (float)p["learning_rate"].as_double();
+		if (p.contains("relative_decay")) m_relative_decay = (float)p["relative_decay"].as_double();
+		if (p.contains("absolute_decay")) m_absolute_decay = (float)p["absolute_decay"].as_double();
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "Novograd";
+		j["beta1"] = m_beta1;
+		j["beta2"] = m_beta2;
+		j["epsilon"] = m_epsilon;
+		j["learning_rate"] = m_learning_rate;
+		j["relative_decay"] = m_relative_decay;
+		j["absolute_decay"] = m_absolute_decay;
+		return j;
+	}
+	Json serialize() const override {
+		Json data = Json::object();
+		data["current_step"] = Json((uint32_t)m_current_step);
+		data["base_learning_rate"] = Json((float)m_learning_rate);
+		data["first_moments_binary"] = device_to_binary(m_first_moments.data(), m_n_weights * sizeof(float));
+		data["per_layer_second_moments_binary"] = device_to_binary(m_per_layer_second_moments.data(), m_layers.size() * sizeof(float));
+		return data;
+	}
+	void deserialize(const Json& data, size_t n_weights) override {
+		const std::vector<uint8_t> first = binary_of(data["first_moments_binary"]), second = binary_of(data["per_layer_second_moments_binary"]);
+		if (first.size() != n_weights * sizeof(float) || second.size() != m_layers.size() * sizeof(float)) throw std::runtime_error{"Novograd: snapshot state has the wrong size."};
+		m_n_weights = n_weights;
+		m_first_moments.resize(first.size());
+		m_per_layer_second_moments.resize(second.size());
+		if (!first.empty()) HIP_CHECK_THROW(hipMemcpy(m_first_moments.data(), first.data(), first.size(), hipMemcpyHostToDevice));
+		if (!second.empty()) HIP_CHECK_THROW(hipMemcpy(m_per_layer_second_moments.data(), second.data(), second.size(), hipMemcpyHostToDevice));
+		m_current_step = (uint32_t)data["current_step"].as_double();
+		m_learning_rate = (float)data["base_learning_rate"].as_double();
+	}
+private:
+	size_t m_n_weights = 0;
+	std::vector<size_t> m_layers;
+	DeviceBuf m_first_moments, m_per_layer_second_moments;
+	uint32_t m_current_step = 0;
+	float m_learning_rate = 1e-3f, m_beta1 = 0.9f, m_beta2 = 0.999f, m_epsilon = 1e-8f, m_relative_decay = 0.0f, m_absolute_decay = 0.0f;
+};
+
 // optimizers/average.h:62-174: the mean of the weights after each of the last n_samples steps, as inference weights
 class AverageOptimizer : public Optimizer {
 public:
@@ -2382,7 +2459,8 @@ inline std::unique_ptr<Optimizer> create_optimizer(const Json& params) {
 	if (equals_case_insensitive(otype, "Average")) return std::unique_ptr<Optimizer>{new AverageOptimizer{params}};
 	if (equals_case_insensitive(otype, "Batched")) return std::unique_ptr<Optimizer>{new BatchedOptimizer{params}};
 	if (equals_case_insensitive(otype, "Lookahead")) return std::unique_ptr<Optimizer>{new LookaheadOptimizer{params}};
-	throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam, SGD, ExponentialDecay, Ema, Composite, Average, Batched, Lookahead)"};
+	if (equals_case_insensitive(otype, "Novograd")) return std::unique_ptr<Optimizer>{new NovogradOptimizer{params}};
+	throw std::runtime_error{"Invalid optimizer type: " + otype + " (this build provides Adam, SGD, ExponentialDecay, Ema, Composite, Average, Batched, Lookahead, Novograd)"};
 }
 
 // ------------------------------------------------------------------------------------------------------------------

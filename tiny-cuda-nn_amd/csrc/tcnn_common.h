@@ -308,6 +308,9 @@ void ema_step(hipStream_t stream, size_t n, float decay, float debias_old, float
 void average_step(hipStream_t stream, size_t n, uint32_t n_samples, const void* weights, void* current_sample, void* average);
 void batched_accumulate(hipStream_t stream, size_t n, bool first, uint32_t multiplier, const void* gradients, float* pool);
 void lookahead_step(hipStream_t stream, size_t n, float alpha, float* weights_full_precision, void* weights, void* weights_lookahead);
+// optimizers/novograd.h:44-94 for ONE layer of n weights: the layer's second moment from the sum of its squared gradients, then the step
+void novograd_layer_step(hipStream_t stream, size_t n, float relative_decay, float absolute_decay, float loss_scale, float learning_rate, float beta1, float beta2, float epsilon,
+                         float* weights_full_precision, void* weights, const void* gradients, float* first_moments, float* layer_second_moment);
 
 // random.h:40-70: strided uniform fill from a pcg32 state; advances (state, inc) on the host copy by n
 void generate_random_uniform(hipStream_t stream, uint64_t* state_inc_host, size_t n, float* out, float lower, float upper);
