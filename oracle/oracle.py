@@ -351,6 +351,29 @@ class OneBlobEncoding:
         return {"otype": "OneBlob", "n_bins": self.n_bins}
 
 
+class EmptyEncoding:
+    """encodings/empty.h:58-150: no live outputs, padding columns of ones, zero input gradient"""
+
+    def __init__(self, n_in, cfg):
+        self.n_in = n_in
+        self.n_output_dims = 0
+        self.n_to_pad = 0
+        self.n_params = 0
+        self.required_output_alignment = 1
+
+    padded_output_width = GridEncoding.padded_output_width
+    set_alignment = GridEncoding.set_alignment
+
+    def initialize_params(self, rng, scale=1.0):
+        return np.empty(0, dtype=np.float32)
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        return np.full((x.shape[0], self.padded_output_width), half_bits(np.float32([1.0]))[0], dtype=np.uint16), {}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        return np.zeros((x.shape[0], self.n_in), dtype=np.float32) if want_dL_dx else None
+
+
 class IdentityEncoding:
     """encodings/identity.h:88-190"""
 
@@ -638,6 +661,8 @@ def create_encoding(n_in, cfg, alignment=8):
         enc = OneBlobEncoding(n_in, cfg)
     elif name == "identity":
         enc = IdentityEncoding(n_in, cfg)
+    elif name == "empty":
+        enc = EmptyEncoding(n_in, cfg)
     elif name == "frequency":
         enc = PeriodicEncoding(n_in, cfg, "frequency")
     elif name == "trianglewave":

@@ -221,3 +221,38 @@ def test_composite_reductions_match_oracle(tcnn, oracle, reduction):
             first = tr.loss(c)
     last = tr.loss(c)
     assert np.isfinite(last) and last < first
+
+
+@pytest.mark.gpu
+def test_empty_encoding_inside_a_composite(tcnn, oracle):
+    """encodings/empty.h: encodes nothing -- as the last nested encoding of a Composite it receives the row's padding (ones) and
+    returns a zero gradient for the input dims it was handed."""
+    from test_gpu_parity import _bits, _t
+
+    cfg = {"otype": "Composite", "nested": [{"n_dims_to_encode": 2, "otype": "Identity", "scale": 2.0, "offset": -0.5}, {"otype": "Empty"}]}
+    ref = oracle.create_encoding(3, cfg, alignment=16)
+    assert [type(e).__name__ for e in ref.nested] == ["IdentityEncoding", "EmptyEncoding"] and ref.padded_output_width == 16
+    n = 512
+    x = oracle.Pcg32(8).uniform_strided(n * 3).reshape(n, 3)
+    want, _ = ref.forward(x)
+    assert np.all(oracle.half_to_f32(want[:, 2:]) == 1.0)
+    # standalone (no alignment): two Identity columns, and dL/dx of the Empty dim is exactly zero
+    enc = tcnn.Encoding(3, cfg)
+    assert enc.n_output_dims == 2 and enc.native_tcnn_module.hyperparams()["nested"][1]["otype"] == "Empty"
+    xt = _t(x).requires_grad_(True)
+    y = enc(xt)
+    assert np.array_equal(_bits(y), want[:, :2])
+    y.float().sum().backward()
+    g = xt.grad.cpu().numpy()
+    assert np.all(g[:, 2] == 0) and np.all(g[:, :2] == 2.0)
+    # in front of a network: the padded row (14 ones from the Empty encoding) reaches the MLP -- one training step against the oracle
+    full = {"loss": {"otype": "L2"}, "optimizer": {"otype": "Adam", "learning_rate": 1e-2}, "encoding": cfg,
+            "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}}
+    tr = tcnn.Trainer(3, 3, full, seed=1337)
+    rt = oracle.Trainer(3, 3, full, seed=1337)
+    xb, tb = oracle.synthetic_batch(1024, 3, 3, seed=3)
+    ctx = tr.training_step(_t(xb), _t(tb))
+    rctx = rt.training_step(xb, tb)
+    a, b = ctx.output().float().cpu().numpy()[:, :3], oracle.half_to_f32(rctx["output"])[:, :3]
+    assert np.abs(a - b).max() <= 1e-2 * max(1.0, np.abs(b).max())
+    assert abs(tr.loss(ctx) - rctx["loss"]) <= 2e-2 * abs(rctx["loss"])

@@ -680,6 +680,42 @@ private:
 	uint32_t m_n_bins, m_n_dims;
 };
 
+// dL_dx = 0 for n samples of n_dims input dims, whatever the view's layout
+inline void zero_input_gradient(hipStream_t stream, uint32_t n, uint32_t n_dims, const MatViewMut& dL_dx) {
+	if (n == 0 || n_dims == 0) return;
+	const bool aos = dL_dx.stride_dim == 1 && dL_dx.stride_sample == n_dims, soa = dL_dx.stride_sample == 1 && dL_dx.stride_dim == n;
+	if (aos || soa) {
+		HIP_CHECK_THROW(hipMemsetAsync(dL_dx.data, 0, (size_t)n * n_dims * sizeof(float), stream));
+	} else { // any other view: one strided column per input dim
+		for (uint32_t d = 0; d < n_dims; ++d) {
+			HIP_CHECK_THROW(hipMemset2DAsync(dL_dx.data + (size_t)d * dL_dx.stride_dim, (size_t)dL_dx.stride_sample * sizeof(float), 0, sizeof(float), n, stream));
+		}
+	}
+}
+
+// encodings/empty.h:58-150: encodes nothing -- its output is its padding, ones (e.g. as a placeholder inside a Composite); zero
+// gradient towards its inputs.  (There output_width() reports the padded width; here it is 0 and the padding is the padding.)
+class EmptyEncoding : public Encoding {
+public:
+	EmptyEncoding(uint32_t n_dims_to_encode, bool fp32) : Encoding{fp32}, m_n_dims{n_dims_to_encode} {}
+	uint32_t input_width() const override { return m_n_dims; }
+	uint32_t output_width() const override { return 0; }
+	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
+		if (out && padded_output_width() > 0) identity_forward(stream, m_fp32, n, 0, 1.0f, 0.0f, x, out, padded_output_width()); // no live columns: all padding
+		return {};
+	}
+	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
+		if (dL_dx) zero_input_gradient(stream, n, m_n_dims, *dL_dx);
+	}
+	Json hyperparams() const override {
+		Json j = Json::object();
+		j["otype"] = "Empty";
+		return j;
+	}
+private:
+	uint32_t m_n_dims;
+};
+
 class IdentityEncoding : public Encoding {
 public:
 	IdentityEncoding(uint32_t n_dims_to_encode, float scale, float offset, bool fp32) : Encoding{fp32}, m_n_dims{n_dims_to_encode}, m_scale{scale}, m_offset{offset} {}
@@ -900,16 +936,7 @@ public:
 		CHECK_THROW(!dy_planes && ctx.nested.size() == m_nested.size());
 		const size_t elem = m_fp32 ? 4 : 2;
 		// input dims no nested encoding looks at have zero gradient
-		if (dL_dx) {
-			const bool aos = dL_dx->stride_dim == 1 && dL_dx->stride_sample == m_n_dims, soa = dL_dx->stride_sample == 1 && dL_dx->stride_dim == n;
-			if (aos || soa) {
-				HIP_CHECK_THROW(hipMemsetAsync(dL_dx->data, 0, (size_t)n * m_n_dims * sizeof(float), stream));
-			} else { // any other view: one strided column per input dim
-				for (uint32_t d = 0; d < m_n_dims; ++d) {
-					HIP_CHECK_THROW(hipMemset2DAsync(dL_dx->data + (size_t)d * dL_dx->stride_dim, (size_t)dL_dx->stride_sample * sizeof(float), 0, sizeof(float), n, stream));
-				}
-			}
-		}
+		if (dL_dx) zero_input_gradient(stream, n, m_n_dims, *dL_dx);
 		uint32_t col = 0;
 		size_t p_off = 0;
 		if (m_reduction != Reduction::Concatenation) { // composite.h:302-330: dL/d(nested outputs) from dL/d(reduced output), then the nested passes
@@ -981,6 +1008,8 @@ inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, cons
 		result.reset(new OneBlobEncoding{enc.value("n_bins", 16u), n_dims_to_encode, fp32});
 	} else if (name == "identity") {
 		result.reset(new IdentityEncoding{n_dims_to_encode, enc.value("scale", 1.0f), enc.value("offset", 0.0f), fp32});
+	} else if (name == "empty") {
+		result.reset(new EmptyEncoding{n_dims_to_encode, fp32});
 	} else if (name == "frequency") {
 		result.reset(new PeriodicEncoding{false, enc.value("n_frequencies", 12u), n_dims_to_encode, fp32});
 	} else if (name == "trianglewave") {
@@ -1009,7 +1038,7 @@ inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, cons
 		composite["nested"] = nested;
 		result.reset(new CompositeEncoding{n_dims_to_encode, composite, fp32});
 	} else {
-		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity, Frequency, TriangleWave, SphericalHarmonics, Composite)"};
+		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity, Empty, Frequency, TriangleWave, SphericalHarmonics, Composite)"};
 	}
 	if (alignment > 0) result->set_alignment(alignment);
 	return result;
