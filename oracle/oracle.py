@@ -351,6 +351,102 @@ class OneBlobEncoding:
         return {"otype": "OneBlob", "n_bins": self.n_bins}
 
 
+class Ppng1Encoding:
+    """encodings/ppng.h:30-119 + ppng_1.h:13-379 (this fork's PPNG1), restated with numpy; parameter gradients are the EXACT sums
+    of the fp16 products the reference forms (it adds them with fp16 atomics in arbitrary order), rounded to half once"""
+
+    def __init__(self, n_in, cfg):
+        if n_in != 3:
+            raise RuntimeError("PPNG1: number of input dims must be 2 or 3")
+        self.n_in = 3
+        self.log2_min = int(_ci(cfg, "log2_min_freq", 0))
+        self.log2_max = int(_ci(cfg, "log2_max_freq", 6))
+        self.Q = int(_ci(cfg, "n_quants", 64))
+        self.F = int(_ci(cfg, "n_frequencies", 6))
+        self.R = int(_ci(cfg, "rank", 4))
+        self.C = int(_ci(cfg, "n_features", 4))
+        if self.R not in (2, 4, 8, 16):
+            raise RuntimeError("PPNG1: rank must be 1, 2, 4, 8 or 16")
+        if self.C not in (2, 4, 8):
+            raise RuntimeError("PPNG1: number of features must be 1, 2, 4 or 8")
+        self.n_output_dims = self.F * 2 * self.C
+        self.n_to_pad = 0
+        self.n_params = self.F * 2 * 3 * self.C * self.Q * self.R
+        self.required_output_alignment = 1
+
+    padded_output_width = GridEncoding.padded_output_width
+    set_alignment = GridEncoding.set_alignment
+
+    def initialize_params(self, rng, scale=1.0):  # ppng_1.h:325-328
+        return rng.uniform_strided(self.n_params, -0.7 * scale, 0.7 * scale)
+
+    def _lookup(self, x):
+        """per (f, s, i): bins p0, p1 and weight w of every sample (ppng_1.h:25-35, 176-190; double literals as written there)"""
+        f = np.arange(self.F, dtype=np.float32)
+        freq_base = (f * np.float32(self.log2_max - self.log2_min)).astype(np.float32) / np.float32(self.F - 1) + np.float32(self.log2_min)
+        freq = (np.power(np.float32(2.0), freq_base.astype(np.float32)).astype(np.float32).astype(np.float64) * 3.1415926535).astype(np.float32)
+        s = np.arange(2, dtype=np.float64)
+        arg = freq.astype(np.float64)[:, None, None, None] * (x.astype(np.float64).T[None, None, :, :] - 0.5) + s[None, :, None, None] * 1.57079632679489661923
+        sc = np.sin(arg.astype(np.float32)).astype(np.float32)  # [F][2][3][n]
+        p = (((sc + np.float32(1.0)).astype(np.float32).astype(np.float64) * 0.5) * float(self.Q - 1)).astype(np.float32)
+        p0 = np.clip(np.floor(p).astype(np.int64), 0, self.Q - 1)
+        p1 = np.clip(np.ceil(p).astype(np.int64), 0, self.Q - 1)
+        w = (p - p0.astype(np.float32)).astype(np.float32)
+        return p0, p1, w
+
+    def _interp(self, feats, p0, p1, w):
+        """fa[f][s][i][c][n][r] = w f1 + (1 - w) f0 in float"""
+        F, C, Q, R = self.F, self.C, self.Q, self.R
+        n = p0.shape[-1]
+        fa = np.empty((F, 2, 3, C, n, R), dtype=np.float32)
+        for f in range(F):
+            for s in range(2):
+                for i in range(3):
+                    t = feats[f, s, i]  # [C][Q][R]
+                    f0, f1 = t[:, p0[f, s, i], :], t[:, p1[f, s, i], :]  # [C][n][R]
+                    ww = w[f, s, i][None, :, None]
+                    fa[f, s, i] = (ww * f1).astype(np.float32) + ((np.float32(1) - ww) * f0).astype(np.float32)
+        return fa
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        feats = half_to_f32(np.asarray(params_half)).reshape(self.F, 2, 3, self.C, self.Q, self.R)
+        p0, p1, w = self._lookup(x)
+        fa = self._interp(feats, p0, p1, w)
+        prod = ((np.float32(1) * fa[:, :, 0]).astype(np.float32) * fa[:, :, 1]).astype(np.float32) * fa[:, :, 2]  # f = 1; f *= fa_i in order
+        prod = prod.astype(np.float32)
+        fs = np.zeros(prod.shape[:-1], dtype=np.float32)
+        for r in range(self.R):  # fs += f, rank by rank
+            fs = (fs + prod[..., r]).astype(np.float32)
+        out = np.full((n, self.padded_output_width), half_bits(np.float32([1.0]))[0], dtype=np.uint16)
+        out[:, : self.n_output_dims] = half_bits(fs.transpose(3, 0, 1, 2).reshape(n, self.n_output_dims))
+        return out, {"p0": p0, "p1": p1, "w": w, "fa": fa}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        if grad_half is not None:
+            p0, p1, w, fa = ctx["p0"], ctx["p1"], ctx["w"], ctx["fa"]
+            go = half_to_f32(np.ascontiguousarray(dL_dy)[:, : self.n_output_dims]).reshape(n, self.F, 2, self.C).transpose(1, 2, 3, 0)  # [F][2][C][n]
+            acc = np.zeros((self.F, 2, 3, self.C, self.Q, self.R), dtype=np.float64)
+            one = np.float32(1)
+            for i in range(3):
+                others = [j for j in range(3) if j != i]
+                cache = ((one * fa[:, :, others[0]]).astype(np.float32) * fa[:, :, others[1]]).astype(np.float32)  # [F][2][C][n][R]
+                g = (go[..., None] * cache).astype(np.float32)
+                ww = w[:, :, i][:, :, None, :, None]
+                v0 = half_to_f32(half_bits((g * (one - ww)).astype(np.float32))).astype(np.float64)
+                v1 = half_to_f32(half_bits((g * ww).astype(np.float32))).astype(np.float64)
+                for f in range(self.F):
+                    for s in range(2):
+                        for c in range(self.C):
+                            np.add.at(acc[f, s, i, c], p0[f, s, i], v0[f, s, c])
+                            np.add.at(acc[f, s, i, c], p1[f, s, i], v1[f, s, c])
+            grad_half[:] = acc.reshape(-1).astype(np.float16).view(np.uint16)  # exact sums (float64 holds them exactly), rounded to half ONCE
+        return np.zeros((n, 3), dtype=np.float32) if want_dL_dx else None
+
+
 class EmptyEncoding:
     """encodings/empty.h:58-150: no live outputs, padding columns of ones, zero input gradient"""
 
@@ -663,6 +759,8 @@ def create_encoding(n_in, cfg, alignment=8):
         enc = IdentityEncoding(n_in, cfg)
     elif name == "empty":
         enc = EmptyEncoding(n_in, cfg)
+    elif name == "ppng1":
+        enc = Ppng1Encoding(n_in, cfg)
     elif name == "frequency":
         enc = PeriodicEncoding(n_in, cfg, "frequency")
     elif name == "trianglewave":

@@ -173,3 +173,92 @@ def test_network_with_spherical_harmonics_trains(tcnn, oracle):
         xs, ts = oracle.synthetic_batch(1024, 3, 3, seed=100 + s)
         ctx = tr.training_step(torch.from_numpy(xs).cuda(), torch.from_numpy(ts).cuda())
     assert tr.loss(ctx) < 0.7 * first
+
+
+PPNG1 = {"otype": "PPNG1", "n_frequencies": 4, "log2_min_freq": 0, "log2_max_freq": 3, "n_quants": 16, "rank": 2, "n_features": 2}
+
+
+def test_ppng1_oracle_layout_and_gradient(oracle):
+    """encodings/ppng_1.h restated (oracle.Ppng1Encoding): sizes, output layout [f][sin|cos][c], and the parameter gradient against a
+    finite difference of the restatement's own forward pass."""
+    enc = oracle.create_encoding(3, PPNG1, alignment=0)
+    assert enc.n_params == 4 * 2 * 3 * 2 * 16 * 2 and enc.padded_output_width == 4 * 2 * 2
+    rs = np.random.RandomState(0)
+    n = 64
+    x = rs.uniform(0, 1, (n, 3)).astype(np.float32)
+    params = rs.uniform(-0.7, 0.7, enc.n_params).astype(np.float32)
+    ph = oracle.half_bits(params)
+    out, ctx = enc.forward(x, ph)
+    y = oracle.half_to_f32(out)
+    assert y.shape == (n, 16) and np.all(np.isfinite(y)) and np.abs(y).max() < 2 * 0.7 ** 3 + 1e-3
+    dy = rs.uniform(-1, 1, (n, 16)).astype(np.float32)
+    g = np.zeros(enc.n_params, dtype=np.uint16)
+    enc.backward(x, ctx, oracle.half_bits(dy), grad_half=g)
+    g = oracle.half_to_f32(g)
+    touched = np.flatnonzero(g)
+    assert 0 < touched.size < enc.n_params  # 64 samples do not reach every bin
+    for idx in touched[:: max(1, touched.size // 12)]:  # d<dy, y>/dparam by central differences (half parameters: steps of 2^-6)
+        hi, lo = oracle.half_to_f32(ph).copy(), oracle.half_to_f32(ph).copy()
+        hi[idx] += 2.0 ** -6
+        lo[idx] -= 2.0 ** -6
+        yh = oracle.half_to_f32(enc.forward(x, oracle.half_bits(hi))[0]).astype(np.float64)
+        yl = oracle.half_to_f32(enc.forward(x, oracle.half_bits(lo))[0]).astype(np.float64)
+        fd = float(np.sum((yh - yl) * oracle.half_to_f32(oracle.half_bits(dy)))) / 2.0 ** -5
+        assert abs(fd - g[idx]) <= 5e-2 * max(1.0, abs(fd)), (idx, fd, g[idx])
+    with pytest.raises(RuntimeError, match="rank must be"):
+        oracle.create_encoding(3, {**PPNG1, "rank": 3}, alignment=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [PPNG1, {"otype": "PPNG1"}, {"otype": "PPNG1", "n_quants": 256, "rank": 16, "n_features": 8, "n_frequencies": 3}])
+def test_ppng1_matches_oracle(tcnn, oracle, cfg):
+    """GPU (k_ppng.hip) against the restatement: outputs within 2e-3 (device sinf / powf against numpy's), parameter gradients --
+    exact sums of the same fp16 products on both sides -- within 2e-3 of their norm; zero input gradient; deterministic.  The third
+    case is the largest table slice (does not fit the LDS: global integer atomics)."""
+    from test_gpu_parity import _bits, _f32, _t
+
+    n = 2048
+    ref = oracle.create_encoding(3, cfg, alignment=0)
+    enc = tcnn.Encoding(3, cfg)
+    native = enc.native_tcnn_module
+    assert enc.n_output_dims == ref.padded_output_width and native.n_params() == ref.n_params
+    assert native.hyperparams()["otype"] == "PPNG1" and native.hyperparams()["rank"] == ref.R
+    x = oracle.Pcg32(42).uniform_strided(n * 3).reshape(n, 3)
+    params = oracle.half_bits(oracle.Pcg32(7).uniform_strided(ref.n_params, -0.7, 0.7))
+    want, ctx = ref.forward(x, params)
+    xt = _t(x).requires_grad_(True)
+    pt = _t(params.view(np.float16)).requires_grad_(True)
+    nctx, out = native.fwd(xt, pt)
+    a, b = _f32(_bits(out)), _f32(want)
+    assert np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(b).max())
+    dy = oracle.half_bits(oracle.Pcg32(5).uniform_strided(n * ref.padded_output_width, -1.0, 1.0).reshape(n, ref.padded_output_width))
+    g_ref = np.zeros(ref.n_params, dtype=np.uint16)
+    ref.backward(x, ctx, dy, grad_half=g_ref)
+    dx, g1 = native.bwd(nctx, xt, pt, out, _t(dy.view(np.float16)))
+    _, g2 = native.bwd(nctx, xt, pt, out, _t(dy.view(np.float16)))
+    assert np.array_equal(_bits(g1), _bits(g2))  # exact integer sums: the same bits every time
+    ga, gb = _f32(_bits(g1)), _f32(g_ref)
+    assert np.linalg.norm(ga - gb) <= 2e-3 * np.linalg.norm(gb) and np.linalg.norm(gb) > 0
+    assert np.all(dx.cpu().numpy() == 0)
+
+
+@pytest.mark.gpu
+def test_network_with_ppng1_trains(tcnn, oracle):
+    """PPNG1 in front of a FullyFusedMLP through the trainer: parameters initialised in +-0.7 (ppng_1.h:325-328), the loss falls."""
+    from test_gpu_parity import _t
+
+    cfg = {"loss": {"otype": "L2"}, "optimizer": {"otype": "Adam", "learning_rate": 1e-2}, "encoding": {"otype": "PPNG1"},
+           "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}}
+    tr = tcnn.Trainer(3, 3, cfg, seed=1337)
+    ref = oracle.Trainer(3, 3, cfg, seed=1337)
+    n_net = ref.model.network.n_params
+    assert tr.n_params == ref.model.n_params
+    p = tr.params_full_precision().cpu().numpy()
+    assert np.array_equal(p.view(np.uint32), ref.params_fp.view(np.uint32)) and np.abs(p[n_net:]).max() <= 0.7 and np.abs(p[n_net:]).max() > 0.6
+    x, _ = oracle.synthetic_batch(4096, 3, 3, seed=2)
+    t = np.stack([np.sin(7 * x[:, 0]) * x[:, 1], x[:, 2] ** 2, np.cos(5 * x[:, 1] + x[:, 0])], axis=1).astype(np.float32)
+    losses = []
+    for _ in range(60):
+        ctx = tr.training_step(_t(x), _t(t))
+        losses.append(tr.loss(ctx))
+    assert np.isfinite(losses).all() and losses[-1] < 0.2 * losses[0]

@@ -136,6 +136,13 @@ ParamRanges grid_scatter_adam_ranges(const GridMeta& meta, const std::vector<Gri
 bool grid_scatter_records_supported(const GridMeta& meta);
 uint32_t grid_scatter_record_planes(const GridMeta& meta);
 
+// ---- PPNG1 (k_ppng.hip; encodings/ppng_1.h): features half [F][2][3][C][Q][R]; out / dL_dy AoS with row stride out_stride;
+// scratch: uint64[n_params], zero on entry, zero again on return (exact integer sums of the fp16 products, rounded once)
+void ppng1_forward(hipStream_t stream, bool fp32_out, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, uint32_t R, int32_t log2_min_freq, int32_t log2_max_freq, MatView x,
+                   const void* features, void* out, uint32_t out_stride);
+void ppng1_backward(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, uint32_t R, int32_t log2_min_freq, int32_t log2_max_freq, MatView x,
+                    const void* features, const void* dL_dy, uint32_t dy_stride, uint64_t* scratch, void* grad, bool accumulate);
+
 // ---- binned form for levels cut into more than 64 chunks (k_grid_bin.hip; GridLevel::scatter_binned): no filter, no gathers.
 // Same exact result as grid_backward_lds; writes every gradient element of the binned levels.  workspace: grid_bin_workspace_bytes().
 bool grid_bin_supported(const GridMeta& meta); // F in {2, 4}
