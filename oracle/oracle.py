@@ -447,6 +447,94 @@ class Ppng1Encoding:
         return np.zeros((n, 3), dtype=np.float32) if want_dL_dx else None
 
 
+class Ppng2Encoding(Ppng1Encoding):
+    """encodings/ppng_2.h:12-506 (this fork's PPNG2): per (frequency, phase) three planes of Q x Q bins per (feature, rank) -- X
+    plane indexed (z, y), Y plane (z, x), Z plane (y, x) -- output = sum_r sum_corners w_corner fx fy fz with the planes' nearest
+    entries; the parameter gradient is THREE times the exact sum of the fp16 products (the reference's loop over the dimensions
+    repeats the same additions three times, ppng_2.h:131-270)"""
+
+    def __init__(self, n_in, cfg):
+        try:
+            super().__init__(n_in, cfg)
+        except RuntimeError as e:
+            raise RuntimeError(str(e).replace("PPNG1", "PPNG2"))
+        self.n_params = self.F * 2 * 3 * self.C * self.Q * self.Q * self.R
+
+    AXES = ((2, 1), (2, 0), (1, 0))  # plane -> (row axis, column axis)
+
+    def _corner_setup(self, x):
+        p0, p1, w = self._lookup(x)  # [F][2][3][n]
+        pb = np.stack([p0, p1], axis=-1)  # [...][bit]
+        one = np.float32(1)
+        w8 = []
+        for k in range(8):  # ppng_2.h:33-40: (x factor * y factor) * z factor
+            a = w[:, :, 0] if k & 1 else (one - w[:, :, 0])
+            b = w[:, :, 1] if k & 2 else (one - w[:, :, 1])
+            c = w[:, :, 2] if k & 4 else (one - w[:, :, 2])
+            w8.append(((a * b).astype(np.float32) * c).astype(np.float32))
+        return pb, np.stack(w8, axis=0)  # w8: [8][F][2][n]
+
+    def _entries(self, pb, f, s, pl, k):
+        hi, lo = self.AXES[pl]
+        return pb[f, s, hi, :, (k >> hi) & 1], pb[f, s, lo, :, (k >> lo) & 1]
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        feats = half_to_f32(np.asarray(params_half)).reshape(self.F, 2, 3, self.C, self.Q, self.Q, self.R)
+        pb, w8 = self._corner_setup(x)
+        fs = np.zeros((n, self.F, 2, self.C), dtype=np.float32)
+        for f in range(self.F):
+            for s in range(2):
+                total = np.zeros((self.C, n), dtype=np.float32)
+                for r in range(self.R):
+                    acc = None
+                    for k in range(8):
+                        v = None
+                        for pl in range(3):
+                            hi, lo = self._entries(pb, f, s, pl, k)
+                            e = feats[f, s, pl][:, hi, lo, r]  # [C][n]
+                            v = e if v is None else (v * e).astype(np.float32)
+                        term = (w8[k, f, s][None, :] * v).astype(np.float32)
+                        acc = term if acc is None else (acc + term).astype(np.float32)
+                    total = (total + acc).astype(np.float32)
+                fs[:, f, s, :] = total.T
+        out = np.full((n, self.padded_output_width), half_bits(np.float32([1.0]))[0], dtype=np.uint16)
+        out[:, : self.n_output_dims] = half_bits(fs.reshape(n, self.n_output_dims))
+        return out, {"pb": pb, "w8": w8, "feats": feats}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        if grad_half is not None:
+            pb, w8, feats = ctx["pb"], ctx["w8"], ctx["feats"]
+            go = half_to_f32(np.ascontiguousarray(dL_dy)[:, : self.n_output_dims]).reshape(n, self.F, 2, self.C)
+            acc = np.zeros((self.F, 2, 3, self.C, self.Q, self.Q, self.R), dtype=np.float64)
+            for f in range(self.F):
+                for s in range(2):
+                    g0 = go[:, f, s, :].T  # [C][n]
+                    for pl in range(3):
+                        hi_ax, lo_ax = self.AXES[pl]
+                        o1, o2 = [q for q in range(3) if q != pl]
+                        for q in range(4):
+                            k0 = (((q >> 1) & 1) << hi_ax) | ((q & 1) << lo_ax)
+                            k1 = k0 | (1 << pl)
+                            hi, lo = self._entries(pb, f, s, pl, k0)
+                            for r in range(self.R):
+                                terms = []
+                                for k in (k0, k1):
+                                    a_hi, a_lo = self._entries(pb, f, s, o1, k)
+                                    b_hi, b_lo = self._entries(pb, f, s, o2, k)
+                                    t = (w8[k, f, s][None, :] * feats[f, s, o1][:, a_hi, a_lo, r]).astype(np.float32)
+                                    terms.append((t * feats[f, s, o2][:, b_hi, b_lo, r]).astype(np.float32))
+                                g = (g0 * (terms[0] + terms[1]).astype(np.float32)).astype(np.float32)
+                                v = half_to_f32(half_bits(g)).astype(np.float64) * 3.0
+                                for c in range(self.C):
+                                    np.add.at(acc[f, s, pl, c, :, :, r], (hi, lo), v[c])
+            grad_half[:] = acc.reshape(-1).astype(np.float16).view(np.uint16)
+        return np.zeros((n, 3), dtype=np.float32) if want_dL_dx else None
+
+
 class EmptyEncoding:
     """encodings/empty.h:58-150: no live outputs, padding columns of ones, zero input gradient"""
 
@@ -761,6 +849,8 @@ def create_encoding(n_in, cfg, alignment=8):
         enc = EmptyEncoding(n_in, cfg)
     elif name == "ppng1":
         enc = Ppng1Encoding(n_in, cfg)
+    elif name == "ppng2":
+        enc = Ppng2Encoding(n_in, cfg)
     elif name == "frequency":
         enc = PeriodicEncoding(n_in, cfg, "frequency")
     elif name == "trianglewave":

@@ -262,3 +262,63 @@ def test_network_with_ppng1_trains(tcnn, oracle):
         ctx = tr.training_step(_t(x), _t(t))
         losses.append(tr.loss(ctx))
     assert np.isfinite(losses).all() and losses[-1] < 0.2 * losses[0]
+
+
+PPNG2 = {"otype": "PPNG2", "n_frequencies": 3, "log2_min_freq": 0, "log2_max_freq": 2, "n_quants": 8, "rank": 2, "n_features": 2}
+
+
+def test_ppng2_oracle_layout_and_gradient(oracle):
+    """encodings/ppng_2.h restated (oracle.Ppng2Encoding): sizes, and the parameter gradient = THREE times the finite difference of
+    the restatement's own forward pass (the reference repeats its additions once per dimension)."""
+    enc = oracle.create_encoding(3, PPNG2, alignment=0)
+    assert enc.n_params == 3 * 2 * 3 * 2 * 8 * 8 * 2 and enc.padded_output_width == 3 * 2 * 2
+    rs = np.random.RandomState(0)
+    n = 96
+    x = rs.uniform(0, 1, (n, 3)).astype(np.float32)
+    ph = oracle.half_bits(rs.uniform(-0.7, 0.7, enc.n_params).astype(np.float32))
+    out, ctx = enc.forward(x, ph)
+    assert np.all(np.isfinite(oracle.half_to_f32(out)))
+    dy = oracle.half_bits(rs.uniform(-1, 1, (n, 12)).astype(np.float32))
+    g = np.zeros(enc.n_params, dtype=np.uint16)
+    enc.backward(x, ctx, dy, grad_half=g)
+    g = oracle.half_to_f32(g)
+    touched = np.flatnonzero(g)
+    assert 0 < touched.size < enc.n_params
+    for idx in touched[:: max(1, touched.size // 10)]:
+        hi, lo = oracle.half_to_f32(ph).copy(), oracle.half_to_f32(ph).copy()
+        hi[idx] += 2.0 ** -6
+        lo[idx] -= 2.0 ** -6
+        yh = oracle.half_to_f32(enc.forward(x, oracle.half_bits(hi))[0]).astype(np.float64)
+        yl = oracle.half_to_f32(enc.forward(x, oracle.half_bits(lo))[0]).astype(np.float64)
+        fd = 3.0 * float(np.sum((yh - yl) * oracle.half_to_f32(dy))) / 2.0 ** -5
+        assert abs(fd - g[idx]) <= 6e-2 * max(1.0, abs(fd)), (idx, fd, g[idx])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [PPNG2, {"otype": "PPNG2", "n_quants": 32, "n_frequencies": 3}, {"otype": "PPNG2", "n_quants": 64, "rank": 8, "n_features": 2, "n_frequencies": 2}])
+def test_ppng2_matches_oracle(tcnn, oracle, cfg):
+    """GPU (k_ppng.hip) against the restatement, as for PPNG1; the third case's planes (64 x 64 x 8) do not fit the LDS."""
+    from test_gpu_parity import _bits, _f32, _t
+
+    n = 1024
+    ref = oracle.create_encoding(3, cfg, alignment=0)
+    enc = tcnn.Encoding(3, cfg)
+    native = enc.native_tcnn_module
+    assert enc.n_output_dims == ref.padded_output_width and native.n_params() == ref.n_params and native.hyperparams()["otype"] == "PPNG2"
+    x = oracle.Pcg32(42).uniform_strided(n * 3).reshape(n, 3)
+    params = oracle.half_bits(oracle.Pcg32(7).uniform_strided(ref.n_params, -0.7, 0.7))
+    want, ctx = ref.forward(x, params)
+    xt = _t(x).requires_grad_(True)
+    pt = _t(params.view(np.float16)).requires_grad_(True)
+    nctx, out = native.fwd(xt, pt)
+    a, b = _f32(_bits(out)), _f32(want)
+    assert np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(b).max())
+    dy = oracle.half_bits(oracle.Pcg32(5).uniform_strided(n * ref.padded_output_width, -1.0, 1.0).reshape(n, ref.padded_output_width))
+    g_ref = np.zeros(ref.n_params, dtype=np.uint16)
+    ref.backward(x, ctx, dy, grad_half=g_ref)
+    dx, g1 = native.bwd(nctx, xt, pt, out, _t(dy.view(np.float16)))
+    _, g2 = native.bwd(nctx, xt, pt, out, _t(dy.view(np.float16)))
+    assert np.array_equal(_bits(g1), _bits(g2))
+    ga, gb = _f32(_bits(g1)), _f32(g_ref)
+    assert np.linalg.norm(ga - gb) <= 2e-3 * np.linalg.norm(gb) and np.linalg.norm(gb) > 0
+    assert np.all(dx.cpu().numpy() == 0)

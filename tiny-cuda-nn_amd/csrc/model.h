@@ -718,21 +718,23 @@ private:
 
 // encodings/ppng.h:30-119 + ppng_1.h:215-379 (this fork's PPNG1: per frequency and phase a rank-R product of three 1-D tables
 // looked up at sin(freq (x - 0.5) + phase); k_ppng.hip).  3 input dims, half precision; parameter gradients only, as there.
-class Ppng1Encoding : public Encoding {
+// PPNG2 (ppng_2.h:345-506) differs in the tables: three Q x Q planes per (frequency, phase, feature, rank) instead of three rows.
+class PpngEncoding : public Encoding {
 public:
-	Ppng1Encoding(uint32_t n_dims_to_encode, const Json& enc, bool fp32) : Encoding{fp32} {
-		if (n_dims_to_encode != 3) throw std::runtime_error{"PPNG1: number of input dims must be 2 or 3"}; // ppng_1.h:370-376 (2 is commented out there)
-		if (fp32) throw std::runtime_error{"PPNG1: this build provides the half-precision form"};
+	PpngEncoding(uint32_t variant, uint32_t n_dims_to_encode, const Json& enc, bool fp32) : Encoding{fp32}, m_variant{variant} {
+		const std::string PPNG1 = "PPNG" + std::to_string(variant); // the messages name the variant
+		if (n_dims_to_encode != 3) throw std::runtime_error{PPNG1 + ": number of input dims must be 2 or 3"}; // ppng_1.h:370-376 (2 is commented out there)
+		if (fp32) throw std::runtime_error{PPNG1 + ": this build provides the half-precision form"};
 		m_log2_min_freq = (int32_t)enc.value("log2_min_freq", 0);
 		m_log2_max_freq = (int32_t)enc.value("log2_max_freq", 6);
 		m_n_quants = enc.value("n_quants", 64u);
 		m_n_frequencies = enc.value("n_frequencies", 6u);
 		m_rank = enc.value("rank", 4u);
 		m_n_features = enc.value("n_features", 4u);
-		if (m_rank != 2 && m_rank != 4 && m_rank != 8 && m_rank != 16) throw std::runtime_error{"PPNG1: rank must be 1, 2, 4, 8 or 16"};
-		if (m_n_features != 2 && m_n_features != 4 && m_n_features != 8) throw std::runtime_error{"PPNG1: number of features must be 1, 2, 4 or 8"};
-		if (m_n_frequencies < 2 || m_n_quants < 2) throw std::runtime_error{"PPNG1: needs at least 2 frequencies and 2 quantisation bins"};
-		m_n_params = (size_t)m_n_frequencies * 2 * 3 * m_n_features * m_n_quants * m_rank;
+		if (m_rank != 2 && m_rank != 4 && m_rank != 8 && m_rank != 16) throw std::runtime_error{PPNG1 + ": rank must be 1, 2, 4, 8 or 16"};
+		if (m_n_features != 2 && m_n_features != 4 && m_n_features != 8) throw std::runtime_error{PPNG1 + ": number of features must be 1, 2, 4 or 8"};
+		if (m_n_frequencies < 2 || m_n_quants < 2) throw std::runtime_error{PPNG1 + ": needs at least 2 frequencies and 2 quantisation bins"};
+		m_n_params = (size_t)m_n_frequencies * 2 * 3 * m_n_features * m_n_quants * (variant == 2 ? m_n_quants : 1u) * m_rank;
 	}
 	uint32_t input_width() const override { return 3; }
 	uint32_t output_width() const override { return m_n_frequencies * 2 * m_n_features; }
@@ -742,7 +744,7 @@ public:
 	}
 	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
 		if (out && padded_output_width() > 0 && n > 0) {
-			ppng1_forward(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_rank, m_log2_min_freq, m_log2_max_freq, x, params, out, padded_output_width());
+			(m_variant == 2 ? ppng2_forward : ppng1_forward)(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_rank, m_log2_min_freq, m_log2_max_freq, x, params, out, padded_output_width());
 		}
 		return {};
 	}
@@ -756,12 +758,12 @@ public:
 			scratch = std::make_unique<DeviceBuf>(m_n_params * sizeof(uint64_t));
 			scratch->memset(0);
 		}
-		ppng1_backward(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_rank, m_log2_min_freq, m_log2_max_freq, x, params, dL_dy, padded_output_width(),
-		               scratch->as<uint64_t>(), grads, mode == GradientMode::Accumulate);
+		(m_variant == 2 ? ppng2_backward : ppng1_backward)(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_rank, m_log2_min_freq, m_log2_max_freq, x, params, dL_dy,
+		                                                   padded_output_width(), scratch->as<uint64_t>(), grads, mode == GradientMode::Accumulate);
 	}
 	Json hyperparams() const override { // ppng.h:92-103
 		Json j = Json::object();
-		j["otype"] = "PPNG1";
+		j["otype"] = "PPNG" + std::to_string(m_variant);
 		j["n_frequencies"] = m_n_frequencies;
 		j["log2_min_freq"] = m_log2_min_freq;
 		j["log2_max_freq"] = m_log2_max_freq;
@@ -771,6 +773,7 @@ public:
 		return j;
 	}
 private:
+	uint32_t m_variant;
 	int32_t m_log2_min_freq, m_log2_max_freq;
 	uint32_t m_n_quants, m_n_frequencies, m_rank, m_n_features;
 	size_t m_n_params;
@@ -1071,8 +1074,8 @@ inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, cons
 		result.reset(new IdentityEncoding{n_dims_to_encode, enc.value("scale", 1.0f), enc.value("offset", 0.0f), fp32});
 	} else if (name == "empty") {
 		result.reset(new EmptyEncoding{n_dims_to_encode, fp32});
-	} else if (name == "ppng1") {
-		result.reset(new Ppng1Encoding{n_dims_to_encode, enc, fp32});
+	} else if (name == "ppng1" || name == "ppng2") {
+		result.reset(new PpngEncoding{name == "ppng2" ? 2u : 1u, n_dims_to_encode, enc, fp32});
 	} else if (name == "frequency") {
 		result.reset(new PeriodicEncoding{false, enc.value("n_frequencies", 12u), n_dims_to_encode, fp32});
 	} else if (name == "trianglewave") {
@@ -1101,7 +1104,7 @@ inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, cons
 		composite["nested"] = nested;
 		result.reset(new CompositeEncoding{n_dims_to_encode, composite, fp32});
 	} else {
-		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity, Empty, Frequency, TriangleWave, SphericalHarmonics, Composite, PPNG1)"};
+		throw std::runtime_error{"Encoding '" + enc.value("otype", "OneBlob") + "' not found (this build provides Grid/HashGrid/TiledGrid/DenseGrid, OneBlob, Identity, Empty, Frequency, TriangleWave, SphericalHarmonics, Composite, PPNG1, PPNG2)"};
 	}
 	if (alignment > 0) result->set_alignment(alignment);
 	return result;

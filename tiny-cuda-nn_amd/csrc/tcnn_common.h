@@ -143,6 +143,12 @@ void ppng1_forward(hipStream_t stream, bool fp32_out, uint32_t n, uint32_t F, ui
 void ppng1_backward(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, uint32_t R, int32_t log2_min_freq, int32_t log2_max_freq, MatView x,
                     const void* features, const void* dL_dy, uint32_t dy_stride, uint64_t* scratch, void* grad, bool accumulate);
 
+// PPNG2 (encodings/ppng_2.h): features half [F][2][3][C][Q][Q][R], otherwise as PPNG1
+void ppng2_forward(hipStream_t stream, bool fp32_out, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, uint32_t R, int32_t log2_min_freq, int32_t log2_max_freq, MatView x,
+                   const void* features, void* out, uint32_t out_stride);
+void ppng2_backward(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, uint32_t R, int32_t log2_min_freq, int32_t log2_max_freq, MatView x,
+                    const void* features, const void* dL_dy, uint32_t dy_stride, uint64_t* scratch, void* grad, bool accumulate);
+
 // ---- binned form for levels cut into more than 64 chunks (k_grid_bin.hip; GridLevel::scatter_binned): no filter, no gathers.
 // Same exact result as grid_backward_lds; writes every gradient element of the binned levels.  workspace: grid_bin_workspace_bytes().
 bool grid_bin_supported(const GridMeta& meta); // F in {2, 4}
