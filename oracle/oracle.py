@@ -535,6 +535,117 @@ class Ppng2Encoding(Ppng1Encoding):
         return np.zeros((n, 3), dtype=np.float32) if want_dL_dx else None
 
 
+class Ppng3Encoding(Ppng1Encoding):
+    """encodings/ppng_3.h:13-84, :300-385, :475-607 + interp.h:25-133 (this fork's PPNG3): per (frequency, phase) a Q^3 volume of C
+    features (cell = p_0 + Q p_1 + Q^2 p_2), trilinear interpolation; the corner loop l = 0..7 carries the bit of axis i at position
+    2 - i and multiplies the weight up as ((1 a_0) a_1) a_2.  Parameter gradients: exact sums of the fp16 products (half)(dL/dy *
+    weight), rounded once.  Input gradients (grad_point_helper): the reference adds the F 2 C terms of a sample with float atomics in
+    arbitrary order; here in the order f, s, c."""
+
+    def __init__(self, n_in, cfg):
+        if n_in != 3:
+            raise RuntimeError("PPNG: number of input dims must be 2,3 or 4.")
+        self.n_in = 3
+        self.log2_min = int(_ci(cfg, "log2_min_freq", 0))
+        self.log2_max = int(_ci(cfg, "log2_max_freq", 6))
+        self.Q = int(_ci(cfg, "n_quants", 64))
+        self.F = int(_ci(cfg, "n_frequencies", 6))
+        self.R = 1
+        self.C = int(_ci(cfg, "n_features", 4))
+        if self.C not in (1, 2, 4, 8):
+            raise RuntimeError("PPNG: number of features must be 1, 2, 4 or 8")
+        if self.C == 1:
+            raise RuntimeError("PPNG: this build provides 2, 4 or 8 features (the single-feature form sums fp32 products in arbitrary order there)")
+        self.n_output_dims = self.F * 2 * self.C
+        self.n_to_pad = 0
+        self.n_params = self.F * 2 * self.Q ** 3 * self.C
+        self.required_output_alignment = 1
+
+    def initialize_params(self, rng, scale=1.0):  # ppng.h:66-69
+        return rng.uniform_strided(self.n_params, -1e-4 * scale, 1e-4 * scale)
+
+    @staticmethod
+    def _bit(l, i):
+        return (l >> (2 - i)) & 1
+
+    def _corner(self, p0, p1, w, f, s, l):
+        """cell index and weight of corner l for every sample (interp.h:58-68)"""
+        one = np.float32(1)
+        weight = np.full(p0.shape[-1], one, dtype=np.float32)
+        cell = np.zeros(p0.shape[-1], dtype=np.int64)
+        for i in range(3):
+            bit = self._bit(l, i)
+            cell += (p1[f, s, i] if bit else p0[f, s, i]) * self.Q ** i
+            weight = (weight * (w[f, s, i] if bit else (one - w[f, s, i]))).astype(np.float32)
+        return cell, weight
+
+    def forward(self, x, params_half=None, want_indices=False, want_dy_dx=False):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        feats = half_to_f32(np.asarray(params_half)).reshape(self.F, 2, self.Q ** 3, self.C)
+        p0, p1, w = self._lookup(x)
+        fs = np.zeros((n, self.F, 2, self.C), dtype=np.float32)
+        for f in range(self.F):
+            for s in range(2):
+                res = np.zeros((n, self.C), dtype=np.float32)
+                for l in range(8):
+                    cell, weight = self._corner(p0, p1, w, f, s, l)
+                    res = (res + (feats[f, s][cell] * weight[:, None]).astype(np.float32)).astype(np.float32)
+                fs[:, f, s, :] = res
+        out = np.full((n, self.padded_output_width), half_bits(np.float32([1.0]))[0], dtype=np.uint16)
+        out[:, : self.n_output_dims] = half_bits(fs.reshape(n, self.n_output_dims))
+        return out, {"p0": p0, "p1": p1, "w": w, "feats": feats}
+
+    def backward(self, x, ctx, dL_dy, grad_half=None, want_dL_dx=False, grad_f32=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        p0, p1, w, feats = ctx["p0"], ctx["p1"], ctx["w"], ctx["feats"]
+        go = half_to_f32(np.ascontiguousarray(dL_dy)[:, : self.n_output_dims]).reshape(n, self.F, 2, self.C)
+        if grad_half is not None:
+            acc = np.zeros((self.F, 2, self.Q ** 3, self.C), dtype=np.float64)
+            for f in range(self.F):
+                for s in range(2):
+                    for l in range(8):
+                        cell, weight = self._corner(p0, p1, w, f, s, l)
+                        v = half_to_f32(half_bits((go[:, f, s, :] * weight[:, None]).astype(np.float32))).astype(np.float64)
+                        np.add.at(acc[f, s], cell, v)
+            grad_half[:] = acc.reshape(-1).astype(np.float16).view(np.uint16)
+        if not want_dL_dx:
+            return None
+        # ppng_3.h:372-383: dsc = cosf(arg) * freq, dw = dsc * 0.5 * (Q - 1) in double
+        fr = np.arange(self.F, dtype=np.float32)
+        freq_base = (fr * np.float32(self.log2_max - self.log2_min)).astype(np.float32) / np.float32(self.F - 1) + np.float32(self.log2_min)
+        freq = (np.power(np.float32(2.0), freq_base.astype(np.float32)).astype(np.float32).astype(np.float64) * 3.1415926535).astype(np.float32)
+        sph = np.arange(2, dtype=np.float64)
+        arg = (freq.astype(np.float64)[:, None, None, None] * (x.astype(np.float64).T[None, None, :, :] - 0.5) + sph[None, :, None, None] * 1.57079632679489661923).astype(np.float32)
+        dsc = (np.cos(arg).astype(np.float32) * freq[:, None, None, None]).astype(np.float32)
+        dw = ((dsc.astype(np.float64) * 0.5) * float(self.Q - 1)).astype(np.float32)  # [F][2][3][n]
+        one = np.float32(1)
+        total = np.zeros((n, 3), dtype=np.float32)
+        for f in range(self.F):
+            for s in range(2):
+                results = np.zeros((3, n, self.C), dtype=np.float32)
+                for l in range(8):
+                    cell = np.zeros(n, dtype=np.int64)
+                    weights = [np.full(n, one, dtype=np.float32) for _ in range(3)]
+                    for i in range(3):
+                        bit = self._bit(l, i)
+                        cell += (p1[f, s, i] if bit else p0[f, s, i]) * self.Q ** i
+                        for k in range(3):
+                            if i == k:
+                                fac = dw[f, s, i] if bit else -dw[f, s, i]
+                            else:
+                                fac = w[f, s, i] if bit else (one - w[f, s, i])
+                            weights[k] = (weights[k] * fac).astype(np.float32)
+                    v = feats[f, s][cell]  # [n][C]
+                    for k in range(3):
+                        results[k] = (results[k] + (v * weights[k][:, None]).astype(np.float32)).astype(np.float32)
+                for c in range(self.C):
+                    for k in range(3):
+                        total[:, k] = (total[:, k] + (go[:, f, s, c] * results[k][:, c]).astype(np.float32)).astype(np.float32)
+        return total
+
+
 class EmptyEncoding:
     """encodings/empty.h:58-150: no live outputs, padding columns of ones, zero input gradient"""
 
@@ -849,6 +960,8 @@ def create_encoding(n_in, cfg, alignment=8):
         enc = EmptyEncoding(n_in, cfg)
     elif name == "ppng1":
         enc = Ppng1Encoding(n_in, cfg)
+    elif name == "ppng3":
+        enc = Ppng3Encoding(n_in, cfg)
     elif name == "ppng2":
         enc = Ppng2Encoding(n_in, cfg)
     elif name == "frequency":

@@ -322,3 +322,100 @@ def test_ppng2_matches_oracle(tcnn, oracle, cfg):
     ga, gb = _f32(_bits(g1)), _f32(g_ref)
     assert np.linalg.norm(ga - gb) <= 2e-3 * np.linalg.norm(gb) and np.linalg.norm(gb) > 0
     assert np.all(dx.cpu().numpy() == 0)
+
+
+PPNG3 = {"otype": "PPNG3", "n_frequencies": 3, "log2_min_freq": 0, "log2_max_freq": 2, "n_quants": 8, "n_features": 2}
+
+
+def test_ppng3_oracle_layout_and_gradients(oracle):
+    """encodings/ppng_3.h + interp.h restated (oracle.Ppng3Encoding): sizes, the volume layout (cell = p_0 + Q p_1 + Q^2 p_2), and both
+    gradients against finite differences of the restatement's own forward pass."""
+    enc = oracle.create_encoding(3, PPNG3, alignment=0)
+    assert enc.n_params == 3 * 2 * 8 ** 3 * 2 and enc.padded_output_width == 3 * 2 * 2
+    with pytest.raises(RuntimeError, match="number of features must be 1, 2, 4 or 8"):
+        oracle.create_encoding(3, {**PPNG3, "n_features": 3}, alignment=0)
+    with pytest.raises(RuntimeError, match="number of input dims"):
+        oracle.create_encoding(2, PPNG3, alignment=0)
+    rs = np.random.RandomState(0)
+    n = 64
+    x = rs.uniform(0.05, 0.95, (n, 3)).astype(np.float32)
+    ph = oracle.half_bits(rs.uniform(-0.7, 0.7, enc.n_params).astype(np.float32))
+    out, ctx = enc.forward(x, ph)
+    # a volume that is linear in the first coordinate's bin index reproduces p_0 / (Q - 1) = (sc_0 + 1) / 2
+    ramp = np.zeros((3, 2, 8, 8, 8, 2), dtype=np.float32)
+    ramp[...] = (np.arange(8, dtype=np.float32) / 7.0)[None, None, None, None, :, None]
+    lin = oracle.half_to_f32(enc.forward(x, oracle.half_bits(ramp.reshape(-1)))[0]).reshape(n, 3, 2, 2)
+    sc0 = np.sin(np.pi * (x[:, 0].astype(np.float64) - 0.5))  # f = 0 (freq = pi), s = 0
+    assert np.abs(lin[:, 0, 0, 0] - (sc0 + 1) / 2).max() < 2e-3
+    dy = oracle.half_bits(rs.uniform(-1, 1, (n, 12)).astype(np.float32))
+    g = np.zeros(enc.n_params, dtype=np.uint16)
+    dx = enc.backward(x, ctx, dy, grad_half=g, want_dL_dx=True)
+    g = oracle.half_to_f32(g)
+    touched = np.flatnonzero(g)
+    assert 0 < touched.size < enc.n_params
+    dyf = oracle.half_to_f32(dy).astype(np.float64)
+    for idx in touched[:: max(1, touched.size // 10)]:
+        hi, lo = oracle.half_to_f32(ph).copy(), oracle.half_to_f32(ph).copy()
+        hi[idx] += 2.0 ** -6
+        lo[idx] -= 2.0 ** -6
+        yh = oracle.half_to_f32(enc.forward(x, oracle.half_bits(hi))[0]).astype(np.float64)
+        yl = oracle.half_to_f32(enc.forward(x, oracle.half_bits(lo))[0]).astype(np.float64)
+        fd = float(np.sum((yh - yl) * dyf)) / 2.0 ** -5
+        assert abs(fd - g[idx]) <= 6e-2 * max(1.0, abs(fd)), (idx, fd, g[idx])
+    # input gradient: the encoding is piecewise smooth in x; central differences with a step that stays inside a cell for most samples
+    h = 1e-3
+    ok = 0
+    for k in range(3):
+        xp, xm = x.copy(), x.copy()
+        xp[:, k] += h
+        xm[:, k] -= h
+        cp, cm = enc.forward(xp, ph)[1], enc.forward(xm, ph)[1]
+        same = np.all(cp["p0"] == cm["p0"], axis=(0, 1, 2))
+        yp = oracle.half_to_f32(enc.forward(xp, ph)[0]).astype(np.float64)
+        ym = oracle.half_to_f32(enc.forward(xm, ph)[0]).astype(np.float64)
+        fd = np.sum((yp - ym) * dyf, axis=1) / (2 * h)
+        err = np.abs(fd[same] - dx[same, k])
+        assert same.sum() > n // 4
+        assert np.median(err) <= 0.05 * max(1.0, np.median(np.abs(fd[same]))), (k, np.median(err))
+        ok += 1
+    assert ok == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [PPNG3, {"otype": "PPNG3", "n_quants": 32, "n_frequencies": 2, "n_features": 4}, {"otype": "PPNG3", "n_quants": 64, "n_features": 8, "n_frequencies": 2, "log2_max_freq": 4}])
+def test_ppng3_matches_oracle(tcnn, oracle, cfg):
+    """GPU (k_ppng.hip) against the restatement: outputs and input gradients within 2e-3 (device sinf / cosf / powf against numpy's),
+    parameter gradients the same exact sums (deterministic).  The third case's layers (64 x 64 x 8) do not fit the LDS (atomic form)."""
+    from test_gpu_parity import _bits, _f32, _t
+
+    n = 768 if cfg["n_quants"] == 8 else 1024
+    ref = oracle.create_encoding(3, cfg, alignment=0)
+    enc = tcnn.Encoding(3, cfg)
+    native = enc.native_tcnn_module
+    assert enc.n_output_dims == ref.padded_output_width and native.n_params() == ref.n_params and native.hyperparams()["otype"] == "PPNG3"
+    x = oracle.Pcg32(42).uniform_strided(n * 3).reshape(n, 3)
+    params = oracle.half_bits(oracle.Pcg32(7).uniform_strided(ref.n_params, -0.7, 0.7))
+    want, ctx = ref.forward(x, params)
+    xt = _t(x).requires_grad_(True)
+    pt = _t(params.view(np.float16)).requires_grad_(True)
+    nctx, out = native.fwd(xt, pt)
+    a, b = _f32(_bits(out)), _f32(want)
+    assert np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(b).max())
+    dy = oracle.half_bits(oracle.Pcg32(5).uniform_strided(n * ref.padded_output_width, -1.0, 1.0).reshape(n, ref.padded_output_width))
+    g_ref = np.zeros(ref.n_params, dtype=np.uint16)
+    dx_ref = ref.backward(x, ctx, dy, grad_half=g_ref, want_dL_dx=True)
+    dx, g1 = native.bwd(nctx, xt, pt, out, _t(dy.view(np.float16)))
+    _, g2 = native.bwd(nctx, xt, pt, out, _t(dy.view(np.float16)))
+    assert np.array_equal(_bits(g1), _bits(g2))
+    ga, gb = _f32(_bits(g1)), _f32(g_ref)
+    assert np.linalg.norm(ga - gb) <= 2e-3 * np.linalg.norm(gb) and np.linalg.norm(gb) > 0
+    da = dx.cpu().numpy()
+    assert np.linalg.norm(da - dx_ref) <= 2e-3 * np.linalg.norm(dx_ref) and np.linalg.norm(dx_ref) > 0
+
+
+@pytest.mark.gpu
+def test_ppng3_rejects_what_the_reference_rejects(tcnn):
+    with pytest.raises(RuntimeError, match="number of features must be 1, 2, 4 or 8"):
+        tcnn.Encoding(3, {"otype": "PPNG3", "n_features": 3})
+    with pytest.raises(RuntimeError, match="number of input dims"):
+        tcnn.Encoding(2, {"otype": "PPNG3"})

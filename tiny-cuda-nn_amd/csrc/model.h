@@ -722,41 +722,60 @@ private:
 class PpngEncoding : public Encoding {
 public:
 	PpngEncoding(uint32_t variant, uint32_t n_dims_to_encode, const Json& enc, bool fp32) : Encoding{fp32}, m_variant{variant} {
-		const std::string PPNG1 = "PPNG" + std::to_string(variant); // the messages name the variant
-		if (n_dims_to_encode != 3) throw std::runtime_error{PPNG1 + ": number of input dims must be 2 or 3"}; // ppng_1.h:370-376 (2 is commented out there)
+		const std::string PPNG1 = variant == 3 ? std::string{"PPNG"} : "PPNG" + std::to_string(variant); // the messages name the variant (ppng_3.h:710, :721 say "PPNG")
+		if (n_dims_to_encode != 3) throw std::runtime_error{PPNG1 + (variant == 3 ? ": number of input dims must be 2,3 or 4." : ": number of input dims must be 2 or 3")}; // ppng_1.h:370-376, ppng_3.h:717-722 (3 only)
 		if (fp32) throw std::runtime_error{PPNG1 + ": this build provides the half-precision form"};
 		m_log2_min_freq = (int32_t)enc.value("log2_min_freq", 0);
 		m_log2_max_freq = (int32_t)enc.value("log2_max_freq", 6);
 		m_n_quants = enc.value("n_quants", 64u);
 		m_n_frequencies = enc.value("n_frequencies", 6u);
-		m_rank = enc.value("rank", 4u);
+		m_rank = variant == 3 ? 1u : enc.value("rank", 4u);
 		m_n_features = enc.value("n_features", 4u);
-		if (m_rank != 2 && m_rank != 4 && m_rank != 8 && m_rank != 16) throw std::runtime_error{PPNG1 + ": rank must be 1, 2, 4, 8 or 16"};
+		if (variant != 3 && m_rank != 2 && m_rank != 4 && m_rank != 8 && m_rank != 16) throw std::runtime_error{PPNG1 + ": rank must be 1, 2, 4, 8 or 16"};
+		if (variant == 3 && m_n_features == 1) throw std::runtime_error{"PPNG: this build provides 2, 4 or 8 features (the single-feature form sums fp32 products in arbitrary order there)"};
 		if (m_n_features != 2 && m_n_features != 4 && m_n_features != 8) throw std::runtime_error{PPNG1 + ": number of features must be 1, 2, 4 or 8"};
 		if (m_n_frequencies < 2 || m_n_quants < 2) throw std::runtime_error{PPNG1 + ": needs at least 2 frequencies and 2 quantisation bins"};
-		m_n_params = (size_t)m_n_frequencies * 2 * 3 * m_n_features * m_n_quants * (variant == 2 ? m_n_quants : 1u) * m_rank;
+		if (variant == 3) { // ppng_3.h:489-494
+			m_n_params = (size_t)m_n_frequencies * 2 * m_n_quants * m_n_quants * m_n_quants * m_n_features;
+			if (m_n_params >= (1ull << 32)) throw std::runtime_error{"PPNG: the volume does not fit 32-bit offsets"};
+		} else {
+			m_n_params = (size_t)m_n_frequencies * 2 * 3 * m_n_features * m_n_quants * (variant == 2 ? m_n_quants : 1u) * m_rank;
+		}
 	}
 	uint32_t input_width() const override { return 3; }
 	uint32_t output_width() const override { return m_n_frequencies * 2 * m_n_features; }
 	size_t n_params() const override { return m_n_params; }
-	void initialize_params(Pcg32& rng, float* params_full_precision, float scale) override { // ppng_1.h:325-328
-		generate_random_uniform(nullptr, rng.st, n_params(), params_full_precision, -0.7f * scale, 0.7f * scale);
+	void initialize_params(Pcg32& rng, float* params_full_precision, float scale) override { // ppng_1.h:325-328; PPNG3 keeps the base class' range (ppng.h:66-69)
+		const float range = m_variant == 3 ? 1e-4f : 0.7f;
+		generate_random_uniform(nullptr, rng.st, n_params(), params_full_precision, -range * scale, range * scale);
 	}
 	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
 		if (out && padded_output_width() > 0 && n > 0) {
-			(m_variant == 2 ? ppng2_forward : ppng1_forward)(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_rank, m_log2_min_freq, m_log2_max_freq, x, params, out, padded_output_width());
+			if (m_variant == 3) ppng3_forward(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_log2_min_freq, m_log2_max_freq, x, params, out, padded_output_width());
+			else (m_variant == 2 ? ppng2_forward : ppng1_forward)(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_rank, m_log2_min_freq, m_log2_max_freq, x, params, out, padded_output_width());
 		}
 		return {};
 	}
 	void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) override {
 		CHECK_THROW(!dy_planes);
-		if (dL_dx) zero_input_gradient(stream, n, 3, *dL_dx); // the reference leaves dL_dinput untouched (ppng_1.h:268-321 never writes it)
+		if (dL_dx) {
+			// PPNG1 / PPNG2: the reference leaves dL_dinput untouched (ppng_1.h:268-321 never writes it); PPNG3: ppng_3.h:586-607
+			if (m_variant == 3 && padded_output_width() > 0) ppng3_backward_input(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_log2_min_freq, m_log2_max_freq, x, params, dL_dy, padded_output_width(), *dL_dx);
+			else zero_input_gradient(stream, n, 3, *dL_dx);
+		}
 		if (mode == GradientMode::Ignore || padded_output_width() == 0) return;
 		CHECK_THROW(grads != nullptr);
 		std::unique_ptr<DeviceBuf>& scratch = m_scratch[(const void*)stream]; // per stream: zero between steps (k_ppng_finalize)
 		if (!scratch) {
 			scratch = std::make_unique<DeviceBuf>(m_n_params * sizeof(uint64_t));
 			scratch->memset(0);
+		}
+		if (m_variant == 3) {
+			const size_t ws_bytes = ppng3_backward_workspace_bytes(n, m_n_frequencies, m_n_quants, m_n_features);
+			ArenaBuf ws = ws_bytes ? ArenaBuf{stream, ws_bytes} : ArenaBuf{};
+			ppng3_backward(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_log2_min_freq, m_log2_max_freq, x, dL_dy, padded_output_width(), ws.data(),
+			               scratch->as<uint64_t>(), grads, mode == GradientMode::Accumulate);
+			return;
 		}
 		(m_variant == 2 ? ppng2_backward : ppng1_backward)(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_rank, m_log2_min_freq, m_log2_max_freq, x, params, dL_dy,
 		                                                   padded_output_width(), scratch->as<uint64_t>(), grads, mode == GradientMode::Accumulate);
@@ -1074,8 +1093,8 @@ inline std::unique_ptr<Encoding> create_encoding(uint32_t n_dims_to_encode, cons
 		result.reset(new IdentityEncoding{n_dims_to_encode, enc.value("scale", 1.0f), enc.value("offset", 0.0f), fp32});
 	} else if (name == "empty") {
 		result.reset(new EmptyEncoding{n_dims_to_encode, fp32});
-	} else if (name == "ppng1" || name == "ppng2") {
-		result.reset(new PpngEncoding{name == "ppng2" ? 2u : 1u, n_dims_to_encode, enc, fp32});
+	} else if (name == "ppng1" || name == "ppng2" || name == "ppng3") {
+		result.reset(new PpngEncoding{(uint32_t)(name.back() - '0'), n_dims_to_encode, enc, fp32});
 	} else if (name == "frequency") {
 		result.reset(new PeriodicEncoding{false, enc.value("n_frequencies", 12u), n_dims_to_encode, fp32});
 	} else if (name == "trianglewave") {

@@ -148,6 +148,14 @@ void ppng2_forward(hipStream_t stream, bool fp32_out, uint32_t n, uint32_t F, ui
                    const void* features, void* out, uint32_t out_stride);
 void ppng2_backward(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, uint32_t R, int32_t log2_min_freq, int32_t log2_max_freq, MatView x,
                     const void* features, const void* dL_dy, uint32_t dy_stride, uint64_t* scratch, void* grad, bool accumulate);
+// PPNG3 (encodings/ppng_3.h): features half [F][2][Q^3][C] (cell = p_0 + Q p_1 + Q^2 p_2), C in {2, 4, 8}; dL_dx is written (not accumulated)
+void ppng3_forward(hipStream_t stream, bool fp32_out, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, int32_t log2_min_freq, int32_t log2_max_freq, MatView x, const void* features, void* out,
+                   uint32_t out_stride);
+size_t ppng3_backward_workspace_bytes(uint32_t n, uint32_t F, uint32_t Q, uint32_t C); // the third coordinate's bins of every (f, s, sample); 0 when the layers do not fit the LDS
+void ppng3_backward(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, int32_t log2_min_freq, int32_t log2_max_freq, MatView x, const void* dL_dy,
+                    uint32_t dy_stride, void* workspace, uint64_t* scratch, void* grad, bool accumulate);
+void ppng3_backward_input(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, int32_t log2_min_freq, int32_t log2_max_freq, MatView x, const void* features,
+                          const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx);
 
 // ---- binned form for levels cut into more than 64 chunks (k_grid_bin.hip; GridLevel::scatter_binned): no filter, no gathers.
 // Same exact result as grid_backward_lds; writes every gradient element of the binned levels.  workspace: grid_bin_workspace_bytes().
