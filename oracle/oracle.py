@@ -646,6 +646,86 @@ class Ppng3Encoding(Ppng1Encoding):
         return total
 
 
+    def _derivs(self, x):
+        """dw = d sc / dx (Q - 1) / 2 and ddw = d2 sc / dx2 (Q - 1) / 2 per (f, s, axis, sample), float as there (ppng_3.h:372-383, :462-471, :215-216)"""
+        fr = np.arange(self.F, dtype=np.float32)
+        freq_base = (fr * np.float32(self.log2_max - self.log2_min)).astype(np.float32) / np.float32(self.F - 1) + np.float32(self.log2_min)
+        freq = (np.power(np.float32(2.0), freq_base.astype(np.float32)).astype(np.float32).astype(np.float64) * 3.1415926535).astype(np.float32)
+        sph = np.arange(2, dtype=np.float64)
+        arg = (freq.astype(np.float64)[:, None, None, None] * (x.astype(np.float64).T[None, None, :, :] - 0.5) + sph[None, :, None, None] * 1.57079632679489661923).astype(np.float32)
+        fq = freq[:, None, None, None]
+        dsc = (np.cos(arg).astype(np.float32) * fq).astype(np.float32)
+        ddsc = (((-np.sin(arg).astype(np.float32)) * fq).astype(np.float32) * fq).astype(np.float32)
+        dw = ((dsc.astype(np.float64) * 0.5) * float(self.Q - 1)).astype(np.float32)
+        ddw = (ddsc.astype(np.float64) * (0.5 * float(self.Q - 1))).astype(np.float32)
+        return dw, ddw
+
+    def backward_backward_input(self, x, ctx, dL_ddLdx, dL_dy, params_half=None, grad_half=None, grad_f32=None, want_dL_ddLdy=False, want_dL_dx=False):
+        """ppng_3.h:86-275, :387-473, :609-676: the second-order pass.  grad_half (if given) is OVERWRITTEN with the exact sums of the fp16
+        products (half)(dL/dy g2f); returns (dL_ddLdy half bits or None, dL_dx float or None), padding columns of dL_ddLdy zero."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        v = np.ascontiguousarray(dL_ddLdx, dtype=np.float32)
+        n = x.shape[0]
+        p0, p1, w, feats = ctx["p0"], ctx["p1"], ctx["w"], ctx["feats"]
+        go = half_to_f32(np.ascontiguousarray(dL_dy)[:, : self.n_output_dims]).reshape(n, self.F, 2, self.C)
+        dw, ddw = self._derivs(x)
+        one = np.float32(1)
+        acc = np.zeros((self.F, 2, self.Q ** 3, self.C), dtype=np.float64) if grad_half is not None else None
+        ddy = np.zeros((n, self.padded_output_width), dtype=np.float32) if want_dL_ddLdy else None
+        dx = np.zeros((n, 3), dtype=np.float32) if want_dL_dx else None
+        for f in range(self.F):
+            for s in range(2):
+                a = [[(one - w[f, s, k]).astype(np.float32), w[f, s, k]] for k in range(3)]  # a[k][bit]
+                d1 = [[-dw[f, s, k], dw[f, s, k]] for k in range(3)]
+                d2 = [[-ddw[f, s, k], ddw[f, s, k]] for k in range(3)]
+                res1 = np.zeros((3, n, self.C), dtype=np.float32)  # grad_grad_helper's results
+                res2 = np.zeros((3, n, self.C), dtype=np.float32)  # grad2_points_helper's results
+                for l in range(8):
+                    bits = [self._bit(l, k) for k in range(3)]
+                    cell = np.zeros(n, dtype=np.int64)
+                    for i in range(3):
+                        cell += (p1[f, s, i] if bits[i] else p0[f, s, i]) * self.Q ** i
+                    feat = feats[f, s][cell]  # [n][C]
+                    if acc is not None or want_dL_ddLdy:
+                        weights = [np.full(n, one, dtype=np.float32) for _ in range(3)]
+                        for i in range(3):
+                            for k in range(3):
+                                weights[k] = (weights[k] * (d1[i][bits[i]] if i == k else a[i][bits[i]])).astype(np.float32)
+                        g2f = np.zeros(n, dtype=np.float32)
+                        for k in range(3):
+                            g2f = (g2f + (weights[k] * v[:, k]).astype(np.float32)).astype(np.float32)
+                            if want_dL_ddLdy:
+                                res1[k] = (res1[k] + ((feat * weights[k][:, None]).astype(np.float32) * v[:, k][:, None]).astype(np.float32)).astype(np.float32)
+                        if acc is not None:
+                            np.add.at(acc[f, s], cell, half_to_f32(half_bits((go[:, f, s, :] * g2f[:, None]).astype(np.float32))).astype(np.float64))
+                    if want_dL_dx:
+                        for i in range(3):
+                            wi = np.zeros(n, dtype=np.float32)
+                            for j in range(3):
+                                weight = np.full(n, one, dtype=np.float32)
+                                for k in range(3):
+                                    if j == i:
+                                        fac = d2[k][bits[k]] if k == i else a[k][bits[k]]
+                                    else:
+                                        fac = d1[k][bits[k]] if (k == i or k == j) else a[k][bits[k]]
+                                    weight = (weight * fac).astype(np.float32)
+                                wi = (wi + (weight * v[:, j]).astype(np.float32)).astype(np.float32)
+                            res2[i] = (res2[i] + (feat * wi[:, None]).astype(np.float32)).astype(np.float32)
+                if want_dL_ddLdy:
+                    ggo = np.zeros((n, self.C), dtype=np.float32)
+                    for k in range(3):
+                        ggo = (ggo + res1[k]).astype(np.float32)
+                    base = f * 2 * self.C + s * self.C
+                    ddy[:, base : base + self.C] = ggo
+                if want_dL_dx:
+                    for c in range(self.C):
+                        for k in range(3):
+                            dx[:, k] = (dx[:, k] + (go[:, f, s, c] * res2[k][:, c]).astype(np.float32)).astype(np.float32)
+        if grad_half is not None:
+            grad_half[:] = acc.reshape(-1).astype(np.float16).view(np.uint16)
+        return (half_bits(ddy) if want_dL_ddLdy else None), dx
+
+
 class EmptyEncoding:
     """encodings/empty.h:58-150: no live outputs, padding columns of ones, zero input gradient"""
 

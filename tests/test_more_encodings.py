@@ -419,3 +419,87 @@ def test_ppng3_rejects_what_the_reference_rejects(tcnn):
         tcnn.Encoding(3, {"otype": "PPNG3", "n_features": 3})
     with pytest.raises(RuntimeError, match="number of input dims"):
         tcnn.Encoding(2, {"otype": "PPNG3"})
+
+
+def test_ppng3_oracle_second_order(oracle):
+    """The restated second-order pass (ppng_3.h:86-275) against finite differences of the restated FIRST-order input gradient:
+    with S(x, params, dy) = <dL_dx(x, params, dy), v>, dL_ddLdy = dS/d(dy), the parameter gradient = dS/d(params), dL_dx = dS/dx."""
+    enc = oracle.create_encoding(3, PPNG3, alignment=0)
+    rs = np.random.RandomState(1)
+    n = 48
+    x = rs.uniform(0.05, 0.95, (n, 3)).astype(np.float32)
+    ph = oracle.half_bits(rs.uniform(-0.7, 0.7, enc.n_params).astype(np.float32))
+    dy = oracle.half_bits(rs.uniform(-1, 1, (n, 12)).astype(np.float32))
+    v = rs.uniform(-1, 1, (n, 3)).astype(np.float32)
+
+    def S(xx, pp, dd):
+        _, c = enc.forward(xx, pp)
+        return (enc.backward(xx, c, dd, want_dL_dx=True).astype(np.float64) * v).sum(axis=1)  # per sample
+
+    _, ctx = enc.forward(x, ph)
+    g = np.zeros(enc.n_params, dtype=np.uint16)
+    ddy, dx = enc.backward_backward_input(x, ctx, v, dy, ph, grad_half=g, want_dL_ddLdy=True, want_dL_dx=True)
+    ddy, g = oracle.half_to_f32(ddy), oracle.half_to_f32(g)
+    # S is linear in dy: dS/d(dy_j) of sample b = S with dy = e_j
+    for j in (0, 5, 11):
+        e = np.zeros((n, 12), dtype=np.float32)
+        e[:, j] = 1.0
+        want = S(x, ph, oracle.half_bits(e))
+        assert np.abs(want - ddy[:, j]).max() <= 2e-3 * max(1.0, np.abs(want).max())
+    # ... and linear in the parameters
+    touched = np.flatnonzero(g)
+    assert 0 < touched.size < enc.n_params
+    base = oracle.half_to_f32(ph)
+    for idx in touched[:: max(1, touched.size // 8)]:
+        hi, lo = base.copy(), base.copy()
+        hi[idx] += 2.0 ** -6
+        lo[idx] -= 2.0 ** -6
+        fd = float((S(x, oracle.half_bits(hi), dy) - S(x, oracle.half_bits(lo), dy)).sum()) / 2.0 ** -5
+        assert abs(fd - g[idx]) <= 6e-2 * max(1.0, abs(fd)), (idx, fd, g[idx])
+    # dS/dx: central differences where the step stays inside a cell
+    h = 2e-4
+    for k in range(3):
+        xp, xm = x.copy(), x.copy()
+        xp[:, k] += h
+        xm[:, k] -= h
+        same = np.all(enc.forward(xp, ph)[1]["p0"] == enc.forward(xm, ph)[1]["p0"], axis=(0, 1, 2))
+        fd = (S(xp, ph, dy) - S(xm, ph, dy)) / (xp[:, k].astype(np.float64) - xm[:, k].astype(np.float64))
+        assert same.sum() > n // 4
+        err = np.abs(fd[same] - dx[same, k])
+        assert np.median(err) <= 0.05 * max(1.0, np.median(np.abs(fd[same]))), (k, np.median(err), np.median(np.abs(fd[same])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [PPNG3, {"otype": "PPNG3", "n_quants": 32, "n_frequencies": 2, "n_features": 4}])
+def test_ppng3_second_order_matches_oracle(tcnn, oracle, cfg):
+    """tcnn_module_backward_backward_input for PPNG3 (k_ppng3_bwdbwd / _input) against the restatement: dL_ddLdoutput and dL_dinput
+    within 2e-3 (device sinf / cosf), the parameter gradient the same exact sums; only what is asked for is computed."""
+    import torch
+
+    from test_gpu_parity import _bits, _f32, _t
+
+    n = 512
+    ref = oracle.create_encoding(3, cfg, alignment=0)
+    enc = tcnn.Encoding(3, cfg)
+    native = enc.native_tcnn_module
+    x = oracle.Pcg32(42).uniform_strided(n * 3).reshape(n, 3)
+    params = oracle.half_bits(oracle.Pcg32(7).uniform_strided(ref.n_params, -0.7, 0.7))
+    dy = oracle.half_bits(oracle.Pcg32(5).uniform_strided(n * ref.padded_output_width, -1.0, 1.0).reshape(n, ref.padded_output_width))
+    v = oracle.Pcg32(9).uniform_strided(n * 3, -1.0, 1.0).reshape(n, 3)
+    _, ctx = ref.forward(x, params)
+    g_ref = np.zeros(ref.n_params, dtype=np.uint16)
+    want_ddy, want_dx = ref.backward_backward_input(x, ctx, v, dy, params, grad_half=g_ref, want_dL_ddLdy=True, want_dL_dx=True)
+    xt = _t(x).requires_grad_(True)
+    pt = _t(params.view(np.float16)).requires_grad_(True)
+    dyt = _t(dy.view(np.float16)).requires_grad_(True)
+    nctx, _ = native.fwd(xt, pt)
+    ddy, dparams, dx = native.bwd_bwd_input(nctx, xt, pt, _t(v), dyt)
+    a, b = _f32(_bits(ddy)), _f32(want_ddy)
+    assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(b) and np.linalg.norm(b) > 0
+    assert np.linalg.norm(dx.cpu().numpy() - want_dx) <= 2e-3 * np.linalg.norm(want_dx) and np.linalg.norm(want_dx) > 0
+    ga, gb = _f32(_bits(dparams)), _f32(g_ref)
+    assert np.linalg.norm(ga - gb) <= 2e-3 * np.linalg.norm(gb) and np.linalg.norm(gb) > 0
+    ddy2, dparams2, dx2 = native.bwd_bwd_input(nctx, xt, pt.detach(), _t(v), dyt)
+    assert dparams2 is None and torch.equal(dx2, dx) and torch.equal(ddy2, ddy)
+    _, dparams3, _ = native.bwd_bwd_input(nctx, xt, pt, _t(v), dyt)
+    assert torch.equal(dparams3, dparams)  # deterministic; the scratch is left zeroed

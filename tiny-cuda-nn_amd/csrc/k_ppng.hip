@@ -67,12 +67,12 @@ __global__ void __launch_bounds__(256) k_ppng1_fwd(const uint32_t n, const uint3
 
 // padding columns (the reference's kernel leaves them unwritten; the encoding interface says ones)
 template <typename T>
-__global__ void __launch_bounds__(256) k_ppng_pad(const uint32_t n, const uint32_t first, const uint32_t out_stride, T* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_ppng_pad(const uint32_t n, const uint32_t first, const uint32_t out_stride, T* __restrict__ out, const float value = 1.0f) {
 	const uint32_t pad = out_stride - first;
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gid >= n * pad) return;
 	const uint32_t b = gid / pad, j = gid - b * pad;
-	out[(size_t)b * out_stride + first + j] = (T)1.0f;
+	out[(size_t)b * out_stride + first + j] = (T)value;
 }
 
 // ppng_1.h:57-140 for a block of samples of one (f, s): exact integer sums, in LDS when the slice fits
@@ -502,6 +502,141 @@ __global__ void __launch_bounds__(256) k_ppng3_bwd_input(const uint32_t n, const
 	for (uint32_t k = 0; k < PPNG_D; ++k) dL_dx.data[(size_t)b * dL_dx.stride_sample + (size_t)k * dL_dx.stride_dim] = sum[k];
 }
 
+// ppng_3.h:86-198 (grad_grad_helper) + :387-428: the second-order pass with respect to the parameters and dL/dy.  With v = dL_ddLdx
+// (one 3-vector per sample): g2f(corner) = sum_k prod_i (i == k ? +-dw_i : a_i) v_k;  parameter gradient += (half)(dL/dy_c g2f) per
+// corner (64-bit exact sums in the scratch, as in the first-order pass; the reference: packed fp16 atomics);  dL_ddLdy_c = sum_k
+// sum_corners feature_c weights_k v_k.
+template <typename T, uint32_t C>
+__global__ void __launch_bounds__(256) k_ppng3_bwdbwd(const uint32_t n, const uint32_t F, const uint32_t Q, const int32_t log2_min, const int32_t log2_max, const MatView x, const MatView dL_ddLdx,
+                                                      const half_t* __restrict__ features, const T* __restrict__ dL_dy, const uint32_t dy_stride, unsigned long long* __restrict__ scratch,
+                                                      T* __restrict__ dL_ddLdy, const bool aligned) {
+	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n) return;
+	const uint32_t f = blockIdx.y, s = blockIdx.z;
+	const float freq = ppng_freq(f, F, log2_min, log2_max);
+	const size_t vol_off = ((size_t)f * 2 + s) * Q * Q * Q * C;
+	Ppng3Lookup L;
+	float dw[PPNG_D], dps[PPNG_D];
+#pragma unroll
+	for (uint32_t i = 0; i < PPNG_D; ++i) {
+		const float arg = (float)((double)freq * ((double)x.data[(size_t)b * x.stride_sample + (size_t)i * x.stride_dim] - 0.5) + (double)s * 1.57079632679489661923);
+		ppng_bins(sinf(arg), Q, L.p[i][0], L.p[i][1], L.w[i]);
+		dw[i] = (float)(((double)(cosf(arg) * freq) * 0.5) * (double)(Q - 1));
+		dps[i] = dL_ddLdx.data[(size_t)b * dL_ddLdx.stride_sample + (size_t)i * dL_ddLdx.stride_dim];
+	}
+	float go[C], results[PPNG_D][C];
+#pragma unroll
+	for (uint32_t c = 0; c < C; ++c) {
+		go[c] = (float)dL_dy[(size_t)b * dy_stride + (size_t)f * 2 * C + s * C + c];
+#pragma unroll
+		for (uint32_t k = 0; k < PPNG_D; ++k) results[k][c] = 0;
+	}
+#pragma unroll
+	for (uint32_t l = 0; l < 8; ++l) {
+		float weights[PPNG_D] = {1, 1, 1};
+#pragma unroll
+		for (uint32_t i = 0; i < PPNG_D; ++i)
+#pragma unroll
+			for (uint32_t k = 0; k < PPNG_D; ++k) weights[k] *= (i == k) ? (ppng3_bit(l, i) ? dw[i] : -dw[i]) : (ppng3_bit(l, i) ? L.w[i] : 1 - L.w[i]);
+		const size_t cell = (size_t)ppng3_cell(L, l, Q) * C;
+		if (dL_ddLdy) {
+			float v[C];
+			ppng_load_vec<C>(features + vol_off + cell, v, aligned);
+#pragma unroll
+			for (uint32_t c = 0; c < C; ++c)
+#pragma unroll
+				for (uint32_t k = 0; k < PPNG_D; ++k) results[k][c] += v[c] * weights[k] * dps[k];
+		}
+		if (scratch) {
+			float g2f = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < PPNG_D; ++k) g2f += weights[k] * dps[k];
+#pragma unroll
+			for (uint32_t c = 0; c < C; ++c) atomicAdd(scratch + vol_off + cell + c, (unsigned long long)half_to_fixed_fast((half_t)(go[c] * g2f)));
+		}
+	}
+	if (dL_ddLdy) {
+#pragma unroll
+		for (uint32_t c = 0; c < C; ++c) {
+			float ggo = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < PPNG_D; ++k) ggo += results[k][c];
+			dL_ddLdy[(size_t)b * dy_stride + (size_t)f * 2 * C + s * C + c] = (T)ggo;
+		}
+	}
+}
+
+// ppng_3.h:200-275 (grad2_points_helper) + :430-473: the second-order pass with respect to the input.  Per corner and axis i:
+// weights_i = sum_j v_j prod_k (j == i ? (k == i ? +-ddw_k : a_k) : (k == i or k == j ? +-dw_k : a_k)), ddw = d2 sc / dx2 (Q - 1) / 2;
+// dL/dx_i = sum_{f, s, c} dL/dy_c sum_corners feature_c weights_i.  One thread per sample, terms added in the order f, s, c (the reference:
+// float atomics).
+template <typename T, uint32_t C>
+__global__ void __launch_bounds__(256) k_ppng3_bwdbwd_input(const uint32_t n, const uint32_t F, const uint32_t Q, const int32_t log2_min, const int32_t log2_max, const MatView x,
+                                                            const MatView dL_ddLdx, const half_t* __restrict__ features, const T* __restrict__ dL_dy, const uint32_t dy_stride,
+                                                            const MatViewMut dL_dx, const bool aligned) {
+	const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n) return;
+	float px[PPNG_D], dps[PPNG_D], sum[PPNG_D] = {0, 0, 0};
+#pragma unroll
+	for (uint32_t i = 0; i < PPNG_D; ++i) {
+		px[i] = x.data[(size_t)b * x.stride_sample + (size_t)i * x.stride_dim];
+		dps[i] = dL_ddLdx.data[(size_t)b * dL_ddLdx.stride_sample + (size_t)i * dL_ddLdx.stride_dim];
+	}
+	for (uint32_t f = 0; f < F; ++f) {
+		const float freq = ppng_freq(f, F, log2_min, log2_max);
+		for (uint32_t s = 0; s < 2; ++s) {
+			const half_t* vol = features + ((size_t)f * 2 + s) * Q * Q * Q * C;
+			Ppng3Lookup L;
+			float dw[PPNG_D], ddw[PPNG_D];
+#pragma unroll
+			for (uint32_t i = 0; i < PPNG_D; ++i) {
+				const float arg = (float)((double)freq * ((double)px[i] - 0.5) + (double)s * 1.57079632679489661923);
+				const float sn = sinf(arg);
+				ppng_bins(sn, Q, L.p[i][0], L.p[i][1], L.w[i]);
+				dw[i] = (float)(((double)(cosf(arg) * freq) * 0.5) * (double)(Q - 1));
+				ddw[i] = (float)((double)(-sn * freq * freq) * (0.5 * (double)(Q - 1)));
+			}
+			float results[PPNG_D][C];
+#pragma unroll
+			for (uint32_t k = 0; k < PPNG_D; ++k)
+#pragma unroll
+				for (uint32_t c = 0; c < C; ++c) results[k][c] = 0;
+#pragma unroll
+			for (uint32_t l = 0; l < 8; ++l) {
+				float weights[PPNG_D] = {0, 0, 0};
+#pragma unroll
+				for (uint32_t i = 0; i < PPNG_D; ++i) {
+#pragma unroll
+					for (uint32_t j = 0; j < PPNG_D; ++j) {
+						float weight = 1;
+#pragma unroll
+						for (uint32_t k = 0; k < PPNG_D; ++k) {
+							const bool bit = ppng3_bit(l, k) != 0;
+							if (j == i) weight *= (k == i) ? (bit ? ddw[k] : -ddw[k]) : (bit ? L.w[k] : 1 - L.w[k]);
+							else weight *= (k == i || k == j) ? (bit ? dw[k] : -dw[k]) : (bit ? L.w[k] : 1 - L.w[k]);
+						}
+						weights[i] += weight * dps[j];
+					}
+				}
+				float v[C];
+				ppng_load_vec<C>(vol + (size_t)ppng3_cell(L, l, Q) * C, v, aligned);
+#pragma unroll
+				for (uint32_t c = 0; c < C; ++c)
+#pragma unroll
+					for (uint32_t k = 0; k < PPNG_D; ++k) results[k][c] += v[c] * weights[k];
+			}
+#pragma unroll
+			for (uint32_t c = 0; c < C; ++c) {
+				const float go = (float)dL_dy[(size_t)b * dy_stride + (size_t)f * 2 * C + s * C + c];
+#pragma unroll
+				for (uint32_t k = 0; k < PPNG_D; ++k) sum[k] += go * results[k][c];
+			}
+		}
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < PPNG_D; ++k) dL_dx.data[(size_t)b * dL_dx.stride_sample + (size_t)k * dL_dx.stride_dim] = sum[k];
+}
+
 // scratch (exact sums) -> gradients, rounded once; the scratch is left zeroed for the next step
 template <typename T>
 __global__ void __launch_bounds__(256) k_ppng_finalize(const size_t n_params, unsigned long long* __restrict__ scratch, T* __restrict__ grad, const int accumulate) {
@@ -703,6 +838,41 @@ void ppng3_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t F,
                           const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx) {
 	if (n == 0) return;
 	PPNG3_BY_C(ppng3_backward_input_c, stream, fp32, n, F, Q, log2_min, log2_max, x, features, dL_dy, dy_stride, dL_dx);
+}
+namespace {
+template <uint32_t C>
+void ppng3_bwdbwd_c(hipStream_t stream, bool fp32, uint32_t n, uint32_t F, uint32_t Q, int32_t log2_min, int32_t log2_max, MatView x, MatView dL_ddLdx, const void* features, const void* dL_dy,
+                    uint32_t dy_stride, uint64_t* scratch, void* dL_ddLdy, MatViewMut* dL_dx) {
+	const bool aligned = (uintptr_t)features % (C * sizeof(half_t)) == 0;
+	if (scratch || dL_ddLdy) {
+		const dim3 grid(div_round_up(n, 256u), F, 2);
+		if (fp32) hipLaunchKernelGGL((k_ppng3_bwdbwd<float, C>), grid, dim3(256), 0, stream, n, F, Q, log2_min, log2_max, x, dL_ddLdx, (const half_t*)features, (const float*)dL_dy, dy_stride, (unsigned long long*)scratch, (float*)dL_ddLdy, aligned);
+		else hipLaunchKernelGGL((k_ppng3_bwdbwd<half_t, C>), grid, dim3(256), 0, stream, n, F, Q, log2_min, log2_max, x, dL_ddLdx, (const half_t*)features, (const half_t*)dL_dy, dy_stride, (unsigned long long*)scratch, (half_t*)dL_ddLdy, aligned);
+	}
+	if (dL_dx) {
+		const dim3 grid(div_round_up(n, 256u));
+		if (fp32) hipLaunchKernelGGL((k_ppng3_bwdbwd_input<float, C>), grid, dim3(256), 0, stream, n, F, Q, log2_min, log2_max, x, dL_ddLdx, (const half_t*)features, (const float*)dL_dy, dy_stride, *dL_dx, aligned);
+		else hipLaunchKernelGGL((k_ppng3_bwdbwd_input<half_t, C>), grid, dim3(256), 0, stream, n, F, Q, log2_min, log2_max, x, dL_ddLdx, (const half_t*)features, (const half_t*)dL_dy, dy_stride, *dL_dx, aligned);
+	}
+	HIP_CHECK_THROW(hipGetLastError());
+}
+} // namespace
+
+void ppng3_backward_backward_input(hipStream_t stream, bool fp32, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, int32_t log2_min, int32_t log2_max, MatView x, MatView dL_ddLdx, const void* features,
+                                   const void* dL_dy, uint32_t dy_stride, uint64_t* scratch, void* grad, bool accumulate, void* dL_ddLdy, MatViewMut* dL_dx) {
+	if (n > 0) { PPNG3_BY_C(ppng3_bwdbwd_c, stream, fp32, n, F, Q, log2_min, log2_max, x, dL_ddLdx, features, dL_dy, dy_stride, grad ? scratch : nullptr, dL_ddLdy, dL_dx); }
+	const uint32_t live = F * 2 * C;
+	if (n > 0 && dL_ddLdy && dy_stride > live) { // padding columns: zero (the reference leaves them unwritten)
+		const uint32_t total = n * (dy_stride - live);
+		if (fp32) hipLaunchKernelGGL(k_ppng_pad<float>, dim3(div_round_up(total, 256u)), dim3(256), 0, stream, n, live, dy_stride, (float*)dL_ddLdy, 0.0f);
+		else hipLaunchKernelGGL(k_ppng_pad<half_t>, dim3(div_round_up(total, 256u)), dim3(256), 0, stream, n, live, dy_stride, (half_t*)dL_ddLdy, 0.0f);
+	}
+	if (grad) {
+		const size_t n_params = (size_t)F * 2 * Q * Q * Q * C;
+		const uint32_t blocks = (uint32_t)((n_params + 255) / 256);
+		if (fp32) hipLaunchKernelGGL(k_ppng_finalize<float>, dim3(blocks), dim3(256), 0, stream, n_params, (unsigned long long*)scratch, (float*)grad, accumulate ? 1 : 0);
+		else hipLaunchKernelGGL(k_ppng_finalize<half_t>, dim3(blocks), dim3(256), 0, stream, n_params, (unsigned long long*)scratch, (half_t*)grad, accumulate ? 1 : 0);
+	}
 }
 #undef PPNG3_BY_C
 

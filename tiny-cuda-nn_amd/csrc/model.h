@@ -250,7 +250,7 @@ public:
 	// dL_dy [n][padded] T; grads: T[n_params] or nullptr (Ignore)
 	// dy_planes: dL_dy is laid out as level planes [padded / F][n][F] (only if level_plane_features() allowed it), else AoS
 	virtual void backward(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, const void* dL_dy, MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode, bool dy_planes) = 0;
-	// second-order input gradients (object.h:278-288); only the grid encoding provides them (grid.h:902-1026)
+	// second-order input gradients (object.h:278-288); the grid encoding (grid.h:902-1026) and PPNG3 (ppng_3.h:609-676) provide them
 	virtual void backward_backward_input(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, MatView dL_ddLdx, const void* dL_dy, void* dL_ddLdy,
 	                                     MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) {
 		throw std::runtime_error{"DifferentiableObject::backward_backward_input_impl: not implemented error"};
@@ -765,20 +765,29 @@ public:
 		}
 		if (mode == GradientMode::Ignore || padded_output_width() == 0) return;
 		CHECK_THROW(grads != nullptr);
-		std::unique_ptr<DeviceBuf>& scratch = m_scratch[(const void*)stream]; // per stream: zero between steps (k_ppng_finalize)
-		if (!scratch) {
-			scratch = std::make_unique<DeviceBuf>(m_n_params * sizeof(uint64_t));
-			scratch->memset(0);
-		}
+		uint64_t* const scratch = scratch_for(stream);
 		if (m_variant == 3) {
 			const size_t ws_bytes = ppng3_backward_workspace_bytes(n, m_n_frequencies, m_n_quants, m_n_features);
 			ArenaBuf ws = ws_bytes ? ArenaBuf{stream, ws_bytes} : ArenaBuf{};
 			ppng3_backward(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_log2_min_freq, m_log2_max_freq, x, dL_dy, padded_output_width(), ws.data(),
-			               scratch->as<uint64_t>(), grads, mode == GradientMode::Accumulate);
+			               scratch, grads, mode == GradientMode::Accumulate);
 			return;
 		}
 		(m_variant == 2 ? ppng2_backward : ppng1_backward)(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_rank, m_log2_min_freq, m_log2_max_freq, x, params, dL_dy,
-		                                                   padded_output_width(), scratch->as<uint64_t>(), grads, mode == GradientMode::Accumulate);
+		                                                   padded_output_width(), scratch, grads, mode == GradientMode::Accumulate);
+	}
+	// ppng_3.h:609-676 (PPNG1 / PPNG2 have none)
+	void backward_backward_input(hipStream_t stream, const EncodingContext& ctx, uint32_t n, MatView x, MatView dL_ddLdx, const void* dL_dy, void* dL_ddLdy,
+	                             MatViewMut* dL_dx, const void* params, void* grads, GradientMode mode) override {
+		if (m_variant != 3) return Encoding::backward_backward_input(stream, ctx, n, x, dL_ddLdx, dL_dy, dL_ddLdy, dL_dx, params, grads, mode);
+		if ((!dL_ddLdy && mode == GradientMode::Ignore && !dL_dx) || padded_output_width() == 0 || n == 0) return;
+		uint64_t* scratch = nullptr;
+		if (mode != GradientMode::Ignore) {
+			CHECK_THROW(grads != nullptr);
+			scratch = scratch_for(stream);
+		}
+		ppng3_backward_backward_input(stream, false, n, m_n_frequencies, m_n_quants, m_n_features, m_log2_min_freq, m_log2_max_freq, x, dL_ddLdx, params, dL_dy, padded_output_width(), scratch,
+		                              mode != GradientMode::Ignore ? grads : nullptr, mode == GradientMode::Accumulate, dL_ddLdy, dL_dx);
 	}
 	Json hyperparams() const override { // ppng.h:92-103
 		Json j = Json::object();
@@ -792,6 +801,14 @@ public:
 		return j;
 	}
 private:
+	uint64_t* scratch_for(hipStream_t stream) { // per stream: zero between passes (k_ppng_finalize)
+		std::unique_ptr<DeviceBuf>& scratch = m_scratch[(const void*)stream];
+		if (!scratch) {
+			scratch = std::make_unique<DeviceBuf>(m_n_params * sizeof(uint64_t));
+			scratch->memset(0);
+		}
+		return scratch->as<uint64_t>();
+	}
 	uint32_t m_variant;
 	int32_t m_log2_min_freq, m_log2_max_freq;
 	uint32_t m_n_quants, m_n_frequencies, m_rank, m_n_features;

@@ -156,6 +156,9 @@ void ppng3_backward(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, ui
                     uint32_t dy_stride, void* workspace, uint64_t* scratch, void* grad, bool accumulate);
 void ppng3_backward_input(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, int32_t log2_min_freq, int32_t log2_max_freq, MatView x, const void* features,
                           const void* dL_dy, uint32_t dy_stride, MatViewMut dL_dx);
+// second order (ppng_3.h:609-676): grad (nullable; scratch as above), dL_ddLdy (nullable, [n][dy_stride]) and dL_dx (nullable, written)
+void ppng3_backward_backward_input(hipStream_t stream, bool fp32_dy, uint32_t n, uint32_t F, uint32_t Q, uint32_t C, int32_t log2_min_freq, int32_t log2_max_freq, MatView x, MatView dL_ddLdx,
+                                   const void* features, const void* dL_dy, uint32_t dy_stride, uint64_t* scratch, void* grad, bool accumulate, void* dL_ddLdy, MatViewMut* dL_dx);
 
 // ---- binned form for levels cut into more than 64 chunks (k_grid_bin.hip; GridLevel::scatter_binned): no filter, no gathers.
 // Same exact result as grid_backward_lds; writes every gradient element of the binned levels.  workspace: grid_bin_workspace_bytes().
