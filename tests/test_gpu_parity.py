@@ -721,6 +721,31 @@ def test_adam_step_counts_are_kept_narrow_and_widened_losslessly(tcnn, oracle, m
     assert counts.max() == 65538 and counts.min() < 65538  # beyond uint16, and parameters that missed updates keep their own count
 
 
+def test_wide_inference_rows_are_independent_at_full_batch(tcnn, oracle):
+    """BASELINE config 4 at its size (FullyFusedMLP 128 x 4, 2^20 rows): a row's output depends on that row alone (object.h:147-176,
+    one workgroup per 128-row tile in the reference) -- any block of rows evaluated on its own, at any offset and batch size, gives the
+    bits the full batch gives for those rows (what sharding the rows over GPUs relies on, tinycudann/parallel.py), and a sample of
+    rows matches the oracle."""
+    cfg = {"loss": {"otype": "L2"}, "optimizer": {"otype": "Adam"}, "encoding": {"otype": "Identity"},
+           "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 4}}
+    import torch
+
+    n = 1 << 20
+    tr = tcnn.Trainer(32, 16, cfg, seed=1337)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    x = torch.rand((n, 32), device="cuda", generator=gen)
+    full = tr.inference_half(x)
+    assert full.shape == (n, 16) and torch.isfinite(full.float()).all()
+    for begin, rows in ((0, 256), (131072, 131072), (n - 4096, 4096), (524288 + 256 * 7, 256 * 33)):
+        part = tr.inference_half(x[begin:begin + rows].contiguous())
+        assert torch.equal(part, full[begin:begin + rows]), (begin, rows)
+    ref = oracle.Trainer(32, 16, cfg, seed=1337)
+    idx = np.arange(0, n, n // 512)[:512]
+    want = ref.inference(x[idx].cpu().numpy())
+    assert rel_err(full[idx].float().cpu().numpy(), want) < 1e-2
+
+
 def test_wide_inference_forms_agree(tcnn, oracle, monkeypatch):
     """BASELINE config 4 (FullyFusedMLP 128 x 4, 32 -> 16): the LDS-resident-weights form used for large batches computes the
     same per-sample MFMA sequence as the L2-resident form -- bit-identical outputs -- and both match the oracle."""
