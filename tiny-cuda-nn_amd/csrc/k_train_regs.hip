@@ -671,6 +671,14 @@ void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uin
 			fprintf(stderr, "k_mlp_train_regs wave 0 clocks, mean over %u workgroups: fill %.0f trips %.0f (%u blocks of 16 per wave) tail %.0f (of which the waves' loop ends are spread over %.0f)\n", grid,
 			        fill / grid, loop / grid, div_round_up(n / 16, grid * REGS_NW), tail / grid, skew / grid);
 			(void)t_min; (void)t_max;
+			{ // when each wave of a workgroup leaves the trip loop (clocks after wave 0's kernel start, mean over the workgroups)
+				double end_w[REGS_NW] = {};
+				for (uint32_t g = 0; g < grid; ++g)
+					for (int w = 0; w < REGS_NW; ++w) end_w[w] += (double)(h[(size_t)grid * 4 + (size_t)g * REGS_NW + w] - h[g * 4]);
+				fprintf(stderr, "  loop end per wave:");
+				for (int w = 0; w < REGS_NW; ++w) fprintf(stderr, " %.0f", end_w[w] / grid);
+				fprintf(stderr, "\n");
+			}
 			double p[5] = {0, 0, 0, 0, 0};
 			for (uint32_t g = 0; g < grid; ++g)
 				for (int i = 0; i < 5; ++i) p[i] += (double)h[(size_t)grid * (4 + REGS_NW) + (size_t)g * 8 + i];
