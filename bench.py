@@ -245,6 +245,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one rank per GPU; with fewer GPUs than ranks (a rehearsal of the N > 1 path on a one-GPU box, gloo only) the ranks share them
+        local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     else:
