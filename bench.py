@@ -120,11 +120,12 @@ def run_c4(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank %= max(torch.cuda.device_count(), 1)  # fewer GPUs than ranks: a gloo rehearsal on a one-GPU box
     torch.cuda.set_device(local_rank if world > 1 else 0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     m = c4_measure(args.steps, args.warmup, world)
     if rank == 0:
         achieved = m["rows_per_gpu"] * C4_FLOP_PER_ROW / (m["stream_ms_per_step"] * 1e-3) / 1e12
