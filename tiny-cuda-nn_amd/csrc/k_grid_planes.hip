@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 ) {
 	typedef typename VecOf<half_t, F>::type vecF;
 	if (prep.image) { // side job (mlp_side_jobs.h): the fragment images of the network this batch is encoded for; independent of everything below
-		const uint32_t total = (prep.desc.n_frags_fwd + prep.desc.n_frags_bwd) * 512;
+		const uint32_t total = (prep.desc.n_frags_fwd + prep.desc.n_frags_bwd + prep.desc.n_frags_r32) * 512;
 		for (uint32_t e = blockIdx.x * FP_THREADS + threadIdx.x; e < total; e += gridDim.x * FP_THREADS) mlp_prep_element(prep.desc, (const half_t*)prep.params, (half_t*)prep.image, e);
 	}
 	constexpr int FP_WAVE_SAMPLES = 64 * FP_SPT;

@@ -574,10 +574,10 @@ inline uint32_t mlp_grid(uint32_t n, int nb) {
 
 } // namespace
 
-size_t mlp_image_bytes(const MlpDesc& d) { return (size_t)(d.n_frags_fwd + d.n_frags_bwd) * 1024; }
+size_t mlp_image_bytes(const MlpDesc& d) { return (size_t)(d.n_frags_fwd + d.n_frags_bwd + d.n_frags_r32) * 1024; }
 
 void mlp_prepare_weights(hipStream_t stream, const MlpDesc& d, const void* params, void* image, bool want_bwd) {
-	const uint32_t n_frags = d.n_frags_fwd + (want_bwd ? d.n_frags_bwd : 0);
+	const uint32_t n_frags = d.n_frags_fwd + (want_bwd ? d.n_frags_bwd + d.n_frags_r32 : 0);
 	const uint32_t total = n_frags * 512;
 	hipLaunchKernelGGL(k_mlp_prep, dim3(div_round_up(total, 256)), dim3(256), 0, stream, d, (const half_t*)params, (half_t*)image, n_frags);
 }

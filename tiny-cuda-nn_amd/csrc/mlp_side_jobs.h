@@ -15,6 +15,65 @@ namespace tcnn_amd {
 __host__ __device__ inline uint32_t frag_k_chain(uint32_t s, uint32_t q, uint32_t j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
 __host__ __device__ inline uint32_t frag_k_natural(uint32_t s, uint32_t q, uint32_t j) { return 32 * s + 8 * q + j; }
 
+// ---- fragments for v_mfma_f32_32x32x16_f16 (k_train_r32.hip): the image's third section, 1 KiB per (32-row tile, 16-deep k-step).
+// Operand maps of that instruction: lane (r = lane & 31, h = lane >> 5), element j = 0..7: A[row r][k = 8 h + j], B[k = 8 h + j][column r];
+// result register g of lane (c, h): D[row (g & 3) + 8 (g >> 2) + 4 h][column c].  A layer's result registers 8 s .. 8 s + 7 of row tile t,
+// converted to halves, ARE the B fragment of the next layer's k-step 2 t + s, element j being feature
+//     r32_chain_k(2 t + s, h, j) = 16 (2 t + s) + 8 (j >> 2) + 4 h + (j & 3);
+// the fragments absorb that order.  The output layer's rows are "positions": position rho < 16 holds output 2 g + h' where
+// (g, h') are the result register and lane half that hold row rho (g = (rho & 3) + 4 (rho >> 3), h' = (rho >> 2) & 1) -- every lane then has
+// the outputs 2 g + h in its registers g = 0..7, and with at most four outputs two registers per lane are live.  Positions 16..31: zero rows.
+__host__ __device__ inline uint32_t r32_chain_k(uint32_t ks, uint32_t h, uint32_t j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
+struct R32Frags {
+	uint32_t wt, ks0, ksw, it, nh;   // row tiles of a hidden layer, k-steps of layer 0, k-steps over the hidden width, row tiles of dL/dinput, hidden layers
+	__host__ __device__ explicit R32Frags(const MlpDesc& d) : wt(d.width / 32), ks0(d.in_width / 16), ksw(d.width / 16), it((d.in_width + 31) / 32), nh(d.n_hidden) {}
+	// forward: layer 0 [t][s], hidden layers l >= 1 [t][ks], output layer [ks]; backward (A = W^T): output layer [t], hidden l >= 1 [t][ks], layer 0 [ti][ks]
+	__host__ __device__ uint32_t fwd0() const { return 0; }
+	__host__ __device__ uint32_t fwd_hidden(uint32_t l) const { return wt * ks0 + (l - 1) * wt * ksw; }
+	__host__ __device__ uint32_t fwd_out() const { return wt * ks0 + (nh - 1) * wt * ksw; }
+	__host__ __device__ uint32_t bwd_out() const { return fwd_out() + ksw; }
+	__host__ __device__ uint32_t bwd_hidden(uint32_t l) const { return bwd_out() + wt + (l - 1) * wt * ksw; }
+	__host__ __device__ uint32_t bwd0() const { return bwd_out() + wt + (nh - 1) * wt * ksw; }
+	__host__ __device__ uint32_t n_frags() const { return bwd0() + it * ksw; }
+};
+// networks that get the section: (16 | 32) -> 64 -> [64 ->] 16
+__host__ __device__ inline bool r32_shape_ok(const MlpDesc& d) { return d.width == 64 && (d.in_width == 16 || d.in_width == 32) && d.out_width == 16 && d.n_hidden >= 1 && d.n_hidden <= 2; }
+
+__device__ inline _Float16 r32_prep_value(const MlpDesc& d, const _Float16* __restrict__ params, const uint32_t frag, const uint32_t lane, const uint32_t j) {
+	const R32Frags f(d);
+	const uint32_t r = lane & 31, h = lane >> 5;
+	const MlpLayer L0 = d.layers[0], LO = d.layers[d.n_hidden];
+	if (frag < f.fwd_hidden(1)) { // layer 0, natural k
+		const uint32_t t = frag / f.ks0, s = frag - t * f.ks0;
+		return params[L0.w_off + (size_t)(32 * t + r) * L0.cols + 16 * s + 8 * h + j];
+	}
+	if (frag < f.fwd_out()) {
+		const uint32_t local = frag - f.fwd_hidden(1), per = f.wt * f.ksw;
+		const uint32_t l = 1 + local / per, rem = local - (l - 1) * per, t = rem / f.ksw, ks = rem - t * f.ksw;
+		const MlpLayer L = d.layers[l];
+		return params[L.w_off + (size_t)(32 * t + r) * L.cols + r32_chain_k(ks, h, j)];
+	}
+	if (frag < f.bwd_out()) { // output layer: row = position
+		const uint32_t ks = frag - f.fwd_out();
+		if (r >= 16) return (_Float16)0.0f;
+		const uint32_t o = 2 * ((r & 3) + 4 * (r >> 3)) + ((r >> 2) & 1);
+		return params[LO.w_off + (size_t)o * LO.cols + r32_chain_k(ks, h, j)];
+	}
+	if (frag < f.bwd_hidden(1)) { // Wout^T: k = position (h, j) <-> output 2 j + h
+		const uint32_t t = frag - f.bwd_out();
+		return params[LO.w_off + (size_t)(2 * j + h) * LO.cols + 32 * t + r];
+	}
+	if (frag < f.bwd0()) {
+		const uint32_t local = frag - f.bwd_hidden(1), per = f.wt * f.ksw;
+		const uint32_t l = 1 + local / per, rem = local - (l - 1) * per, t = rem / f.ksw, ks = rem - t * f.ksw;
+		const MlpLayer L = d.layers[l];
+		return params[L.w_off + (size_t)r32_chain_k(ks, h, j) * L.cols + 32 * t + r];
+	}
+	const uint32_t local = frag - f.bwd0(), t = local / f.ksw, ks = local - t * f.ksw;
+	const uint32_t col = 32 * t + r;
+	return col < L0.cols ? params[L0.w_off + (size_t)r32_chain_k(ks, h, j) * L0.cols + col] : (_Float16)0.0f;
+}
+
 // weights (row-major half) -> fragment images, element gid of n_frags_total * 512:
 // forward fragment (layer l, row tile t, k-step s), lane (r = lane & 15, q = lane >> 4), element j:  W_l[16 t + r][k], 0 beyond the matrix
 // backward fragment (A = W_l^T; row tile t over the COLUMNS of W_l, k over its ROWS):              W_l[k_chain(s, q, j)][16 t + r]
@@ -22,6 +81,10 @@ __device__ inline void mlp_prep_element(const MlpDesc& d, const _Float16* __rest
 	uint32_t frag = gid >> 9;
 	const uint32_t lane = (gid >> 3) & 63;
 	const uint32_t j = gid & 7;
+	if (frag >= d.n_frags_fwd + d.n_frags_bwd) { // third section
+		image[gid] = r32_prep_value(d, params, frag - (d.n_frags_fwd + d.n_frags_bwd), lane, j);
+		return;
+	}
 	const uint32_t r = lane & 15, q = lane >> 4;
 	const bool bwd = frag >= d.n_frags_fwd;
 	if (bwd) frag -= d.n_frags_fwd;
@@ -48,7 +111,7 @@ __device__ inline void mlp_prep_element(const MlpDesc& d, const _Float16* __rest
 	image[gid] = v;
 }
 
-// side job of the encoding's forward kernel: build the fragment images of `params` (all n_frags_fwd + n_frags_bwd fragments)
+// side job of the encoding's forward kernel: build the fragment images of `params` (all n_frags_fwd + n_frags_bwd + n_frags_r32 fragments)
 struct MlpPrepJob {
 	MlpDesc desc;
 	const void* params; // half, the MLP's matrices at the front

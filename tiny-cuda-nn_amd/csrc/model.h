@@ -1219,6 +1219,7 @@ public:
 		}
 		m_desc.n_frags_fwd = f_off;
 		m_desc.n_frags_bwd = b_off;
+		m_desc.n_frags_r32 = r32_shape_ok(m_desc) ? R32Frags(m_desc).n_frags() : 0u;
 		m_n_params = w_off;
 	}
 

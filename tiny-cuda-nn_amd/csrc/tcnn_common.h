@@ -207,10 +207,11 @@ struct MlpDesc {
 	uint32_t in_width, width, out_width, n_hidden, n_layers;
 	uint32_t activation, output_activation;
 	uint32_t n_frags_fwd, n_frags_bwd;
+	uint32_t n_frags_r32;   // third section of the image: fragments for v_mfma_f32_32x32x16_f16 (k_train_r32.hip; mlp_side_jobs.h R32Frags), 0: none
 	MlpLayer layers[MAX_MLP_LAYERS];
 };
 
-size_t mlp_image_bytes(const MlpDesc& d);   // bytes of fwd+bwd images
+size_t mlp_image_bytes(const MlpDesc& d);   // bytes of the fwd + bwd (+ r32) images
 // params (half, row-major matrices) -> images.  image = [fwd frags][bwd frags], 1 KiB per fragment.
 void mlp_prepare_weights(hipStream_t stream, const MlpDesc& d, const void* params, void* image, bool want_bwd);
 // x: [n][in_width] half AoS; out: [n][out_width] half; hidden (optional): [n_hidden][n][width] half post-activation
@@ -265,6 +266,13 @@ uint32_t mlp_train_regs_grid(const MlpDesc& d, uint32_t n);
 void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, uint32_t x_plane_features, const float* target, const float* data_pdf,
                     const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* compact_dL_dout, float* compact_L, void* dL_dx,
                     uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params);
+// ---- the same step for 32 -> 64 -> 64 -> 16 networks fed by a 2-D grid encoding with 2 features per level, on the 32x32x16 matrix
+// instruction (k_train_r32.hip): 32 samples per wave and trip, operands of the weight-gradient products transposed through wave-private
+// LDS images.  mlp_train_regs dispatches to it (TCNN_AMD_MLP_R32=0: never); `grid` workgroups write one slab each.
+bool mlp_train_r32_applies(const MlpDesc& d, uint32_t n, uint32_t x_plane_features, const float* data_pdf, const void* external_dL_dy, uint32_t dims, LossType loss, const void* out,
+                           const void* dL_dx, uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims);
+void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, uint32_t dims, LossType loss, float loss_scale, void* out,
+                   void* compact_dL_dout, float* compact_L, void* dL_dx, const float* dx_record_x, float* slabs, uint32_t n_params, uint32_t grid);
 void mlp_expand_context(hipStream_t stream, uint32_t n, uint32_t dims, const void* compact_dL_dout, const float* compact_L, void* dL_dout, float* L);
 // grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once
 void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate);
