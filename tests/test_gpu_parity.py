@@ -629,15 +629,24 @@ def test_bench_configuration_scatter_forms_agree_at_full_batch(tcnn, oracle, mon
             monkeypatch.delenv(k)
         return g, out
 
-    base_g, base_out = grads({})
+    # the default MLP kernel of this shape (k_mlp_train_r32) only takes level planes in and records out: its own variants first ...
+    r32_g, r32_out = grads({})
+    assert np.count_nonzero(r32_g) > 5_000_000
+    for env, steps in (({}, 1), ({"TCNN_AMD_SCATTER_TUNE": "0"}, 3)):
+        g, out = grads(env, steps=steps)
+        assert np.array_equal(g, r32_g) and np.array_equal(out, r32_out), (env, steps)
+    # ... then every form of the encoding's kernels behind ONE MLP kernel that takes them all (another MLP kernel is another fp32
+    # summation order, hence other last bits in dL/d(encoding))
+    fixed = {"TCNN_AMD_MLP_R32": "0"}
+    base_g, base_out = grads(fixed)
     assert np.count_nonzero(base_g) > 5_000_000
-    first_g, first_out = grads({}, steps=1)
+    first_g, first_out = grads(fixed, steps=1)
     assert np.array_equal(first_g, base_g) and np.array_equal(first_out, base_out)
     for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_GRID_PLANES": "0"}):
-        g, out = grads(env)
+        g, out = grads({**fixed, **env})
         assert np.array_equal(out, base_out), env
         assert np.array_equal(g, base_g), env
-    g, out = grads({"TCNN_AMD_GRID_SCATTER": "atomic"})
+    g, out = grads({**fixed, "TCNN_AMD_GRID_SCATTER": "atomic"})
     assert np.array_equal(out, base_out)
     a, b = _f32(g), _f32(base_g)
     assert float(np.linalg.norm(a - b)) <= 2e-2 * float(np.linalg.norm(b))

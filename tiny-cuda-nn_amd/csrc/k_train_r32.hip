@@ -48,17 +48,17 @@ struct R32Args {
 	uint32_t n, dims, n_params;
 	uint32_t w_off[3];      // element offsets of W0, W1, Wout inside a slab
 	float loss_scale;
-	unsigned long long* dbg; // TCNN_AMD_MLP_TIMING: per workgroup wave 0's clock at start / loop start / loop end / end
+	uint32_t stagger;        // TCNN_AMD_MLP_STAGGER: waves 4..7 start their first trip this many times 64 clocks late
+	uint32_t prio_mode;      // TCNN_AMD_MLP_PRIO: 0 no priorities, 1 the two waves of a SIMD alternate their priority per trip, 2 the younger half at priority 1, 3 a trip's matrix regions above its loss
+	unsigned long long* dbg; // TCNN_AMD_MLP_TIMING: per workgroup wave 0's clock at start / loop start / loop end / end, then every wave's loop end
 };
 
 constexpr int R32_NW = 8;                 // waves per workgroup
 constexpr int R32_NF = 30;                // weight fragments (R32Frags of 32 -> 64 -> 64 -> 16)
-constexpr int R32_ZERO = R32_NF * 1024;   // 1 KiB of zeros (the upper half of the 16-position dL/doutput image)
-constexpr int R32_WAVE0 = R32_ZERO + 1024;
+constexpr int R32_WAVE0 = R32_NF * 1024;
 constexpr int R32_WAVE_BYTES = 15 * 1024; // X 2 K | H0 4 K | H1 4 K | dH 4 K | dY 1 K
 constexpr int IMG_X = 0, IMG_H0 = 2048, IMG_H1 = 6144, IMG_DH = 10240, IMG_DY = 14336;
-constexpr int R32_LDS_BYTES = R32_WAVE0 + R32_NW * R32_WAVE_BYTES; // 154 624
-constexpr int R32_NT = 8;                 // weight-gradient tiles: dW0 [2][1], dW1 [2][2], dWout [1][2]
+constexpr int R32_LDS_BYTES = R32_WAVE0 + R32_NW * R32_WAVE_BYTES; // 153 600
 
 __device__ inline f16v mfma32(const h8 a, const h8 b, const f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ inline f16v zero16() {
@@ -77,14 +77,19 @@ __device__ inline h8 pack8(const f16v v, const int s) {
 __device__ inline h8 relu8(const h8 v) { return __builtin_bit_cast(h8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), s16x8{0, 0, 0, 0, 0, 0, 0, 0})); }
 // ... and its derivative from the forward output (common_device.h:241-297): the gradient where the output has any bit set, +0 elsewhere
 // (min(bits, 1) = 0 / 1, times the gradient's bits as an integer product)
-__device__ inline h8 relu_bwd8(const h8 g, const h8 fwd) {
+template <bool AND_FORM = false> __device__ inline h8 relu_bwd8(const h8 g, const h8 fwd) {
 	const u32x4 f = __builtin_bit_cast(u32x4, fwd), gb = __builtin_bit_cast(u32x4, g);
 	u32x4 r;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		uint32_t m, o;
 		asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(m) : "v"(f[i]));
-		asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o) : "v"(gb[i]), "v"(m));
+		if constexpr (AND_FORM) { // 0 - (0 / 1) = all zeros / all ones, and
+			asm("v_pk_sub_u16 %0, 0, %1 op_sel_hi:[0,1]" : "=v"(o) : "v"(m));
+			o &= gb[i];
+		} else {
+			asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o) : "v"(gb[i]), "v"(m));
+		}
 		r[i] = o;
 	}
 	return __builtin_bit_cast(h8, r);
@@ -101,7 +106,19 @@ template <typename V> __device__ inline void st32_stream(void* base, const uint3
 
 // LOSS 1: L2, 2: RelativeL2
 // DIAG (timing-only builds, TCNN_AMD_MLP_DIAG; results are wrong): bit 0: weight fragments are not read from LDS, bit 1: the transposing
-// reads are not done, bit 2: the image writes are not done, bit 3: the loss is not evaluated
+// reads are not done, bit 2: the image writes are not done, bit 3: the loss is not evaluated; bit 4: ReLU' as min / sub / and;
+// bit 6: clocks per region of the trip (waves 0 and 4) into a.dbg (results are right with bits 4 and 6)
+//
+// The trip is written as a software pipeline of regions closed by sched_barrier(0): a region holds the matrix instructions of one
+// step of the chain together with the vector / LDS work of the step before (conversion, activation, image writes of the tile the
+// previous instructions finished) and the LDS reads of the operands of the region after, so that in program order vector
+// instructions sit between matrix instructions (a wave issues in order: behind two back-to-back matrix instructions nothing of it
+// issues until the second one has the pipe) and every LDS operand is requested one region (64 .. 256 clocks) before its use.
+#define R32_SB() __builtin_amdgcn_sched_barrier(0)
+#define R32_STAMP(i) do { if constexpr ((DIAG & 64) != 0) { const unsigned long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - ph_prev; ph_prev = now_; } } while (0)
+constexpr int R32_REGIONS = 15;
+// within a region: one matrix instruction, then V vector and D LDS instructions (sched_group_barrier masks: 0x8 MFMA, 0x2 VALU, 0x80 DS)
+#define R32_MVD(V, D) do { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, V, 0); __builtin_amdgcn_sched_group_barrier(0x80, D, 0); } while (0)
 template <int LOSS, int DIAG = 0>
 __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,7 +133,21 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 	const uint32_t n_total = a.n * a.dims; // loss normalisation (relative_l2.h:58)
 	const uint32_t n4 = a.n * 4;
 
-	// ---- global addressing: wave-uniform base of the trip's 32-sample block + a lane offset that never changes
+	// ---- global addressing: raw buffer accesses -- descriptor (scalar, per matrix) + a lane offset that never changes + a scalar offset of the
+	// trip's 32-sample block: the trip loop spends one scalar addition per stream on addresses and no vector instruction (as plain
+	// pointers the compiler carried 64-bit vector addresses: ~40 vector and ~50 scalar instructions per trip).  Offsets are 32-bit
+	// (mlp_train_r32_applies caps n); an access beyond a matrix would be dropped by the range check instead of faulting.
+	// STORES of 16 bytes take the block's offset in the vector offset (one addition) and no scalar offset: with a scalar-register
+	// offset the compiler assumes the hardware needs no wait state between such a store and a vector instruction that overwrites
+	// its data registers (GCNHazardRecognizer: "only if the instruction is not using a register in the soffset field"); on gfx950 it
+	// does -- measured: the third dword of two of a trip's four records came out as whatever the next conversion wrote there.
+	const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(a.n * 64), 0x00020000);
+	const auto rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)a.target, 0, (int)(a.n * a.dims * 4), 0x00020000);
+	const auto rs_xs = __builtin_amdgcn_make_buffer_rsrc((void*)a.rec_x, 0, (int)(a.n * 8), 0x00020000);
+	const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(a.n * 32), 0x00020000);
+	const auto rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)a.dL_dout, 0, (int)(a.n * a.dims * 2), 0x00020000);
+	const auto rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)a.L, 0, (int)(a.n * a.dims * 4), 0x00020000);
+	const auto rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)a.rec, 0, (int)(a.n * 128), 0x00020000);
 	const uint32_t x_off = (4 * h * a.n + c) * 4; // levels 8 s + 4 h + i at + (8 s + i) n 4
 	struct In { h8 x[2]; float t[2]; float2 xs; };
 	uint32_t t_off[2];
@@ -124,24 +155,23 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 	for (int r = 0; r < 2; ++r) t_off[r] = (c * a.dims + min(2 * r + h, a.dims - 1)) * 4; // outputs >= dims re-read the last one (masked where used)
 	auto load_in = [&](const uint32_t blk) -> In {
 		In r;
-		const char* xb = (const char*)a.x + (size_t)blk * 128;
 #pragma unroll
 		for (int s = 0; s < 2; ++s) {
 			u32x4 v;
 #pragma unroll
-			for (int i = 0; i < 4; ++i) v[i] = ld32<uint32_t>(xb + (size_t)n4 * (8 * s + i), x_off); // features 16 s + 8 h + 2 i, + 1
+			for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_x, x_off, blk * 128 + n4 * (8 * s + i), 0); // features 16 s + 8 h + 2 i, + 1
 			r.x[s] = __builtin_bit_cast(h8, v);
 		}
-		const char* tb = (const char*)a.target + (size_t)blk * (128 * a.dims);
-		r.t[0] = ld32<float>(tb, t_off[0]);
-		r.t[1] = ld32<float>(tb, t_off[1]);
-		r.xs = ld32<float2>((const char*)a.rec_x + (size_t)blk * 256, c * 8);
+		const uint32_t tb = blk * (128 * a.dims);
+		r.t[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, t_off[0], tb, 0));
+		r.t[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, t_off[1], tb, 0));
+		r.xs = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_xs, c * 8, blk * 256, 0));
 		return r;
 	};
 	In pre{};
 	if (first < n_blocks) pre = load_in(first);
 
-	// ---- weight fragments into LDS, the zero block, nothing else to prepare
+	// ---- weight fragments into LDS
 	{
 		constexpr uint32_t N16 = R32_NF * 64;
 		constexpr int FILL = (N16 + R32_NW * 64 - 1) / (R32_NW * 64);
@@ -152,13 +182,12 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		for (int k = 0; k < FILL; ++k) {
 			if (tid + k * R32_NW * 64 < N16) ((h8*)smem)[tid + k * R32_NW * 64] = tmp[k];
 		}
-		if (tid < 64) ((h8*)(smem + R32_ZERO))[tid] = h8{0, 0, 0, 0, 0, 0, 0, 0};
 	}
 	__syncthreads();
 	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 1] = __builtin_readcyclecounter();
 
 	// ---- LDS addressing.  Weight fragment f: f KiB + 16 lane.  An opaque per-trip copy of the lane offset keeps the (loop-invariant)
-	// fragment reads inside the trip loop, next to their uses (hoisted they would need 120 registers).
+	// fragment reads inside the trip loop (hoisted they would need 120 registers).
 	uint32_t lane16 = lane * 16;
 	h8 fake = __builtin_bit_cast(h8, u32x4{lane, lane16, tid, wave});
 	auto frag = [&](const int f) -> h8 {
@@ -178,9 +207,10 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		w_nat[k] = wbase + gn * 256 + ((c + 4 * gn) & 31) * 8;
 	}
 	//   transposing reads (ds_read_b64_tr_b16: per 16 lanes a block of 4 rows x 16 columns; lane 4 q + p supplies the address of row q,
-	//   columns 4 p .. 4 p + 3, and receives column (lane & 15) of the 4 rows): operand fragment of sample k-step s', element j =
-	//   sample 16 s' + 8 hh + j of feature (lane & 31), hh = lane >> 5 -- two reads (e = 0, 1) of 4 samples each.
-	uint32_t r_tr[4], r_dy[4]; // [2 s' + e]; r_dy: the 16-position image, lanes of the features 16..31 read the zero block
+	//   columns 4 p .. 4 p + 3, and receives column (lane & 15) of the 4 rows)
+	//   32x32x16 operand of sample k-step s': element j = sample 16 s' + 8 hh + j of feature (lane & 31), hh = lane >> 5: reads e = 0, 1 of 4 samples
+	//   16x16x32 operand (all 32 samples): element j = sample 8 (lane >> 4) + j of feature 16 half + (lane & 15)
+	uint32_t r_tr[4], r_16[4]; // [2 s' + e], [2 half + e]
 	{
 		const uint32_t grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, hh = grp >> 1;
 		const uint32_t g = 4 * (grp & 1) + p;
@@ -188,7 +218,8 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t row = 16 * (k >> 1) + 8 * hh + 4 * (k & 1) + q;
 			r_tr[k] = wbase + g * 256 + ((row + 4 * g) & 31) * 8;
-			r_dy[k] = (grp & 1) ? (uint32_t)R32_ZERO + li * 8 : wbase + IMG_DY + g * 256 + ((row + 4 * g) & 31) * 8;
+			const uint32_t g16 = 4 * (k >> 1) + p, row16 = 8 * grp + 4 * (k & 1) + q;
+			r_16[k] = wbase + g16 * 256 + ((row16 + 4 * g16) & 31) * 8;
 		}
 	}
 	auto img_write = [&](const int img, const uint32_t (&w)[4], const int s, const h8 v) {
@@ -201,99 +232,146 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		const h4 lo = *(const h4*)(smem + w_chain[2 * s + 0] + img), hi = *(const h4*)(smem + w_chain[2 * s + 1] + img);
 		return h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 	};
-	auto tr_frag = [&](const int img, const uint32_t (&r)[4], const int sp) -> h8 {
+	auto tr2 = [&](const uint32_t a0, const uint32_t a1) -> h8 {
 		if constexpr (DIAG & 2) { asm volatile("" : "+v"(fake)); return fake; }
-		const h4 lo = lds_read_tr((const half_t*)(smem + r[2 * sp + 0] + img)), hi = lds_read_tr((const half_t*)(smem + r[2 * sp + 1] + img));
+		const h4 lo = lds_read_tr((const half_t*)(smem + a0)), hi = lds_read_tr((const half_t*)(smem + a1));
 		return h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 	};
+	auto tr_frag = [&](const int img, const int sp) -> h8 { return tr2(r_tr[2 * sp] + img, r_tr[2 * sp + 1] + img); };   // 32x32x16 operand
+	auto tr_frag16 = [&](const int img, const int half) -> h8 { return tr2(r_16[2 * half] + img, r_16[2 * half + 1] + img); }; // 16x16x32 operand
 
 	// ---- lane offsets of the stores
 	const uint32_t cg_off0 = (c * a.dims + h) * 2;              // compact dL_dout: output 2 r + h (+ 4 r bytes); compact L: twice that
 	const uint32_t o_off = c * 32 + h * 16;                     // out [n][16] halves: this lane stores the row's half h (16 bytes)
 	const uint32_t rec_off = (h * a.n + c) * 16;                // records: level pair 2 g + h at + g 2 n 16
 
-	f16v wacc[R32_NT];
+	// weight-gradient accumulators: dW0 row tiles 0, 1; dW1 tiles (tr, tc); dWout as four 16 x 16 tiles (positions x 16 hidden features)
+	f16v wacc[6];
+	f4 wout[4];
 #pragma unroll
-	for (int i = 0; i < R32_NT; ++i) wacc[i] = zero16();
+	for (int i = 0; i < 6; ++i) wacc[i] = zero16();
+#pragma unroll
+	for (int i = 0; i < 4; ++i) wout[i] = f4{0, 0, 0, 0};
 
 	// fragment slots (R32Frags of this network)
 	constexpr int F0 = 0, F1 = 4, FO = 12, BO = 16, B1 = 18, B0 = 26;
+	const f16v Z = zero16();
 
+	unsigned long long ph[R32_REGIONS] = {}, ph_prev = 0;
+	h8 f0[4]; // layer 0's fragments: requested at the end of the trip before
+#pragma unroll
+	for (int i = 0; i < 4; ++i) f0[i] = frag(F0 + i);
+
+	// The two waves of a SIMD (waves w and w + 4) are arbitrated oldest first; left alone the older one takes every contended issue slot and
+	// ends its trips long before its partner (k_train_regs.hip).  prio_mode 1 alternates their priorities per trip.
+	if (a.prio_mode == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+	if (wave >= 4) { // wave-uniform
+		for (uint32_t i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+	}
+	uint32_t prio_phase = wave >= 4 ? 1u : 0u;
 	for (uint32_t blk = first; blk < n_blocks; blk += step) {
+		if (a.prio_mode == 1) { // wave-uniform
+			if (prio_phase & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+			prio_phase ^= 1u;
+		}
+		if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(1); // the regions with matrix instructions above the loss (vector only)
 		asm volatile("" : "+v"(lane16));
+		if constexpr ((DIAG & 64) != 0) ph_prev = __builtin_readcyclecounter();
 		const In in = pre;
+		// ------------------------------------------------------------------------------------------------ forward
 		{ // unconditionally (the last trip re-reads its own block): no branch between a trip's loads and its stores, so that the
 		  // compiler's wait for these loads at the top of the next trip is a counted one that leaves the stores in flight
 			const uint32_t next = min(blk + step, n_blocks - 1);
 			pre = load_in(next);
 		}
-
-		// =============================================================== forward
 		img_write(IMG_X, w_nat, 0, in.x[0]);
 		img_write(IMG_X, w_nat, 1, in.x[1]);
-		f16v acc[2];
+		f16v a0 = mfma32(f0[0], in.x[0], Z);
+		a0 = mfma32(f0[1], in.x[1], a0);
+		h8 wa0 = frag(F1 + 0), wa1 = frag(F1 + 1);
+		R32_SB(); R32_STAMP(0);
+		f16v a1 = mfma32(f0[2], in.x[0], Z);
+		a1 = mfma32(f0[3], in.x[1], a1);
+		const h8 h00 = relu8(pack8(a0, 0)), h01 = relu8(pack8(a0, 1));
+		img_write(IMG_H0, w_chain, 0, h00);
+		img_write(IMG_H0, w_chain, 1, h01);
+		h8 wa2 = frag(F1 + 4), wa3 = frag(F1 + 5);
+		R32_MVD(8, 3); R32_MVD(8, 3);
+		R32_SB(); R32_STAMP(1);
+		f16v b0 = mfma32(wa0, h00, Z);
+		b0 = mfma32(wa1, h01, b0);
+		f16v b1 = mfma32(wa2, h00, Z);
+		b1 = mfma32(wa3, h01, b1);
+		const h8 h02 = relu8(pack8(a1, 0)), h03 = relu8(pack8(a1, 1));
+		img_write(IMG_H0 + 2048, w_chain, 0, h02);
+		img_write(IMG_H0 + 2048, w_chain, 1, h03);
+		h8 wb0 = frag(F1 + 2), wb1 = frag(F1 + 3), wb2 = frag(F1 + 6), wb3 = frag(F1 + 7);
+		R32_MVD(4, 2); R32_MVD(4, 2); R32_MVD(4, 2); R32_MVD(4, 2);
+		R32_SB(); R32_STAMP(2);
+		b0 = mfma32(wb0, h02, b0);
+		b0 = mfma32(wb1, h03, b0);
+		wa0 = frag(FO + 0); wa1 = frag(FO + 1);
+		R32_SB(); R32_STAMP(3);
+		b1 = mfma32(wb2, h02, b1);
+		b1 = mfma32(wb3, h03, b1);
+		const h8 h10 = relu8(pack8(b0, 0)), h11 = relu8(pack8(b0, 1));
+		img_write(IMG_H1, w_chain, 0, h10);
+		img_write(IMG_H1, w_chain, 1, h11);
+		wa2 = frag(FO + 2); wa3 = frag(FO + 3);
+		R32_MVD(8, 3); R32_MVD(8, 3);
+		R32_SB(); R32_STAMP(4);
+		f16v o = mfma32(wa0, h10, Z);
+		o = mfma32(wa1, h11, o);
+		const h8 h12 = relu8(pack8(b1, 0)), h13 = relu8(pack8(b1, 1));
+		img_write(IMG_H1 + 2048, w_chain, 0, h12);
+		img_write(IMG_H1 + 2048, w_chain, 1, h13);
+		wb0 = frag(BO + 0); wb1 = frag(BO + 1);
+		R32_MVD(8, 3); R32_MVD(8, 3);
+		R32_SB(); R32_STAMP(5);
+		o = mfma32(wa2, h12, o);
+		o = mfma32(wa3, h13, o);
+		// operands of dWout = dY H1^T: H1^T, 16 features per fragment
+		h8 bH[4];
 #pragma unroll
-		for (int t = 0; t < 2; ++t) {
-			acc[t] = mfma32(frag(F0 + 2 * t + 0), in.x[0], zero16());
-			acc[t] = mfma32(frag(F0 + 2 * t + 1), in.x[1], acc[t]);
-		}
-		h8 hf[4]; // chain fragments of the current layer's output, k-step 2 t + s
-#pragma unroll
-		for (int t = 0; t < 2; ++t)
-#pragma unroll
-			for (int s = 0; s < 2; ++s) {
-				hf[2 * t + s] = relu8(pack8(acc[t], s));
-				img_write(IMG_H0 + 2048 * t, w_chain, s, hf[2 * t + s]);
-			}
-#pragma unroll
-		for (int t = 0; t < 2; ++t) {
-			acc[t] = mfma32(frag(F1 + 4 * t + 0), hf[0], zero16());
-#pragma unroll
-			for (int ks = 1; ks < 4; ++ks) acc[t] = mfma32(frag(F1 + 4 * t + ks), hf[ks], acc[t]);
-		}
-#pragma unroll
-		for (int t = 0; t < 2; ++t)
-#pragma unroll
-			for (int s = 0; s < 2; ++s) {
-				hf[2 * t + s] = relu8(pack8(acc[t], s));
-				img_write(IMG_H1 + 2048 * t, w_chain, s, hf[2 * t + s]);
-			}
+		for (int tc = 0; tc < 4; ++tc) bH[tc] = tr_frag16(IMG_H1 + 2048 * (tc >> 1), tc & 1);
+		R32_SB(); R32_STAMP(6);
 
-		// =============================================================== output layer + loss on the result tile
-		h8 ov;
-		{
-			f16v o = mfma32(frag(FO + 0), hf[0], zero16());
-#pragma unroll
-			for (int ks = 1; ks < 4; ++ks) o = mfma32(frag(FO + ks), hf[ks], o);
-			ov = pack8(o, 0); // element g: output 2 g + h (output activation None)
-		}
+		// ------------------------------------------------------------------------------------------------ loss on the result tile
+		if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
+		const h8 ov = pack8(o, 0); // element g: output 2 g + h (output activation None)
 		h8 dyf = h8{0, 0, 0, 0, 0, 0, 0, 0}; // dL/doutput, the B fragment of the first backward product (k = position)
 		{
-			// l2.h:40-74 / relative_l2.h:40-75, the same operations in the same order; values and gradients of the live outputs go
-			// to the compact context matrices [n][dims]
-			char* gb = (char*)a.dL_dout + (size_t)blk * (64 * a.dims);
-			char* lb = (char*)a.L + (size_t)blk * (128 * a.dims);
+			// l2.h:40-74 / relative_l2.h:40-75, the same operations in the same order, the two output slots of a lane side by side (two
+			// independent chains of IEEE divisions); values and gradients of the live outputs go to the compact context matrices [n][dims]
+			float value[2];
+			half_t grad[2];
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
 				const float prediction = (float)ov[r];
 				const float difference = prediction - in.t[r];
-				float value, gradient;
+				float gradient;
 				if constexpr (DIAG & 8) {
-					value = difference;
+					value[r] = difference;
 					gradient = prediction;
 				} else if constexpr (LOSS == 2) {
 					const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-					value = difference * difference / prediction_sq_plus_epsilon / n_total;
+					value[r] = difference * difference / prediction_sq_plus_epsilon / n_total;
 					gradient = 2 * difference / prediction_sq_plus_epsilon;
 				} else {
-					value = difference * difference / n_total;
+					value[r] = difference * difference / n_total;
 					gradient = 2 * difference;
 				}
-				const half_t grad = (half_t)(a.loss_scale * gradient / n_total);
+				grad[r] = (half_t)(a.loss_scale * gradient / n_total);
+			}
+			asm volatile("" : "+v"(value[0]), "+v"(value[1])); // both chains are evaluated here, in one block, not inside the masked stores below
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
 				const bool live = 2 * r + h < a.dims;
-				dyf[r] = live ? grad : (half_t)0.0f;
-				if (live) st32_stream(gb + 4 * r, cg_off0, grad);
-				if (live) st32_stream(lb + 8 * r, 2 * cg_off0, value);
+				dyf[r] = live ? grad[r] : (half_t)0.0f;
+				if (live) {
+					__builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, grad[r]), rs_g, cg_off0 + 4 * r, blk * (64 * a.dims), 2);
+					__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, value[r]), rs_l, 2 * cg_off0 + 8 * r, blk * (128 * a.dims), 2);
+				}
 			}
 		}
 		{ // out [n][16]: words (2 g, 2 g + 1) of this lane and of its partner lane (the other half) interleave into the row
@@ -307,125 +385,148 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 				w[2 * k + 0] = __builtin_amdgcn_perm(odd, even, 0x05040100u); // (even.lo, odd.lo)
 				w[2 * k + 1] = __builtin_amdgcn_perm(odd, even, 0x07060302u); // (even.hi, odd.hi)
 			}
-			st32_stream((char*)a.out + (size_t)blk * 1024, o_off, u32x4{w[0], w[1], w[2], w[3]});
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, rs_out, o_off + blk * 1024, 0, 2);
 		}
 		img_write(IMG_DY, w_chain, 0, dyf); // positions 4 h .. 4 h + 3 (plane h) and 8 + 4 h .. (plane 2 + h)
+		const h8 aY = tr_frag16(IMG_DY, 0);  // dY^T: 16 positions x 32 samples
+		if (a.prio_mode == 3) __builtin_amdgcn_s_setprio(1);
+		R32_SB(); R32_STAMP(7);
 
-		// =============================================================== backward chain and weight gradients
-		// dWout = dY H1^T: rows = positions, columns = the 64 hidden features
-		{
-			const h8 a0 = tr_frag(0, r_dy, 0), a1 = tr_frag(0, r_dy, 1);
+		// ------------------------------------------------------------------------------------------------ backward chain and weight gradients
+		f16v g0 = mfma32(wb0, dyf, Z);
+		f16v g1 = mfma32(wb1, dyf, Z);
+		asm volatile("" : "+v"(g1)); // here, not sunk to its use two regions further
+		wa0 = frag(B1 + 0); wa1 = frag(B1 + 1); wa2 = frag(B1 + 4); wa3 = frag(B1 + 5);
+		R32_SB(); R32_STAMP(8);
+		// dWout (rows = positions, 16 hidden features per tile) beside the first tile of dH1 = (Wout^T dY) act'(H1) (common_device.h:241-297: from the forward OUTPUT)
+#pragma unroll
+		for (int tc = 0; tc < 4; ++tc) wout[tc] = mfma(aY, bH[tc], wout[tc]);
+		const h8 d10 = relu_bwd8<(DIAG & 16) != 0>(pack8(g0, 0), h10), d11 = relu_bwd8<(DIAG & 16) != 0>(pack8(g0, 1), h11);
+		img_write(IMG_DH, w_chain, 0, d10);
+		img_write(IMG_DH, w_chain, 1, d11);
+		R32_SB(); R32_STAMP(9);
+		f16v e0 = mfma32(wa0, d10, Z);
+		e0 = mfma32(wa1, d11, e0);
+		f16v e1 = mfma32(wa2, d10, Z);
+		e1 = mfma32(wa3, d11, e1);
+		const h8 d12 = relu_bwd8<(DIAG & 16) != 0>(pack8(g1, 0), h12), d13 = relu_bwd8<(DIAG & 16) != 0>(pack8(g1, 1), h13);
+		img_write(IMG_DH + 2048, w_chain, 0, d12);
+		img_write(IMG_DH + 2048, w_chain, 1, d13);
+		wb0 = frag(B1 + 2); wb1 = frag(B1 + 3); wb2 = frag(B1 + 6); wb3 = frag(B1 + 7);
+		R32_SB(); R32_STAMP(10);
+		e0 = mfma32(wb0, d12, e0);
+		e0 = mfma32(wb1, d13, e0);
+		e1 = mfma32(wb2, d12, e1);
+		e1 = mfma32(wb3, d13, e1);
+		// operands of dW1 = dH1 H0^T
+		h8 tA[4], tB[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			tA[k] = tr_frag(IMG_DH + 2048 * (k >> 1), k & 1);
+			tB[k] = tr_frag(IMG_H0 + 2048 * (k >> 1), k & 1);
+		}
+		R32_SB(); R32_STAMP(11);
+#pragma unroll
+		for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
 			for (int tc = 0; tc < 2; ++tc) {
-				wacc[6 + tc] = mfma32(a0, tr_frag(IMG_H1 + 2048 * tc, r_tr, 0), wacc[6 + tc]);
-				wacc[6 + tc] = mfma32(a1, tr_frag(IMG_H1 + 2048 * tc, r_tr, 1), wacc[6 + tc]);
+				wacc[2 + 2 * tr + tc] = mfma32(tA[2 * tr + 0], tB[2 * tc + 0], wacc[2 + 2 * tr + tc]);
+				wacc[2 + 2 * tr + tc] = mfma32(tA[2 * tr + 1], tB[2 * tc + 1], wacc[2 + 2 * tr + tc]);
 			}
-		}
+		const h8 d00 = relu_bwd8<(DIAG & 16) != 0>(pack8(e0, 0), img_own(IMG_H0, 0)), d01 = relu_bwd8<(DIAG & 16) != 0>(pack8(e0, 1), img_own(IMG_H0, 1));
+		const h8 d02 = relu_bwd8<(DIAG & 16) != 0>(pack8(e1, 0), img_own(IMG_H0 + 2048, 0)), d03 = relu_bwd8<(DIAG & 16) != 0>(pack8(e1, 1), img_own(IMG_H0 + 2048, 1));
+		img_write(IMG_DH, w_chain, 0, d00); // behind the reads of dH1 above: LDS operations of a wave execute in order
+		img_write(IMG_DH, w_chain, 1, d01);
+		img_write(IMG_DH + 2048, w_chain, 0, d02);
+		img_write(IMG_DH + 2048, w_chain, 1, d03);
+		wa0 = frag(B0 + 0); wa1 = frag(B0 + 1); wa2 = frag(B0 + 2); wa3 = frag(B0 + 3);
+		R32_SB(); R32_STAMP(12);
+		// dX = W0^T dH0
+		f16v dx = mfma32(wa0, d00, Z);
+		dx = mfma32(wa1, d01, dx);
+		dx = mfma32(wa2, d02, dx);
+		dx = mfma32(wa3, d03, dx);
+		// operands of dW0 = dH0 X^T, and layer 0's fragments for the next trip
 #pragma unroll
-		for (int t = 0; t < 2; ++t) acc[t] = mfma32(frag(BO + t), dyf, zero16());
-		h8 gf[4];
+		for (int k = 0; k < 4; ++k) tA[k] = tr_frag(IMG_DH + 2048 * (k >> 1), k & 1);
+		tB[0] = tr_frag(IMG_X, 0);
+		tB[1] = tr_frag(IMG_X, 1);
 #pragma unroll
-		for (int t = 0; t < 2; ++t)
-#pragma unroll
-			for (int s = 0; s < 2; ++s) {
-				gf[2 * t + s] = relu_bwd8(pack8(acc[t], s), hf[2 * t + s]); // times act'(H1) from the forward OUTPUT (common_device.h:241-297)
-				img_write(IMG_DH + 2048 * t, w_chain, s, gf[2 * t + s]);
-			}
-		// dW1 = dH1 H0^T
+		for (int i = 0; i < 4; ++i) f0[i] = frag(F0 + i);
+		R32_SB(); R32_STAMP(13);
 #pragma unroll
 		for (int tr = 0; tr < 2; ++tr) {
-			const h8 a0 = tr_frag(IMG_DH + 2048 * tr, r_tr, 0), a1 = tr_frag(IMG_DH + 2048 * tr, r_tr, 1);
-#pragma unroll
-			for (int tc = 0; tc < 2; ++tc) {
-				wacc[2 + 2 * tr + tc] = mfma32(a0, tr_frag(IMG_H0 + 2048 * tc, r_tr, 0), wacc[2 + 2 * tr + tc]);
-				wacc[2 + 2 * tr + tc] = mfma32(a1, tr_frag(IMG_H0 + 2048 * tc, r_tr, 1), wacc[2 + 2 * tr + tc]);
-			}
+			wacc[tr] = mfma32(tA[2 * tr + 0], tB[0], wacc[tr]);
+			wacc[tr] = mfma32(tA[2 * tr + 1], tB[1], wacc[tr]);
 		}
-#pragma unroll
-		for (int t = 0; t < 2; ++t) {
-			acc[t] = mfma32(frag(B1 + 4 * t + 0), gf[0], zero16());
-#pragma unroll
-			for (int ks = 1; ks < 4; ++ks) acc[t] = mfma32(frag(B1 + 4 * t + ks), gf[ks], acc[t]);
-		}
-#pragma unroll
-		for (int t = 0; t < 2; ++t)
-#pragma unroll
-			for (int s = 0; s < 2; ++s) {
-				gf[2 * t + s] = relu_bwd8(pack8(acc[t], s), img_own(IMG_H0 + 2048 * t, s));
-				img_write(IMG_DH + 2048 * t, w_chain, s, gf[2 * t + s]); // behind the reads of dH1 above: LDS operations of a wave execute in order
-			}
-		// dW0 = dH0 X^T
+		// scatter records {x, y, gradients of levels 2 p, 2 p + 1}: registers 4 g .. 4 g + 3 are features 8 g + 4 h .. + 3, i.e. level pair p = 2 g + h
 		{
-			const h8 b0 = tr_frag(IMG_X, r_tr, 0), b1 = tr_frag(IMG_X, r_tr, 1);
-#pragma unroll
-			for (int tr = 0; tr < 2; ++tr) {
-				wacc[tr] = mfma32(tr_frag(IMG_DH + 2048 * tr, r_tr, 0), b0, wacc[tr]);
-				wacc[tr] = mfma32(tr_frag(IMG_DH + 2048 * tr, r_tr, 1), b1, wacc[tr]);
-			}
-		}
-		// dX = W0^T dH0 -> scatter records {x, y, gradients of levels 2 p, 2 p + 1}: registers 4 g .. 4 g + 3 are features 8 g + 4 h .. + 3,
-		// i.e. level pair p = 2 g + h
-		{
-			f16v o = mfma32(frag(B0 + 0), gf[0], zero16());
-#pragma unroll
-			for (int ks = 1; ks < 4; ++ks) o = mfma32(frag(B0 + ks), gf[ks], o);
-			const u32x4 lo = __builtin_bit_cast(u32x4, pack8(o, 0)), hi = __builtin_bit_cast(u32x4, pack8(o, 1));
+			const u32x4 lo = __builtin_bit_cast(u32x4, pack8(dx, 0)), hi = __builtin_bit_cast(u32x4, pack8(dx, 1));
 			const uint32_t x0 = __builtin_bit_cast(uint32_t, in.xs.x), x1 = __builtin_bit_cast(uint32_t, in.xs.y);
-			char* rb = (char*)a.rec + (size_t)blk * 512;
-			const size_t pair2 = (size_t)a.n * 32; // two level pairs further
-			st32(rb, rec_off, u32x4{x0, x1, lo[0], lo[1]});
-			st32(rb + pair2, rec_off, u32x4{x0, x1, lo[2], lo[3]});
-			st32(rb + 2 * pair2, rec_off, u32x4{x0, x1, hi[0], hi[1]});
-			st32(rb + 3 * pair2, rec_off, u32x4{x0, x1, hi[2], hi[3]});
+			const uint32_t rb = blk * 512, pair2 = a.n * 32; // pair2: two level pairs further
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, lo[0], lo[1]}, rs_rec, rec_off + rb, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, lo[2], lo[3]}, rs_rec, rec_off + (rb + pair2), 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[0], hi[1]}, rs_rec, rec_off + (rb + 2 * pair2), 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[2], hi[3]}, rs_rec, rec_off + (rb + 3 * pair2), 0, 0);
+		}
+		R32_SB(); R32_STAMP(14);
+	}
+	if constexpr ((DIAG & 64) != 0) {
+		if (a.dbg && lane == 0 && (wave == 0 || wave == 4)) {
+			for (int i = 0; i < R32_REGIONS; ++i) a.dbg[(size_t)gridDim.x * (4 + R32_NW) + ((size_t)blockIdx.x * 2 + (wave >> 2)) * R32_REGIONS + i] = ph[i];
 		}
 	}
+	if (a.dbg && lane == 0) a.dbg[gridDim.x * 4 + blockIdx.x * R32_NW + wave] = __builtin_readcyclecounter();
 	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
 
-	// ---- weight gradients: 8 waves -> 4 -> the slab, through LDS (the images and fragments are dead: barrier first), in a fixed order
-	//   waves 4..7 dump, waves 0..3 add region w in place; then wave w sums the four regions of tile w and stores it into the slab
+	// ---- weight gradients: the 8 waves' accumulators -> the workgroup's slab, through LDS (the images and fragments are dead: barrier
+	// first), in two passes of 14 register quads: every wave dumps its quads, then wave w adds up the eight copies of the quads
+	// q = w (mod 8) in a fixed tree (bitwise reproducible) and stores them.  All eight waves write and read in every phase.
+	constexpr int NQ = 6 * 4 + 4, HALF = NQ / 2; // register quads per wave: 6 tiles of 16 registers, 4 tiles of 4
+	auto quad = [&](const int qi) -> f4 {
+		if (qi < 24) { const int i = qi >> 2, qd = qi & 3; return f4{wacc[i][4 * qd], wacc[i][4 * qd + 1], wacc[i][4 * qd + 2], wacc[i][4 * qd + 3]}; }
+		return wout[qi - 24];
+	};
+	f4* region = (f4*)smem; // [8 waves][14 quads][64 lanes]
+	float* slab = a.slabs + (size_t)blockIdx.x * a.n_params;
+	const uint32_t grp = lane >> 4, li = lane & 15;
 	__syncthreads();
-	f4* region = (f4*)smem; // [4 waves][8 tiles][4 register quads][64 lanes]
-	if (wave >= 4) {
-		f4* dst = region + (size_t)(wave - 4) * (R32_NT * 4 * 64) + lane;
 #pragma unroll
-		for (int i = 0; i < R32_NT; ++i)
+	for (int pass = 0; pass < 2; ++pass) {
+		f4* dst = region + (size_t)wave * (HALF * 64) + lane;
 #pragma unroll
-			for (int qd = 0; qd < 4; ++qd) dst[(i * 4 + qd) * 64] = f4{wacc[i][4 * qd], wacc[i][4 * qd + 1], wacc[i][4 * qd + 2], wacc[i][4 * qd + 3]};
-	}
-	__syncthreads();
-	if (wave < 4) {
-		f4* reg = region + (size_t)wave * (R32_NT * 4 * 64) + lane;
+		for (int q = 0; q < HALF; ++q) dst[q * 64] = quad(pass * HALF + q);
+		__syncthreads();
 #pragma unroll
-		for (int i = 0; i < R32_NT; ++i)
+		for (int q = 0; q < HALF; ++q) {
+			if ((uint32_t)(q & 7) != wave) continue; // wave-uniform
+			const int qi = pass * HALF + q;
+			const f4* src = region + (size_t)q * 64 + lane;
+			f4 r[8];
 #pragma unroll
-			for (int qd = 0; qd < 4; ++qd) {
-				const f4 v = reg[(i * 4 + qd) * 64];
-				reg[(i * 4 + qd) * 64] = f4{wacc[i][4 * qd] + v[0], wacc[i][4 * qd + 1] + v[1], wacc[i][4 * qd + 2] + v[2], wacc[i][4 * qd + 3] + v[3]}; // own slot: no hazard
-			}
-	}
-	__syncthreads();
-	{
-		float* slab = a.slabs + (size_t)blockIdx.x * a.n_params;
-		// tile `wave`: 0, 1: dW0 rows 32 tr (32 columns); 2..5: dW1 tile (tr, tc); 6, 7: dWout columns 32 tc, rows = positions (registers 0..7: output 2 g + h)
-		const uint32_t i = wave;
-		const uint32_t w_off = i < 2 ? a.w_off[0] : i < 6 ? a.w_off[1] : a.w_off[2];
-		const uint32_t cols = i < 2 ? 32u : 64u;
-		const uint32_t tr = i < 2 ? i : i < 6 ? (i - 2) >> 1 : 0u, tc = i < 2 ? 0u : i < 6 ? (i - 2) & 1u : i - 6;
+			for (int w = 0; w < 8; ++w) r[w] = src[(size_t)w * (HALF * 64)];
+			f4 sum;
 #pragma unroll
-		for (int qd = 0; qd < 4; ++qd) {
-			if (i >= 6 && qd >= 2) break; // positions 16..31: no outputs
-			const f4* src = region + (size_t)(i * 4 + qd) * 64 + lane;
-			const f4 r0 = src[0], r1 = src[R32_NT * 4 * 64], r2 = src[2 * R32_NT * 4 * 64], r3 = src[3 * R32_NT * 4 * 64];
+			for (int e = 0; e < 4; ++e) sum[e] = ((r[0][e] + r[1][e]) + (r[2][e] + r[3][e])) + ((r[4][e] + r[5][e]) + (r[6][e] + r[7][e]));
+			if (qi < 24) { // 32 x 32 tile i, registers 4 qd .. 4 qd + 3: rows (e) + 8 qd + 4 h of the tile, column c
+				const int i = qi >> 2, qd = qi & 3;
+				const uint32_t w_off = i < 2 ? a.w_off[0] : a.w_off[1], cols = i < 2 ? 32u : 64u;
+				const uint32_t tr = i < 2 ? i : (i - 2) >> 1, tc = i < 2 ? 0u : (i - 2) & 1u;
 #pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				const uint32_t g = 4 * qd + e;
-				const uint32_t row = i >= 6 ? 2 * g + h : 32 * tr + (g & 3) + 8 * (g >> 2) + 4 * h;
-				slab[w_off + row * cols + 32 * tc + c] = (r0[e] + r1[e]) + (r2[e] + r3[e]);
+				for (int e = 0; e < 4; ++e) slab[w_off + (32 * tr + e + 8 * qd + 4 * h) * cols + 32 * tc + c] = sum[e];
+			} else { // dWout, 16 x 16 tile tc: register e of lane group grp is position 4 grp + e = output 2 e + 8 (grp >> 1) + (grp & 1), column 16 tc + li
+				const int tc = qi - 24;
+#pragma unroll
+				for (int e = 0; e < 4; ++e) slab[a.w_off[2] + (2 * e + 8 * (grp >> 1) + (grp & 1)) * 64 + 16 * tc + li] = sum[e];
 			}
 		}
+		if (pass == 0) __syncthreads(); // before the second pass overwrites the copies
 	}
 	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
 }
+#undef R32_SB
+#undef R32_STAMP
+#undef R32_MVD
 
 } // namespace
 
@@ -467,14 +568,17 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
 	static int timing_left = 5;
 	if (timing && timing_left > 0) {
-		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * 32));
-		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * 32));
+		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * (32 + 8 * R32_NW + 16 * R32_REGIONS)));
+		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * (32 + 8 * R32_NW + 16 * R32_REGIONS)));
 	}
 	auto go = [&](auto kernel) {
 		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R32_LDS_BYTES));
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(R32_NW * 64), R32_LDS_BYTES, stream, a);
 		HIP_CHECK_THROW(hipGetLastError());
 	};
+	a.prio_mode = 1;
+	if (const char* e = getenv("TCNN_AMD_MLP_PRIO")) a.prio_mode = (uint32_t)atoi(e);
+	if (const char* e = getenv("TCNN_AMD_MLP_STAGGER")) a.stagger = (uint32_t)atoi(e);
 	static const int diag = getenv("TCNN_AMD_MLP_DIAG") ? atoi(getenv("TCNN_AMD_MLP_DIAG")) : 0;
 	if (diag == 1) go(k_mlp_train_r32<2, 1>);
 	else if (diag == 2) go(k_mlp_train_r32<2, 2>);
@@ -482,10 +586,12 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 	else if (diag == 7) go(k_mlp_train_r32<2, 7>);
 	else if (diag == 8) go(k_mlp_train_r32<2, 8>);
 	else if (diag == 15) go(k_mlp_train_r32<2, 15>);
+	else if (diag == 16) go(k_mlp_train_r32<2, 16>);
+	else if (diag == 64) go(k_mlp_train_r32<2, 64>);
 	else if (loss == LossType::L2) go(k_mlp_train_r32<1>);
 	else go(k_mlp_train_r32<2>);
 	if (a.dbg) {
-		std::vector<unsigned long long> hst((size_t)grid * 4);
+		std::vector<unsigned long long> hst((size_t)grid * (4 + R32_NW + 2 * R32_REGIONS));
 		HIP_CHECK_THROW(hipMemcpy(hst.data(), a.dbg, hst.size() * 8, hipMemcpyDeviceToHost));
 		if (--timing_left == 0) {
 			double fill = 0, loop = 0, tail = 0;
@@ -496,6 +602,23 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 			}
 			fprintf(stderr, "k_mlp_train_r32 wave 0 clocks, mean over %u workgroups: fill %.0f trips %.0f (%u blocks of 32 per wave) tail %.0f\n", grid, fill / grid, loop / grid,
 			        div_round_up(n / 32, grid * R32_NW), tail / grid);
+			double end_w[R32_NW] = {};
+			for (uint32_t g = 0; g < grid; ++g)
+				for (int w = 0; w < R32_NW; ++w) end_w[w] += (double)(hst[(size_t)grid * 4 + (size_t)g * R32_NW + w] - hst[g * 4]);
+			fprintf(stderr, "  loop end per wave (clocks after wave 0's start):");
+			for (int w = 0; w < R32_NW; ++w) fprintf(stderr, " %.0f", end_w[w] / grid);
+			fprintf(stderr, "\n");
+			if (diag == 64) {
+				for (int half = 0; half < 2; ++half) {
+					fprintf(stderr, "  wave %d, clocks per region summed over its trips:", 4 * half);
+					for (int i = 0; i < R32_REGIONS; ++i) {
+						double v = 0;
+						for (uint32_t g = 0; g < grid; ++g) v += (double)hst[(size_t)grid * (4 + R32_NW) + ((size_t)g * 2 + half) * R32_REGIONS + i];
+						fprintf(stderr, " %.0f", v / grid);
+					}
+					fprintf(stderr, "\n");
+				}
+			}
 		}
 		(void)hipFree(a.dbg);
 	}
