@@ -64,27 +64,37 @@ C4 = {  # BASELINE config 4: FullyFusedMLP 128 x 4, inference only, 
     "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 4},
 }
 C4_ROWS, C4_IN, C4_OUT = 1 << 20, 32, 16
+C4_CHUNKS = 4  # row ranges whose gathers overlap the next range's kernel (tinycudann/parallel.py)
 C4_FLOP_PER_ROW = 2 * (32 * 128 + 3 * 128 * 128 + 128 * 16)  # 110 592
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak
 
 
-def c4_measure(steps, warmup, world):
+def c4_setup():
+    """Allocations of the sharded inference (no collective: a rank that fails here can say so before any rank waits for it)."""
+    import torch
+
+    import tinycudann as tcnn
+
+    tr = tcnn.Trainer(C4_IN, C4_OUT, C4, seed=1337)  # same seed on every rank = replicated weights
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(42)
+    x = torch.rand((C4_ROWS, C4_IN), device="cuda", generator=gen)  # every rank holds the batch; it evaluates only its rows
+    return tr, x
+
+
+def c4_measure(steps, warmup, world, setup=None):
     """network->inference() on 1M rows, rows sharded in contiguous blocks over the ranks, weights replicated, ONE collective per
     step: the all-gather of the half output rows (tinycudann/parallel.py; RCCL over xGMI).  Returns rank-independent numbers
     (the MAX over ranks of the elapsed time) -- call on every rank."""
     import torch
     import torch.distributed as dist
 
-    import tinycudann as tcnn
     from tinycudann.parallel import shard_rows, sharded_inference
 
-    tr = tcnn.Trainer(C4_IN, C4_OUT, C4, seed=1337)  # same seed on every rank = replicated weights
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(42)
-    x = torch.rand((C4_ROWS, C4_IN), device="cuda", generator=gen)  # every rank holds the batch; it evaluates only its rows
+    tr, x = setup if setup is not None else c4_setup()
 
     def step():
-        return sharded_inference(lambda rows: tr.inference_half(rows), x, C4_OUT)
+        return sharded_inference(lambda rows: tr.inference_half(rows), x, C4_OUT, out_dtype=torch.half, chunks=C4_CHUNKS if world > 1 else 1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -112,6 +122,17 @@ def c4_measure(steps, warmup, world):
     return {"elapsed": elapsed, "rows_per_gpu": e - b, "stream_ms_per_step": kernel_ms, "checksum": float(y.double().sum().item())}
 
 
+def ranks_device(torch, local_rank, backend):
+    """One rank per GPU.  Fewer GPUs than ranks is a rehearsal of the N > 1 path on a one-GPU box and only makes sense with gloo (RCCL
+    refuses two ranks on one device): fail at once instead of in the first collective."""
+    n_dev = max(torch.cuda.device_count(), 1)
+    if local_rank >= n_dev:
+        if backend == "nccl":
+            raise RuntimeError(f"bench.py: local rank {local_rank} but only {n_dev} GPU(s) visible; one rank per GPU is required with the nccl (RCCL) backend")
+        local_rank %= n_dev
+    return local_rank
+
+
 def run_c4(args):
     """`--workload c4`: the sharded inference as the headline line.  Strong scaling: the job is the same 1M rows whatever N is."""
     import torch
@@ -120,7 +141,7 @@ def run_c4(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank %= max(torch.cuda.device_count(), 1)  # fewer GPUs than ranks: a gloo rehearsal on a one-GPU box
+    local_rank = ranks_device(torch, local_rank, args.backend)
     torch.cuda.set_device(local_rank if world > 1 else 0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -144,6 +165,16 @@ def run_c4(args):
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+ENCODE_KERNEL = {"c3a": "k_grid_fwd_planes", "c3b": "k_grid_fwd_planes", "c5": "k_grid_fwd_planes"}
+SCATTER_KERNEL = {"c3a": "k_grid_scatter (+ finalize)", "c3b": "k_grid_scatter (+ finalize)", "c5": "k_bin_* + k_grid_scatter"}
+
+
+def hbm_piece(kernel, algorithmic_bytes, ms):
+    """A piece of the step against the HBM peak: SURVEY 8(d)'s algorithmic bytes over the piece's time between its HIP events."""
+    if not kernel or not algorithmic_bytes or not ms or ms <= 0:
+        return None
+    gbs = algorithmic_bytes / (ms * 1e-3) / 1e9
+    return {"kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": algorithmic_bytes}
 ADAM_BYTES_PER_PARAM = 32  # half grad r 2 + fp32 w/m/v r+w 24 + step count r+w 4 (kept as uint16 below 65 535 steps; SURVEY 8(d) counts 8 for uint32: 36) + half w write 2
 
 
@@ -193,13 +224,100 @@ def pmc_traffic(kernel, workload):
 
 
 FLOP_PER_SAMPLE = {"c3a": 38016, "c3b": 38016, "c2": 58496, "c5": 149760}  # useful FLOP of one training sample (unpadded outputs)
-MLP_KERNEL = {"c3a": "k_mlp_train_regs", "c3b": "k_mlp_train_regs", "c2": "k_mlp_train", "c5": "k_mlp_train"}
+MLP_KERNEL = {"c3a": "k_mlp_train_r32", "c3b": "k_mlp_train_r32", "c2": "k_mlp_train", "c5": "k_mlp_train"}
 METRIC = {
     "c3a": "training_step throughput (samples/s) HashGrid+64-wide FFMLP, batch=256k; % fp16-MFMA peak",
     "c3b": "training_step throughput (samples/s) HashGrid(T=2^15)+64-wide FFMLP, batch=256k; % fp16-MFMA peak",
     "c2": "training_step throughput (samples/s) OneBlob+64-wide FFMLP, batch=64k; % fp16-MFMA peak",
     "c5": "training_step throughput (samples/s) HashGrid(F=4,T=2^22)+128-wide FFMLP, batch=512k; % fp16-MFMA peak",
 }
+
+
+POOL = 4  # pre-generated batches, visited in turn: the step is timed on fresh samples, not on one batch its scatter plan was cut for
+
+
+def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=None):
+    """`steps` timed trainer->training_step(input, target) calls (trainer.h:163-190) of workload `name` after `warmup` untimed ones.
+    Every 4th timed step also records HIP events on the launch stream around its pieces (tcnn_trainer_profile_next_step: events
+    without the system-scope fence; a record costs a few microseconds of dispatch, hence not on every step)."""
+    n_in, n_out, _, cfg = WORKLOADS[name]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    xs = [torch.rand((batch, n_in), device="cuda", generator=gen) for _ in range(POOL)]
+    ts = [torch.rand((batch, n_out), device="cuda", generator=gen) for _ in range(POOL)]
+    tr = tcnn.Trainer(n_in, n_out, cfg, seed=1337)
+    if barrier is None:
+        barrier = torch.cuda.synchronize
+    ctx = None
+    for i in range(warmup):
+        ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
+    loss0 = tr.loss(ctx) if ctx is not None else float("nan")
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i % 4 == 0:
+            tr.profile_next_step()
+        ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    loss1 = tr.loss(ctx)
+    pieces, n_profiled = tr.profile_collect()
+    n_params = tr.n_params
+    del tr, xs, ts, ctx
+    return {"elapsed": elapsed, "n_params": n_params, "pieces": pieces, "n_profiled": n_profiled, "loss0": loss0, "loss1": loss1}
+
+
+def mlp_param_count(name):
+    """Parameters of the workload's MLP: matrices [W x in_padded], (h - 1) x [W x W], [16 x W] (fully_fused_mlp.cu:656-671)."""
+    n_in, n_out, _, cfg = WORKLOADS[name]
+    enc, net = cfg["encoding"], cfg["network"]
+    if enc["otype"] == "HashGrid":
+        enc_out = enc["n_levels"] * enc["n_features_per_level"]
+    elif enc["otype"] == "OneBlob":
+        enc_out = n_in * enc["n_bins"]
+    else:
+        enc_out = n_in
+    in_padded = -(-enc_out // 16) * 16
+    w, h = net["n_neurons"], net["n_hidden_layers"]
+    return w * in_padded + (h - 1) * w * w + (-(-n_out // 16) * 16) * w
+
+
+def grid_gather_bytes(name, batch):
+    """algorithmic bytes of the grid encoding's forward gather (and of its backward scatter): B x L x 2^D x F x 2."""
+    n_in, _, _, cfg = WORKLOADS[name]
+    enc = cfg["encoding"]
+    if enc["otype"] != "HashGrid":
+        return None
+    return batch * enc["n_levels"] * (1 << n_in) * enc["n_features_per_level"] * 2
+
+
+def other_configs(tcnn, torch):
+    """The other BASELINE configurations, short runs after the headline's timed region (same process, rank 0 of a single-GPU run):
+    {c2, c3b, c5: training_step; c4: inference} -> ms_per_step, value, the fraction of the fp16 MFMA peak of the MLP kernel."""
+    out = {}
+    for name, steps, warmup in (("c3b", 40, 10), ("c2", 100, 20), ("c5", 12, 4)):
+        try:
+            batch = WORKLOADS[name][2]
+            m = measure_training(tcnn, torch, name, batch, steps, warmup)
+            ms = m["elapsed"] / steps * 1e3
+            mlp_ms = m["pieces"]["mlp_kernel"]
+            tf = FLOP_PER_SAMPLE[name] * batch / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+            out[name] = {"metric": METRIC[name], "ms_per_step": ms, "value": batch * steps / m["elapsed"], "unit": "samples/s", "batch": batch, "steps": steps,
+                         "roofline": {"bound": "mfma", "kernel": MLP_KERNEL[name], "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "avg_launch_ms": mlp_ms},
+                         "pieces_ms": {k: m["pieces"][k] for k in ("encode", "mlp_kernel", "encoding_backward", "optimizer")}}
+        except Exception as e:  # the headline line must not die with an extra measurement
+            out[name] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+    try:
+        steps = 60
+        m = c4_measure(steps, 10, 1)
+        tf = C4_ROWS * C4_FLOP_PER_ROW / (m["stream_ms_per_step"] * 1e-3) / 1e12
+        out["c4"] = {"metric": "inference throughput (rows/s) FullyFusedMLP 128x4, batch=1M", "ms_per_step": m["elapsed"] / steps * 1e3, "value": C4_ROWS * steps / m["elapsed"], "unit": "rows/s",
+                     "batch": C4_ROWS, "steps": steps,
+                     "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<128>", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "avg_launch_ms": m["stream_ms_per_step"]}}
+    except Exception as e:
+        out["c4"] = {"error": repr(e)[:200]}
+    return out
 
 
 def launch_ranks(n):
@@ -227,6 +345,7 @@ def main():
     ap.add_argument("--workload", default="c3a", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configurations behind the headline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the timing collectives (tests: gloo)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "none"], help="none: launcher / collective plumbing only, no GPU work (CPU tests)")
     args = ap.parse_args()
@@ -246,8 +365,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # one rank per GPU; with fewer GPUs than ranks (a rehearsal of the N > 1 path on a one-GPU box, gloo only) the ranks share them
-        local_rank %= max(torch.cuda.device_count(), 1)
+        local_rank = ranks_device(torch, local_rank, args.backend)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
     else:
@@ -258,15 +376,6 @@ def main():
     n_in, n_out, batch, cfg = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(42 + rank)
-    # a small pool of batches, visited in turn: the step is timed on fresh samples, not on one batch its scatter plan was cut for
-    POOL = 4
-    xs = [torch.rand((batch, n_in), device="cuda", generator=gen) for _ in range(POOL)]
-    ts = [torch.rand((batch, n_out), device="cuda", generator=gen) for _ in range(POOL)]
-
-    tr = tcnn.Trainer(n_in, n_out, cfg, seed=1337)
-    n_params = tr.n_params
 
     def barrier():
         torch.cuda.synchronize()
@@ -274,39 +383,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx = None
-    for i in range(args.warmup):
-        ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
-    loss0 = tr.loss(ctx) if ctx is not None else float("nan")
-
-    # Every step is trainer->training_step(input, target) (trainer.h:163-190).  Every 4th one also records HIP events on the launch
-    # stream around its pieces (tcnn_trainer_profile_next_step: events without the system-scope fence; a record costs a few
-    # microseconds of dispatch, hence not on every step).
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i % 4 == 0:
-            tr.profile_next_step()
-        ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
-    barrier()
-    elapsed = time.perf_counter() - t0
-
+    m = measure_training(tcnn, torch, args.workload, batch, args.steps, args.warmup, seed=42 + rank, barrier=barrier)
+    elapsed, n_params, pieces, n_profiled, loss0, loss1 = m["elapsed"], m["n_params"], m["pieces"], m["n_profiled"], m["loss0"], m["loss1"]
     if world > 1:
         el = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
-    loss1 = tr.loss(ctx)
-    pieces, n_profiled = tr.profile_collect()
 
     sharded = None
     if world > 1:  # the path that shards, on the same ranks: rows over the GPUs + one RCCL all-gather per step
+        # allocations first, on every rank, and a vote: a rank that cannot set up (out of memory) must not leave the others waiting
+        # in the measurement's collectives -- either all ranks measure or none does, and the headline line is printed either way
+        setup, err = None, None
         try:
-            m = c4_measure(max(args.steps // 4, 10), 5, world)
-            sharded = {"metric": "inference throughput (rows/s) FullyFusedMLP 128x4, batch=1M, rows sharded + all_gather of half outputs", "value": C4_ROWS * max(args.steps // 4, 10) / m["elapsed"],
-                       "unit": "rows/s", "ms_per_step": m["elapsed"] / max(args.steps // 4, 10) * 1e3, "rows_per_gpu": m["rows_per_gpu"], "scaling": "strong",
+            setup = c4_setup()
+        except Exception as e:
+            err = repr(e)[:300]
+        ok = torch.tensor([1 if setup is not None else 0], device="cuda", dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            n_sh = max(args.steps // 4, 10)
+            m = c4_measure(n_sh, 5, world, setup)
+            sharded = {"metric": "inference throughput (rows/s) FullyFusedMLP 128x4, batch=1M, rows sharded + all_gather of half outputs", "value": C4_ROWS * n_sh / m["elapsed"],
+                       "unit": "rows/s", "ms_per_step": m["elapsed"] / n_sh * 1e3, "rows_per_gpu": m["rows_per_gpu"], "scaling": "strong",
                        "output_checksum": m["checksum"]}
-        except Exception as e:  # the headline line must not die with the extra measurement
-            sharded = {"error": repr(e)[:300]}
+        else:
+            sharded = {"error": err or "another rank could not set the sharded inference up"}
+        del setup
 
     if rank == 0:
         step_ms = elapsed / args.steps * 1e3
@@ -319,7 +422,8 @@ def main():
         adam_gbs = adam_bytes / (pieces["optimizer"] * 1e-3) / 1e9 if pieces["optimizer"] > 0 else 0.0
         # compulsory HBM bytes of a step: Adam's ADAM_BYTES_PER_PARAM per parameter, the half gradient table written and the half table read once
         # more by the forward pass, and per sample the inputs (4 n_in), targets (4 n_out) and the half outputs (2 x 16)
-        grid_params = max(n_params - 7168, 0) if args.workload in ("c3a", "c3b") else n_params
+        gather_bytes = grid_gather_bytes(args.workload, batch)
+        grid_params = max(n_params - mlp_param_count(args.workload), 0)
         floor_bytes = adam_bytes + 2 * grid_params + batch * (4 * n_in + 4 * n_out + 32)
         result = {
             "metric": METRIC[args.workload],
@@ -344,6 +448,8 @@ def main():
                          "share_of_step": mlp_ms / step_ms if step_ms > 0 else None,
                          "pieces": {"encode_ms": pieces["encode"], "mlp_kernel_ms": mlp_ms, "encoding_backward_ms": pieces["encoding_backward"],
                                     "optimizer_ms": pieces["optimizer"],
+                                    "encode_hbm": hbm_piece(ENCODE_KERNEL.get(args.workload), gather_bytes, pieces["encode"]),
+                                    "encoding_backward_hbm": hbm_piece(SCATTER_KERNEL.get(args.workload), gather_bytes, pieces["encoding_backward"]),
                                     "optimizer_hbm": {"kernel": "k_adam", "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": adam_gbs / HBM_PEAK_GBS,
                                                       "bytes_per_launch": adam_bytes}},
                          "hbm_floor_frac": floor_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if step_ms > 0 else None,
@@ -351,6 +457,8 @@ def main():
         }
         if sharded is not None:
             result["c4_sharded_inference"] = sharded
+        if world == 1 and args.workload == "c3a" and not args.batch and not args.no_other_configs:
+            result["other_configs"] = other_configs(tcnn, torch)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(result), flush=True)

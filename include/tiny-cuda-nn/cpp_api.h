@@ -4,7 +4,7 @@
 #pragma once
 
 #include "../tcnn_amd.h"
-#include "json_lite.h"
+#include "json_select.h"
 
 #include <cstddef>
 #include <cstdint>
@@ -15,7 +15,7 @@
 
 namespace tcnn { namespace cpp {
 
-using json = tcnn_amd::Json;
+using json = tcnn::json;
 typedef void* stream_t; // hipStream_t
 
 enum class LogSeverity { Info = TCNN_LOG_INFO, Debug = TCNN_LOG_DEBUG, Warning = TCNN_LOG_WARNING, Error = TCNN_LOG_ERROR, Success = TCNN_LOG_SUCCESS }; // cpp_api.h:52-58

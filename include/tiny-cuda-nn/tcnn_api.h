@@ -3,7 +3,7 @@
 // any C++14 compiler, link with -ltcnn_amd.
 //
 // What is mirrored (reference file:line):
-//   tcnn::json                                     nlohmann::json as used by config.h:53 / the samples' config literals
+//   tcnn::json                                     nlohmann::json as used by config.h:53 / the samples' config literals (the real one when <json/json.hpp> is on the include path)
 //   tcnn::GPUMemory<T>                             gpu_memory.h:60-392   (allocation, host <-> device copies, memset)
 //   tcnn::GPUMatrixDynamic<T>, GPUMatrix<T, L>     gpu_matrix.h:115-470  (m x n, column-major by default = [n][m] in memory)
 //   tcnn::Loss<T>, create_loss<T>                  loss.h:48-77, src/loss.cu:54-68          (L2, RelativeL2)
@@ -19,7 +19,7 @@
 #pragma once
 
 #include "../tcnn_amd.h"
-#include "json_lite.h"
+#include "json_select.h" // tcnn::json: nlohmann::json where <json/json.hpp> is on the include path, else json_lite.h's
 #include "random.h" // trainer.h includes random.h in the reference: callers get default_rng_t / generate_random_uniform from config.h
 
 #include <cstdint>
@@ -31,7 +31,6 @@
 
 namespace tcnn {
 
-using json = tcnn_amd::Json;
 typedef void* stream_t; // hipStream_t (cudaStream_t in the reference)
 
 static constexpr uint32_t BATCH_SIZE_GRANULARITY = 256; // common.h:235
@@ -276,7 +275,7 @@ public:
 		const void* bytes = nullptr;
 		size_t size = 0;
 		detail::check(tcnn_trainer_serialize(m_handle, serialize_optimizer ? 1 : 0, &bytes, &size));
-		return json::from_msgpack((const uint8_t*)bytes, size);
+		return json::from_msgpack(std::vector<uint8_t>((const uint8_t*)bytes, (const uint8_t*)bytes + size));
 	}
 	void deserialize(const json& data) {
 		const std::vector<uint8_t> bytes = json::to_msgpack(data);

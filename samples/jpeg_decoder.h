@@ -107,7 +107,12 @@ struct BitReader {
 		throw std::runtime_error{"JPEG: invalid Huffman code"};
 	}
 	static int extend(int v, int n) { return n == 0 ? 0 : (v < (1 << (n - 1)) ? v - (1 << n) + 1 : v); } // T.81 F.2.2.1
-	int receive_extend(int n) { return extend(get_bits(n), n); }
+	// n comes from a Huffman table of the FILE (0..255): a magnitude category beyond 16 bits is not JPEG (T.81 F.1.2.1.1: DC <= 11,
+	// AC <= 10 for 8-bit samples) and would shift by more than the word
+	int receive_extend(int n) {
+		if (n < 0 || n > 16) throw std::runtime_error{"JPEG: magnitude category out of range"};
+		return extend(get_bits(n), n);
+	}
 };
 
 inline void idct_block(const int16_t* in, const uint16_t* q, uint8_t* out, int stride) {
@@ -196,6 +201,8 @@ inline Image decode(const uint8_t* data, size_t size) {
 			width = seg[3] << 8 | seg[4];
 			const int nc = seg[5];
 			if (width <= 0 || height <= 0) throw std::runtime_error{"JPEG: empty image"};
+			// a header can ask for 65535 x 65535: bound what the coefficient and pixel buffers may take (a training image, not a scan of a wall)
+			if ((size_t)width * (size_t)height > ((size_t)1 << 28)) throw std::runtime_error{"JPEG: image larger than 2^28 pixels is refused"};
 			if ((nc != 1 && nc != 3) || seg_len < 6 + 3 * nc) throw std::runtime_error{"JPEG: only 1 or 3 components are supported"};
 			comps.resize((size_t)nc);
 			for (int c = 0; c < nc; ++c) {
@@ -222,6 +229,7 @@ inline Image decode(const uint8_t* data, size_t size) {
 			restart_interval = seg[0] << 8 | seg[1];
 		} else if (marker == 0xDA) { // SOS + entropy-coded data
 			if (!have_frame) throw std::runtime_error{"JPEG: scan before frame header"};
+			if (seg_len < 1) throw std::runtime_error{"JPEG: bad scan header"};
 			const int ns = seg[0];
 			if (ns < 1 || ns > (int)comps.size() || seg_len < 4 + 2 * ns) throw std::runtime_error{"JPEG: bad scan header"};
 			Component* sc[3];

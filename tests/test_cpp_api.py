@@ -37,6 +37,23 @@ def test_header_api_compiles_and_host_checks_pass(binary):
     assert "host checks ok" in r.stdout
 
 
+NLOHMANN_INCLUDE = "/root/reference/dependencies"  # the reference vendors nlohmann::json there as json/json.hpp (a header its callers already have)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(NLOHMANN_INCLUDE, "json", "json.hpp")), reason="nlohmann/json.hpp (vendored by the reference) is not on this machine")
+def test_header_api_with_the_real_nlohmann_json(tcnn, tmp_path):
+    """With <json/json.hpp> on the include path tcnn::json IS nlohmann::json (tcnn_api.h): the same caller, host checks included
+    (the MessagePack known answers are then nlohmann's own bytes: they pin json_lite.h's encoder to the real one)."""
+    out = str(tmp_path / "header_api_nlohmann")
+    hip = _hip_libdir()
+    cmd = ["g++", "-std=c++14", "-Wall", "-Werror", "-Wno-deprecated-declarations", "-O1", f"-I{os.path.join(ROOT, 'include')}", f"-I{NLOHMANN_INCLUDE}", "-DEXPECT_NLOHMANN_JSON", SRC,
+           f"-L{LIBDIR}", "-ltcnn_amd", f"-Wl,-rpath,{LIBDIR}", f"-Wl,-rpath,{hip}", f"-Wl,-rpath-link,{hip}", "-o", out]
+    subprocess.check_call(cmd)
+    r = subprocess.run([out, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host checks ok" in r.stdout
+
+
 def test_reference_include_names_exist():
     """Callers include <tiny-cuda-nn/config.h>, <tiny-cuda-nn/trainer.h>, ...: each name the hot path's callers use must resolve."""
     inc = os.path.join(ROOT, "include", "tiny-cuda-nn")

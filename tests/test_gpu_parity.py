@@ -518,8 +518,11 @@ def test_torch_module_pads_batch(tcnn, oracle):
 
 
 def test_torch_module_working_copy_follows_the_master(tcnn, oracle):
-    """The half copy of the fp32 master parameters is kept between calls and rebuilt whenever the master changes: in-place
-    updates (an optimizer step), `load_state_dict`, and a replaced `.data`.  Gradients still arrive at the fp32 master."""
+    """By default the half copy of the fp32 master parameters is cast on every call (like the reference binding), so ANY write to
+    the master shows in the next forward pass -- also one through `.data` (torch_ema's copy_to / restore, `p.data.clamp_()`), which
+    bumps no version counter.  With `reuse_working_copy = True` the copy is kept between calls and rebuilt whenever the master's
+    version or address changes (an optimizer step, `load_state_dict`, a replaced `.data`); writes through `.data` then need
+    `invalidate_working_copy()`.  Gradients arrive at the fp32 master either way."""
     import torch
 
     m = tcnn.NetworkWithInputEncoding(2, 3, CONFIG_C3B["encoding"], CONFIG_C3B["network"])
@@ -528,6 +531,17 @@ def test_torch_module_working_copy_follows_the_master(tcnn, oracle):
     def fresh():
         return tcnn.modules._Evaluate.apply(x, m.params.detach().half(), m.native_tcnn_module, m.loss_scale)[:, :3]
 
+    # default: nothing is kept
+    with torch.no_grad():
+        y0 = m(x)
+        assert m._working_copy is None and torch.equal(y0, fresh())
+        m.params.data.copy_(m.params.data * 0.5)  # through .data: version and address unchanged
+        y_half = m(x)
+        assert torch.equal(y_half, fresh()) and not torch.equal(y_half, y0)
+        m.params.data.mul_(2.0)
+        assert torch.equal(m(x), y0)
+
+    m.reuse_working_copy = True
     with torch.no_grad():
         y0 = m(x)
         copy0 = m._working_copy
@@ -544,6 +558,12 @@ def test_torch_module_working_copy_follows_the_master(tcnn, oracle):
         m.load_state_dict(state)
         assert torch.equal(m(x), fresh())
         m.params.data = m.params.data * 2.0
+        assert torch.equal(m(x), fresh())
+        # the documented limit of the reuse, and its remedy
+        kept = m(x)
+        m.params.data.copy_(m.params.data * 0.5)
+        assert torch.equal(m(x), kept) and not torch.equal(kept, fresh())
+        m.invalidate_working_copy()
         assert torch.equal(m(x), fresh())
     # two graphs alive at once, built from the same kept copy
     a, b = m(x), m(x)

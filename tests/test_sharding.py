@@ -49,7 +49,7 @@ def _row_fn(x):
     return torch.stack([x.sum(1), (x * x).sum(1), x[:, 0] - x[:, -1]], dim=1)
 
 
-def _worker(rank, world, port, n, results):
+def _worker(rank, world, port, n, results, chunks=1, half=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,12 +61,17 @@ def _worker(rank, world, port, n, results):
 
         def infer(rows):
             calls.append(rows.shape[0])
-            return _row_fn(rows)
+            y = _row_fn(rows)
+            return y.half() if half else y  # Trainer.inference_half returns halves
 
-        out = par.sharded_inference(infer, x, 3)
+        out = par.sharded_inference(infer, x, 3, chunks=chunks)
         want = _row_fn(x)
+        if half:
+            want = want.half()
         b, e = par.shard_rows(n, world, rank)
-        ok = bool(torch.equal(out, want)) and calls == ([e - b] if e > b else [])
+        chunked = chunks > 1 and n % (chunks * world * 256) == 0
+        want_calls = [n // chunks // world] * chunks if chunked else ([e - b] if e > b else [])
+        ok = bool(torch.equal(out, want)) and out.dtype == want.dtype and calls == want_calls
         results[rank] = ok
     finally:
         dist.destroy_process_group()
@@ -86,6 +91,27 @@ def test_sharded_inference_gloo_world2(n):
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n, results), nprocs=world, join=True)
+    assert dict(results) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("n,chunks", [(4096, 4), (2048, 2), (1024, 4)])  # the last one cannot be cut that way: one gather
+def test_sharded_inference_chunked_overlap_gloo_world2(n, chunks):
+    """chunks > 1: the batch as `chunks` consecutive row ranges, each sharded over the ranks, the gather of one range issued
+    asynchronously before the next range is evaluated (the 8-GPU exchange of BASELINE config 4 is longer than its kernel)."""
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, results, chunks), nprocs=world, join=True)
+    assert dict(results) == {0: True, 1: True}
+
+
+def test_sharded_inference_half_outputs_with_an_empty_shard_gloo_world2():
+    """n = 256 on two ranks: rank 1 has no rows and cannot learn the output dtype from infer_fn; the ranks agree on it, so the
+    exchange buffers have the same dtype (and byte size) everywhere -- with RCCL a mismatch hangs or corrupts."""
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), 256, results, 1, True), nprocs=world, join=True)
     assert dict(results) == {0: True, 1: True}
 
 

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -1576,7 +1577,21 @@ public:
 	}
 	bool fused_step_supported(uint32_t n) const { return use_fused_step() && mlp_train_fused_supported(m_network->desc(), n); }
 	// the register-resident fused kernel (k_train_regs.hip) writes dL_doutput / L as compact [n][dims] matrices (TrainContext::compact)
-	bool fused_compact_context_supported(uint32_t n) const { return use_fused_step() && mlp_train_regs_supported(m_network->desc(), n) && m_network->padded_output_width() == 16; }
+	bool fused_compact_context_supported(uint32_t n) const {
+		const bool ok = use_fused_step() && mlp_train_regs_supported(m_network->desc(), n) && m_network->padded_output_width() == 16;
+		// the register-resident kernels address [n][...] matrices with 32-bit byte offsets: beyond 2^22 rows the step silently took the
+		// much slower LDS-image kernel -- say so once (a caller can split the batch)
+		if (!ok && use_fused_step() && n > (1u << 22) && mlp_train_regs_supported(m_network->desc(), 1u << 22)) {
+			static bool told = false;
+			if (!told) {
+				told = true;
+				const std::string msg = "training_step: batches of more than 4194304 rows run the general fused MLP kernel (several times slower for this network); split the batch to stay on the fast path";
+				log_message(TCNN_LOG_WARNING, msg);
+				fprintf(stderr, "tcnn_amd warning: %s\n", msg.c_str());
+			}
+		}
+		return ok;
+	}
 
 	// forward + loss + backward of a training step with the MLP part as ONE kernel (k_train.hip): same results as
 	// forward() -> loss_evaluate() -> backward(), activations never leave the CU.  out / dL_dout / L: [n][padded_out].

@@ -263,13 +263,18 @@ def _pad_rows(x, multiple):
 
 
 class _WorkingCopy(torch.autograd.Function):
-    """The parameters in the module's working precision.  The cast is the only per-call cost that grows with the model (67 MB read
-    + 22 MB written for the C3a grid), so the copy is kept and reused until the fp32 master changes: every in-place update
-    (optimizer steps, `load_state_dict`, `copy_`) bumps the tensor's version counter, a replaced `.data` changes its address.
-    The gradient goes back as a plain cast to fp32."""
+    """The parameters in the module's working precision.  By default this is a cast on every call, like the reference binding
+    (modules.py:205 there: `self.params.to(_torch_precision(...))`).  The cast is the only per-call cost that grows with the model
+    (67 MB read + 22 MB written for the C3a grid), so a module can be told to keep the copy between calls
+    (`module.reuse_working_copy = True`): it is then rebuilt when the fp32 master's version counter or address changes -- optimizer
+    steps, `load_state_dict`, `copy_` on the parameter, a replaced `.data`.  Writes THROUGH `.data` (`p.data.copy_(ema)`, as
+    torch_ema's copy_to / restore do, `p.data.clamp_()`) change neither: after such a write call `invalidate_working_copy()`, or
+    leave the reuse off.  The gradient goes back as a plain cast to fp32."""
 
     @staticmethod
     def forward(ctx, params, owner):
+        if not owner.reuse_working_copy:
+            return params.detach().to(owner.dtype).contiguous()
         key = (params._version, params.data_ptr(), params.device)
         if owner._working_key != key:
             owner._working_copy = params.detach().to(owner.dtype).contiguous()
@@ -298,6 +303,13 @@ class Module(torch.nn.Module):
         precision = self.native_tcnn_module.param_precision()
         self.dtype = _torch_precision(precision)
         self.loss_scale = _C.default_loss_scale(precision)
+        self._working_copy, self._working_key = None, None
+        if not hasattr(self, "reuse_working_copy"):
+            self.reuse_working_copy = False  # opt-in (see _WorkingCopy): the default casts on every call like the reference
+
+    def invalidate_working_copy(self):
+        """Forget the kept half-precision copy of the parameters (needed after writes through `params.data` when
+        `reuse_working_copy` is on: those do not show in the parameter's version counter)."""
         self._working_copy, self._working_key = None, None
 
     def forward(self, x):

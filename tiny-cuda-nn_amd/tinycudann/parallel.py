@@ -23,27 +23,68 @@ def shard_rows(n_rows, world_size, rank, granularity=BATCH_SIZE_GRANULARITY):
     return min(begin_u * granularity, n_rows), min(end_u * granularity, n_rows)
 
 
-def sharded_inference(infer_fn, x, n_out, group=None, out_dtype=None):
+_DTYPE_CODES = [torch.float32, torch.float16, torch.bfloat16, torch.float64]
+
+
+def _agreed_dtype(local_dtype, group, device):
+    """The output dtype when some rank has no rows to learn it from: the ranks that have rows say what infer_fn returned (one small
+    all-reduce; which shards are empty is known on every rank, so every rank makes the same calls)."""
+    code = torch.tensor([_DTYPE_CODES.index(local_dtype) + 1 if local_dtype is not None else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(code, op=dist.ReduceOp.MAX, group=group)
+    if int(code.item()) == 0:
+        return torch.float32
+    return _DTYPE_CODES[int(code.item()) - 1]
+
+
+def sharded_inference(infer_fn, x, n_out, group=None, out_dtype=None, chunks=1):
     """Every rank holds the full input `x` [n, n_in] (or at least its own rows); rank r evaluates rows shard_rows(...) with
     `infer_fn(x_rows) -> [rows, n_out]` and all ranks end up with the full [n, n_out] output, in the dtype infer_fn returns
     (half for Trainer.inference_half: SURVEY 8e's 4 MB per GPU for BASELINE config 4) unless out_dtype says otherwise.
 
     One collective: all_gather_into_tensor -- 7 simultaneous point-to-point transfers per GPU on a fully connected xGMI node
     rather than a ring.  Equal shards (n a multiple of world_size x 256, e.g. config 4) are gathered straight into the result;
-    ragged ones go through padded buffers."""
+    ragged ones go through padded buffers.  The dtype is the same on every rank also when a rank has no rows (n < world_size x
+    256): it is then agreed on with one small all-reduce.
+
+    chunks > 1 (and n a multiple of chunks x world_size x 256): the batch is cut into `chunks` consecutive row ranges, each of them
+    sharded over the ranks; the gather of range i runs (asynchronously, on the collective's stream) while the ranks evaluate range
+    i + 1 -- at 8 GPUs config 4's exchange (7 x 4 MB inbound per GPU) is longer than its kernel, so only overlap hides either."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = x.shape[0]
+    if world > 1 and chunks > 1 and n > 0 and n % (chunks * world * BATCH_SIZE_GRANULARITY) == 0:
+        rows = n // chunks       # rows of a range
+        mine = rows // world     # ... of which this rank evaluates `mine`
+        out, works = None, []
+        for i in range(chunks):
+            b = i * rows + rank * mine
+            local = infer_fn(x[b : b + mine])
+            if out_dtype is not None:
+                local = local.to(out_dtype)
+            if out is None:
+                out = torch.empty((n, n_out), dtype=local.dtype, device=x.device)
+            works.append((dist.all_gather_into_tensor(out[i * rows : (i + 1) * rows], local.contiguous(), group=group, async_op=True), local))
+        for w, _keep in works:  # `local` stays referenced until its gather has completed
+            w.wait()
+        return out
     begin, end = shard_rows(n, world, rank)
+    shards = [shard_rows(n, world, r) for r in range(world)]
+    any_empty = any(e == b for b, e in shards)
     if end > begin:
         local = infer_fn(x[begin:end])
         if out_dtype is not None:
             local = local.to(out_dtype)
+        dtype = local.dtype
     else:
-        local = torch.empty((0, n_out), dtype=out_dtype or torch.float32, device=x.device)
+        local, dtype = None, out_dtype
+    if world > 1 and any_empty and out_dtype is None:
+        dtype = _agreed_dtype(dtype, group, x.device)
+        if local is not None and local.dtype != dtype:
+            raise RuntimeError("sharded_inference: infer_fn returned different dtypes on different ranks")
+    if local is None:
+        local = torch.empty((0, n_out), dtype=dtype or torch.float32, device=x.device)
     if world == 1:
         return local
-    shards = [shard_rows(n, world, r) for r in range(world)]
     max_rows = max(e - b for b, e in shards)
     if all(e - b == max_rows for b, e in shards):  # the shards tile the result in rank order: no padding, no copies
         out = torch.empty((n, n_out), dtype=local.dtype, device=x.device)
