@@ -485,10 +485,23 @@ def test_oneblob_inside_the_training_kernel_is_bit_identical(tcnn, oracle, monke
             monkeypatch.delenv(k)
         return res
 
-    fused, plain = run({}), run({"TCNN_AMD_FUSE_ONEBLOB": "0"})
+    # the LDS-image kernel of k_train.hip (TCNN_AMD_MLP_R32=0) with and without the encoding inside: the same arithmetic
+    old = {"TCNN_AMD_MLP_R32": "0"}
+    fused, plain = run(old), run({**old, "TCNN_AMD_FUSE_ONEBLOB": "0"})
     for a, b in zip(fused, plain):
         assert np.array_equal(a, b)
     assert np.any(fused[3] != 0)
+    # the default for this shape, k_mlp_train_r32ob (32x32x16 matrix instruction: k = 16 per instruction, other fp32 summation order):
+    # the same features (the inputs at and beyond the ends of the unit interval included), everything after them within fp16 rounding
+    new = run({})
+    o1, o0 = _f32(new[0]).reshape(n, 16), _f32(plain[0]).reshape(n, 16)
+    assert np.mean(new[0] != plain[0]) < 0.02 and float(np.max(np.abs(o1 - o0))) <= 4e-3 * max(1.0, float(np.max(np.abs(o0))))
+    assert np.all(_f32(new[2]).reshape(n, 16)[:, 3:] == 0) and np.all(new[1].view(np.float32).reshape(n, 16)[:, 3:] == 0)
+    l1, l0 = new[1].view(np.float32), plain[1].view(np.float32)
+    assert abs(float(l1.sum()) - float(l0.sum())) <= 2e-3 * abs(float(l0.sum()))
+    for k in (3, 4):  # gradients of the third step, parameters after it
+        a, b = _f32(new[k]), _f32(plain[k])
+        assert float(np.linalg.norm(a - b)) <= 1e-2 * float(np.linalg.norm(b)), k
 
 
 def test_batch_size_granularity_error(tcnn):

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libtcnn_amd.so")
-SOURCES = ["k_grid.hip", "k_grid_planes.hip", "k_grid_scatter.hip", "k_grid_bin.hip", "k_grid_bwdbwd.hip", "k_encodings.hip", "k_ppng.hip", "k_mlp.hip", "k_train.hip", "k_train_regs.hip", "k_train_r32.hip", "k_misc.hip", "capi.cpp"]
-HEADERS = ["tcnn_common.h", "grid_device.h", "grid_fixed.h", "mlp_device.h", "mlp_side_jobs.h", "adam_device.h", "oneblob_device.h", "model.h", "json_lite.h", os.path.join("..", "..", "include", "tcnn_amd.h"),
+SOURCES = ["k_grid.hip", "k_grid_planes.hip", "k_grid_scatter.hip", "k_grid_bin.hip", "k_grid_bwdbwd.hip", "k_encodings.hip", "k_ppng.hip", "k_mlp.hip", "k_train.hip", "k_train_regs.hip", "k_train_r32.hip", "k_train_r32ob.hip", "k_misc.hip", "capi.cpp"]
+HEADERS = ["tcnn_common.h", "grid_device.h", "grid_fixed.h", "mlp_device.h", "r32_device.h", "mlp_side_jobs.h", "adam_device.h", "oneblob_device.h", "model.h", "json_lite.h", os.path.join("..", "..", "include", "tcnn_amd.h"),
            os.path.join("..", "..", "include", "tiny-cuda-nn", "json_lite.h")]
 # -ffp-contract=off: fused multiply-adds only where the source says fma (bit-exact grid arithmetic, see k_grid.hip)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-unused-result",
@@ -28,7 +28,9 @@ def _newest(paths):
 # k_train_regs.hip: the "max-ilp" strategy of the AMDGPU machine scheduler batches the LDS reads of the weight fragments ahead of the
 # MFMAs that use them instead of placing each right before its use (measured on C3a: the trip loop of k_mlp_train_regs 32.9 k ->
 # 30.3 k clocks, the kernel 26.4 -> 25.7 us; 236 registers, no spills).
-EXTRA_FLAGS = {"k_train_regs.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "k_train_r32.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+EXTRA_FLAGS = {"k_train_regs.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "k_train_r32.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+               # k_train_r32ob.hip keeps its weight-gradient accumulators in AGPRs through inline assembly; the builtins' results must then stay in VGPRs
+               "k_train_r32ob.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _compile(src):

@@ -815,7 +815,8 @@ bool mlp_train_fused_supported(const MlpDesc& d, uint32_t n) {
 	return cfg.ok && n % cfg.s == 0 && n > 0;
 }
 
-uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n) {
+uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n, uint32_t oneblob_bins, uint32_t oneblob_dims) {
+	if (oneblob_bins && mlp_train_r32ob_shape(d, n, oneblob_bins, oneblob_dims)) return mlp_train_r32ob_grid(n); // mlp_train_fused: the same test
 	if (mlp_train_regs_supported(d, n)) return mlp_train_regs_grid(d, n);
 	const TrainConfig cfg = pick_config(d);
 	if (!cfg.ok) return 0;
@@ -829,6 +830,9 @@ void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, ui
                      const void* external_dL_dy, uint32_t dims, LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, void* dL_dx,
                      uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims, float* slabs, uint32_t n_params, const MlpOneBlobInput* oneblob) {
 	CHECK_THROW(!oneblob || mlp_train_fused_oneblob_supported(d, n, oneblob->n_bins));
+	if (!compact_context && mlp_train_r32ob_applies(d, n, oneblob, data_pdf, external_dL_dy, dims, loss, out, dL_dx, slabs)) {
+		return mlp_train_r32ob(stream, d, image, n, *oneblob, target, dims, loss, loss_scale, out, dL_dout, L, slabs, n_params);
+	}
 	if (mlp_train_regs_supported(d, n) && slabs != nullptr) { // without weight gradients (GradientMode::Ignore): the kernels below
 		CHECK_THROW(compact_context || external_dL_dy);
 		return mlp_train_regs(stream, d, image, n, x, x_plane_features, target, data_pdf, external_dL_dy, dims, loss, loss_scale, out, dL_dout, L, dL_dx, dx_plane_features,

@@ -1662,7 +1662,7 @@ public:
 		uint32_t n_slabs = 0;
 		if (mode != GradientMode::Ignore) {
 			CHECK_THROW(gradients != nullptr);
-			n_slabs = mlp_train_fused_grid(d, n);
+			n_slabs = mlp_train_fused_grid(d, n, ctx.oneblob_bins, ctx.oneblob_bins ? m_encoding->input_width() : 0u);
 			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
 		}
 		const MlpOneBlobInput oneblob_input{input, m_encoding->input_width(), ctx.oneblob_bins};

@@ -241,7 +241,7 @@ void mlp_backward(hipStream_t stream, const MlpDesc& d, const void* image, uint3
 // ---- the Trainer's fused step (k_train.hip): forward + loss + backward + weight gradients in one kernel.
 // Supported when out_width <= 32, width in {64, 128} and the activations of one trip fit in LDS; else use the pieces above.
 bool mlp_train_fused_supported(const MlpDesc& d, uint32_t n);
-uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n); // workgroups = number of weight-gradient slabs
+uint32_t mlp_train_fused_grid(const MlpDesc& d, uint32_t n, uint32_t oneblob_bins = 0, uint32_t oneblob_dims = 0); // workgroups = number of weight-gradient slabs (oneblob_*: the encoding is evaluated inside the kernel)
 // x [n][in_width] half (x_plane_features = 0) or level planes [in_width / F][n][F] (x_plane_features = F in {2, 4, 8}).
 // target / data_pdf [n][dims] float or external_dL_dy [n][out_width] half (loss-scaled).
 // compact_context (only where mlp_train_regs_supported() and slabs != nullptr): dL_dout and L are the COMPACT matrices [n][dims]
@@ -273,6 +273,14 @@ bool mlp_train_r32_applies(const MlpDesc& d, uint32_t n, uint32_t x_plane_featur
                            const void* dL_dx, uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims);
 void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, uint32_t dims, LossType loss, float loss_scale, void* out,
                    void* compact_dL_dout, float* compact_L, void* dL_dx, const float* dx_record_x, float* slabs, uint32_t n_params, uint32_t grid);
+// ---- BASELINE config 2's step, OneBlob(64 bins, 2 dims) -> 64 -> 64 -> 16 with the encoding evaluated in the kernel, on the 32x32x16
+// matrix instruction (k_train_r32ob.hip): one wave per SIMD, weight-gradient accumulators in AGPRs.  mlp_train_fused dispatches to it.
+bool mlp_train_r32ob_shape(const MlpDesc& d, uint32_t n, uint32_t n_bins, uint32_t n_dims);
+uint32_t mlp_train_r32ob_grid(uint32_t n);
+bool mlp_train_r32ob_applies(const MlpDesc& d, uint32_t n, const MlpOneBlobInput* oneblob, const float* data_pdf, const void* external_dL_dy, uint32_t dims, LossType loss, const void* out,
+                             const void* dL_dx, const float* slabs);
+void mlp_train_r32ob(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const MlpOneBlobInput& oneblob, const float* target, uint32_t dims, LossType loss, float loss_scale,
+                     void* out, void* dL_dout, float* L, float* slabs, uint32_t n_params);
 void mlp_expand_context(hipStream_t stream, uint32_t n, uint32_t dims, const void* compact_dL_dout, const float* compact_L, void* dL_dout, float* L);
 // grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once
 void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate);
