@@ -15,6 +15,6 @@ for grp in "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_V
            "SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d gpurun_out/${tag}_sq$i -o p -- python bench.py --steps 12 --warmup 4 --no-cpu-baseline > gpurun_out/${tag}_sq$i.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d gpurun_out/${tag}_sq$i -o p -- python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-other-configs > gpurun_out/${tag}_sq$i.log 2>&1
   python tools/pmc.py gpurun_out/${tag}_sq$i ${KERNELS:-k_mlp_train}
 done
