@@ -377,6 +377,44 @@ def test_training_step_matches_oracle(tcnn, oracle, cfg, n_in, n):
     assert tr.optimizer_step_count() == 1
 
 
+@pytest.mark.parametrize("base,n_out,loss,n", [(CONFIG_C3B, 1, "L2", 256), (CONFIG_C3B, 2, "RelativeL2", 512), (CONFIG_C3A, 4, "L2", 2048), (CONFIG_C3B, 3, "L2", 256 * 33),
+                                               (CONFIG_C2, 1, "L2", 256), (CONFIG_C2, 4, "RelativeL2", 2048), (CONFIG_C2, 2, "L2", 256 * 9)])
+def test_r32_kernels_other_output_counts_losses_and_batches(tcnn, oracle, monkeypatch, base, n_out, loss, n):
+    """The 32x32x16 training kernels (k_mlp_train_r32: grid configs; k_mlp_train_r32ob: OneBlob config) beyond BASELINE's 3 outputs
+    and RelativeL2: 1, 2 and 4 outputs (their two output slots per lane: both live, one dead, the odd lane half dead), the L2 loss,
+    batches that leave most waves without a block (256 = 8 blocks of 32) or give the waves unequal trip counts.  Against the oracle
+    like test_training_step_matches_oracle, and against the other kernel of the same step (TCNN_AMD_MLP_R32=0) within fp16 rounding."""
+    n_in = 2
+    cfg = {**base, "loss": {"otype": loss}}
+    ref = oracle.Trainer(n_in, n_out, cfg, seed=1337)
+    x, t = oracle.synthetic_batch(n, n_in, n_out, seed=17)
+    grads32 = np.zeros(ref.model.n_params, dtype=np.float32)
+    want = ref.training_step(x, t, run_optimizer=False, grads_f32=grads32)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(n_in, n_out, cfg, seed=1337)
+        ctx = tr.training_step(_t(x), _t(t), run_optimizer=False)
+        res = (_f32(_bits(ctx.output())), ctx.L().cpu().numpy(), _f32(_bits(ctx.dL_doutput())), _f32(_bits(tr.param_gradients())), tr.loss(ctx))
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
+
+    out, L, dy, g, l = run({})
+    assert rel_err(out[:, :n_out], _f32(want["output"])[:, :n_out]) < 1e-2
+    assert abs(l - want["loss"]) <= 2e-2 * abs(want["loss"]) and rel_err(L, want["L"]) < 3e-2
+    assert np.all(L[:, n_out:] == 0) and np.all(dy[:, n_out:] == 0) and np.any(dy[:, :n_out] != 0)
+    n_net = ref.model.network.n_params
+    assert rel_err(g[:n_net], grads32[:n_net]) < 3e-2
+    if ref.model.encoding.n_params > 0:
+        ge, we = g[n_net:], grads32[n_net:]
+        assert float(np.linalg.norm(ge - we)) <= 5e-2 * float(np.linalg.norm(we)) and np.all(ge[we == 0] == 0)
+    out0, L0, dy0, g0, l0 = run({"TCNN_AMD_MLP_R32": "0"})
+    assert float(np.max(np.abs(out - out0))) <= 4e-3 * max(1.0, float(np.max(np.abs(out0)))) and abs(l - l0) <= 1e-4 * abs(l0)
+    assert float(np.linalg.norm(g - g0)) <= 5e-3 * float(np.linalg.norm(g0))
+
+
 @pytest.mark.parametrize("cfg,n_in", [(CONFIG_C3B, 2), (CONFIG_C1, 2)])
 def test_adam_step_matches_oracle(tcnn, oracle, cfg, n_in):
     """adam.h:48-119 on IDENTICAL gradients (copied into the trainer's gradient buffer): fp32 master weights within 1e-5
