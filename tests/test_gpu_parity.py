@@ -761,6 +761,38 @@ def test_adam_in_the_scatter_flush_is_bit_identical(tcnn, oracle, cfg, n_in, n, 
     assert steps.max() == len(batches) and steps.min() < len(batches)  # some parameters missed updates: the skip is exercised
 
 
+@pytest.mark.parametrize("cfg,n", [(CONFIG_C2, 8192), (CONFIG_C1, 4096)])
+def test_adam_behind_the_slab_reduction_is_bit_identical(tcnn, oracle, cfg, n, monkeypatch):
+    """Models without encoding parameters (BASELINE configs 2 and 1): the optimizer's update of the network's weights is applied by the
+    kernel that sums the weight-gradient slabs (k_wgrad_reduce_adam, the default) instead of a k_adam launch behind it
+    (TCNN_AMD_ADAM_IN_REDUCE=0): the same adam_one on the same half gradients -- weights (fp32 master and half), both moments and
+    the step counts agree bit for bit over several steps."""
+    import msgpack
+
+    batches = [oracle.synthetic_batch(n, 2, 3, seed=40 + i) for i in range(4)]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, cfg, seed=1337)
+        for x, t in batches:
+            tr.training_step(_t(x), _t(t))
+        state = msgpack.unpackb(tr.serialize(True), raw=False)
+        for k in env:
+            monkeypatch.delenv(k)
+        return _bits(tr.params()), tr.params_full_precision().cpu().numpy().view(np.uint32), state["optimizer"], _bits(tr.param_gradients()), tr.params_updated_in_flush()
+
+    half_a, fp_a, opt_a, g_a, n_a = run({})
+    half_b, fp_b, opt_b, g_b, n_b = run({"TCNN_AMD_ADAM_IN_REDUCE": "0"})
+    # config 1's 32-wide network does not take the fused step (no slabs to ride on): both runs are then the same path
+    assert n_b == 0 and n_a == (len(half_a) if cfg is CONFIG_C2 else n_a), "which kernel applied the update is not what this run asked for"
+    assert np.array_equal(g_a, g_b) and np.any(g_a != 0)
+    assert np.array_equal(fp_a, fp_b) and np.array_equal(half_a, half_b)
+    assert opt_a["current_step"] == opt_b["current_step"] == len(batches)
+    for key in ("first_moments_binary", "second_moments_binary", "param_steps_binary"):
+        assert opt_a[key] == opt_b[key], key
+
+
 def test_adam_step_counts_are_kept_narrow_and_widened_losslessly(tcnn, oracle, monkeypatch):
     """The per-parameter update counts live as uint16 while the optimizer's own step count is below 65 535 and are widened to uint32
     before one could overflow (AdamOptimizer::ensure_step_width): weights, moments and the counts a snapshot reports are bit-identical

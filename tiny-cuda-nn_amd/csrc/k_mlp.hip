@@ -22,6 +22,7 @@
 //   Layer 0 reads its B operand from memory ([n][in] half, 16 bytes per lane) in natural order k = 32 s + 8 q + j.
 #include "mlp_device.h"
 #include "mlp_side_jobs.h"
+#include "adam_device.h"
 #include "oneblob_device.h"
 
 namespace tcnn_amd {
@@ -530,6 +531,34 @@ __global__ void __launch_bounds__(WR_ELEMS * WR_GROUPS) k_wgrad_reduce(const uin
 	mlp_reduce_block(part, blockIdx.x, threadIdx.x, n_elems, cols, ldg, n_slabs, slabs, grad, accumulate); // mlp_side_jobs.h: the grid scatter can carry this along
 }
 
+// The same reduction with the optimizer's update behind it (AdamInFlush, tcnn_common.h): a matrix weight's gradient is final the moment
+// its slabs are summed, so adam.h:48-119 runs on it at once -- the same adam_one as k_adam, on the same half-rounded gradient: the same
+// bits.  For networks without encoding parameters (BASELINE config 2) this IS the optimizer step: one ~4 us launch less.
+template <typename STEP_T>
+__global__ void __launch_bounds__(WR_ELEMS * WR_GROUPS) k_wgrad_reduce_adam(const uint32_t n_elems, const uint32_t n_slabs, const float* __restrict__ slabs, half_t* __restrict__ grad,
+                                                                            const AdamInFlush adam) {
+	__shared__ float part[WR_GROUPS * WR_ELEMS];
+	mlp_reduce_block(part, blockIdx.x, threadIdx.x, n_elems, n_elems, n_elems, n_slabs, slabs, grad, 0);
+	const uint32_t e = threadIdx.x & (WR_ELEMS - 1), grp = threadIdx.x / WR_ELEMS;
+	const uint32_t i = blockIdx.x * WR_ELEMS + e;
+	if (grp != 0 || i >= n_elems) return;
+	const half_t g = grad[i]; // written by this very thread a moment ago
+	float w_fp = adam.w_fp[i], m1 = adam.m1[i], m2 = adam.m2[i];
+	STEP_T* steps = (STEP_T*)adam.steps;
+	uint32_t step = steps[i];
+	half_t w_h;
+	bool updated;
+	const float* __restrict__ table = adam.debias_table;
+	adam_one(adam.args, [&](const uint32_t t) { return table[t]; }, table[adam.args.common_step], /*is_matrix=*/true, g, w_fp, w_h, m1, m2, step, updated);
+	if (updated) {
+		adam.w_fp[i] = w_fp;
+		((half_t*)adam.w_half)[i] = w_h;
+		adam.m1[i] = m1;
+		adam.m2[i] = m2;
+		steps[i] = (STEP_T)step;
+	}
+}
+
 // kernel_activation_backward_output (common_device.h:748): dL/d(pre-activation output) from the forward OUTPUT values
 __global__ void __launch_bounds__(256) k_act_bwd_output(const uint32_t n_elems, const uint32_t act, const half_t* __restrict__ dL_dout, const half_t* __restrict__ out, half_t* __restrict__ result) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -659,9 +688,16 @@ void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32
 	hipLaunchKernelGGL(k_act_bwd_output, dim3(div_round_up(n_elems, 256)), dim3(256), 0, stream, n_elems, activation, (const half_t*)dL_dout, (const half_t*)out, (half_t*)result);
 }
 
-void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate) {
+void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate, const AdamInFlush* adam) {
 	if (n_params == 0) return;
-	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_params, (uint32_t)WR_ELEMS)), dim3(WR_ELEMS * WR_GROUPS), 0, stream, n_params, n_params, n_params, n_slabs, slabs, (half_t*)grad_half, accumulate ? 1 : 0);
+	const dim3 grid(div_round_up(n_params, (uint32_t)WR_ELEMS)), block(WR_ELEMS * WR_GROUPS);
+	if (adam && !accumulate) {
+		if (adam->steps16) hipLaunchKernelGGL(k_wgrad_reduce_adam<uint16_t>, grid, block, 0, stream, n_params, n_slabs, slabs, (half_t*)grad_half, *adam);
+		else hipLaunchKernelGGL(k_wgrad_reduce_adam<uint32_t>, grid, block, 0, stream, n_params, n_slabs, slabs, (half_t*)grad_half, *adam);
+	} else {
+		hipLaunchKernelGGL(k_wgrad_reduce, grid, block, 0, stream, n_params, n_params, n_params, n_slabs, slabs, (half_t*)grad_half, accumulate ? 1 : 0);
+	}
+	HIP_CHECK_THROW(hipGetLastError());
 }
 
 size_t wgrad_workspace_floats(uint32_t rows, uint32_t cols, uint32_t n) { return (size_t)wgrad_grid(n) * rows * cols; }

@@ -1576,6 +1576,8 @@ public:
 		return !(e && e[0] == '0');
 	}
 	bool fused_step_supported(uint32_t n) const { return use_fused_step() && mlp_train_fused_supported(m_network->desc(), n); }
+	// the fused step of a model without encoding parameters hands its weight gradients to the optimizer inside the slab reduction
+	bool optimizer_rides_on_reduce() const { return m_encoding->n_params() == 0; }
 	// the register-resident fused kernel (k_train_regs.hip) writes dL_doutput / L as compact [n][dims] matrices (TrainContext::compact)
 	bool fused_compact_context_supported(uint32_t n) const {
 		const bool ok = use_fused_step() && mlp_train_regs_supported(m_network->desc(), n) && m_network->padded_output_width() == 16;
@@ -1683,8 +1685,15 @@ public:
 			reduce_job.slabs = slabs.as<float>();
 			reduce_job.grad = g;
 			reduce_job.accumulate = mode == GradientMode::Accumulate ? 1 : 0;
-			if (!(need_dx && side_jobs_enabled())) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
-			else ctx.encoding_ctx.reduce_job = &reduce_job;
+			if (!(need_dx && side_jobs_enabled())) {
+				// a model whose only parameters are the network's: the optimizer's update rides on the reduction (k_wgrad_reduce_adam)
+				const bool with_adam = adam && adam_done && !need_dx && m_encoding->n_params() == 0 && mode == GradientMode::Overwrite;
+				mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate, with_adam ? adam : nullptr);
+				if (with_adam) {
+					adam_done->clear();
+					adam_done->emplace_back((size_t)0, (size_t)n_net);
+				}
+			} else ctx.encoding_ctx.reduce_job = &reduce_job;
 		}
 		if (need_dx) {
 			if (profile) profile->mark(stream, StepProfile::EncodingBackward, false);
@@ -2716,6 +2725,12 @@ public:
 		const char* e = getenv("TCNN_AMD_ADAM_IN_FLUSH");
 		return e && e[0] == '1';
 	}
+	// TCNN_AMD_ADAM_IN_REDUCE=0: models without encoding parameters (BASELINE config 2) run the optimizer as a launch of its own again
+	// instead of behind the weight gradients' slab reduction (k_wgrad_reduce_adam; bit-identical, one ~4 us launch less per step)
+	static bool adam_in_reduce_enabled() {
+		const char* e = getenv("TCNN_AMD_ADAM_IN_REDUCE");
+		return !(e && e[0] == '0');
+	}
 
 	void optimizer_step(hipStream_t stream, float loss_scale) { // trainer.h:155-157
 		m_optimizer->step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data());
@@ -2757,7 +2772,7 @@ public:
 			// the owner of a chunk updates its parameters as it flushes); what they did not take is done afterwards.
 			AdamInFlush adam;
 			ParamRanges adam_done;
-			const bool split = run_optimizer && mode == GradientMode::Overwrite && adam_in_flush_enabled() &&
+			const bool split = run_optimizer && mode == GradientMode::Overwrite && (adam_in_flush_enabled() || (adam_in_reduce_enabled() && m_model->optimizer_rides_on_reduce())) &&
 			                   m_optimizer->begin_split_step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), adam);
 			ctx->model_ctx = m_model->fused_step(stream, n, input, target, data_pdf, external_dL_dy, m_loss, loss_scale, ctx->output.data(),
 			                                     ctx->compact ? ctx->compact_dL_doutput.data() : ctx->dL_doutput.data(),

@@ -283,7 +283,9 @@ void mlp_train_r32ob(hipStream_t stream, const MlpDesc& d, const void* image, ui
                      void* out, void* dL_dout, float* L, float* slabs, uint32_t n_params);
 void mlp_expand_context(hipStream_t stream, uint32_t n, uint32_t dims, const void* compact_dL_dout, const float* compact_L, void* dL_dout, float* L);
 // grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once
-void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate);
+// adam (optional, not with accumulate): the optimizer's update of these (matrix) weights is applied behind the reduction, bit-identical to adam_step run afterwards
+struct AdamInFlush;
+void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, const float* slabs, void* grad_half, bool accumulate, const AdamInFlush* adam = nullptr);
 // fully_fused_mlp.cu:757-762: result = dL_dout * act'(out), elementwise over n_elems halfs
 void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32_t activation, const void* dL_dout, const void* out, void* result);
 // dW[rows x cols] = sum_i dO[i][rows]^T In[i][cols]; result written as half into grad (overwrite or accumulate). workspace: float[wgrad_workspace_floats()]
