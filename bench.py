@@ -13,7 +13,7 @@ of the reference that shards (rows over the GPUs, one RCCL all-gather of the hal
 
 The JSON line carries `roofline` for the step's MFMA kernel, the fused MLP training kernel (BASELINE metric: "% fp16-MFMA
 peak"; SURVEY 8d: achieved = samples/s of the kernel x 38 016 FLOP), timed live with HIP events on the launch stream inside
-the timed region on every 4th step (tcnn_trainer_profile_next_step), with the other pieces of the step beside it
+the timed region on every 8th step (tcnn_trainer_profile_next_step), with the other pieces of the step beside it
 (`roofline.pieces`: encoding forward, encoding backward, optimizer against the HBM peak; `hbm_floor_frac`: the step's
 compulsory HBM bytes over the whole step time), and `cpu_baseline`: the CPU oracle (a port of the reference algorithm, the
 reference has no CPU path) timed on a bounded sample on rank 0.
@@ -238,8 +238,8 @@ POOL = 4  # pre-generated batches, visited in turn: the step is timed on fresh s
 
 def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=None):
     """`steps` timed trainer->training_step(input, target) calls (trainer.h:163-190) of workload `name` after `warmup` untimed ones.
-    Every 4th timed step also records HIP events on the launch stream around its pieces (tcnn_trainer_profile_next_step: events
-    without the system-scope fence; a record costs a few microseconds of dispatch, hence not on every step)."""
+    Every 8th timed step also records HIP events on the launch stream around its pieces (tcnn_trainer_profile_next_step: events
+    without the system-scope fence; the eight records of such a step cost it ~10 us of dispatch bubbles, hence not on every step)."""
     n_in, n_out, _, cfg = WORKLOADS[name]
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
@@ -255,7 +255,7 @@ def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=N
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        if i % 4 == 0:
+        if i % 8 == 0:
             tr.profile_next_step()
         ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
     barrier()
