@@ -224,7 +224,7 @@ def pmc_traffic(kernel, workload):
 
 
 FLOP_PER_SAMPLE = {"c3a": 38016, "c3b": 38016, "c2": 58496, "c5": 149760}  # useful FLOP of one training sample (unpadded outputs)
-MLP_KERNEL = {"c3a": "k_mlp_train_r32", "c3b": "k_mlp_train_r32", "c2": "k_mlp_train_r32ob", "c5": "k_mlp_train"}
+MLP_KERNEL = {"c3a": "k_mlp_train_r32", "c3b": "k_mlp_train_r32", "c2": "k_mlp_train_r32ob", "c5": "k_mlp_train_r32w"}
 METRIC = {
     "c3a": "training_step throughput (samples/s) HashGrid+64-wide FFMLP, batch=256k; % fp16-MFMA peak",
     "c3b": "training_step throughput (samples/s) HashGrid(T=2^15)+64-wide FFMLP, batch=256k; % fp16-MFMA peak",

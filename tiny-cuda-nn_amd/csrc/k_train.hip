@@ -833,6 +833,9 @@ void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, ui
 	if (!compact_context && mlp_train_r32ob_applies(d, n, oneblob, data_pdf, external_dL_dy, dims, loss, out, dL_dx, slabs)) {
 		return mlp_train_r32ob(stream, d, image, n, *oneblob, target, dims, loss, loss_scale, out, dL_dout, L, slabs, n_params);
 	}
+	if (!compact_context && mlp_train_r32w_applies(d, n, x_plane_features, data_pdf, external_dL_dy, dims, loss, out, dL_dx, dx_plane_features, dx_record_x, slabs, oneblob != nullptr)) {
+		return mlp_train_r32w(stream, d, image, n, x, target, dims, loss, loss_scale, out, dL_dout, L, dL_dx, slabs, n_params, mlp_train_fused_grid(d, n));
+	}
 	if (mlp_train_regs_supported(d, n) && slabs != nullptr) { // without weight gradients (GradientMode::Ignore): the kernels below
 		CHECK_THROW(compact_context || external_dL_dy);
 		return mlp_train_regs(stream, d, image, n, x, x_plane_features, target, data_pdf, external_dL_dy, dims, loss, loss_scale, out, dL_dout, L, dL_dx, dx_plane_features,

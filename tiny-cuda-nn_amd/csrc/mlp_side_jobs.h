@@ -36,8 +36,11 @@ struct R32Frags {
 	__host__ __device__ uint32_t bwd0() const { return bwd_out() + wt + (nh - 1) * wt * ksw; }
 	__host__ __device__ uint32_t n_frags() const { return bwd0() + it * ksw; }
 };
-// networks that get the section: (16 | 32 | 128) -> 64 -> [64 ->] 16
-__host__ __device__ inline bool r32_shape_ok(const MlpDesc& d) { return d.width == 64 && (d.in_width == 16 || d.in_width == 32 || d.in_width == 128) && d.out_width == 16 && d.n_hidden >= 1 && d.n_hidden <= 2; }
+// networks that get the section: (16 | 32 | 128) -> 64 -> [64 ->] 16 and 64 -> 128 -> 128 -> 16
+__host__ __device__ inline bool r32_shape_ok(const MlpDesc& d) {
+	if (d.out_width != 16 || d.n_hidden < 1 || d.n_hidden > 2) return false;
+	return (d.width == 64 && (d.in_width == 16 || d.in_width == 32 || d.in_width == 128)) || (d.width == 128 && d.in_width == 64 && d.n_hidden == 2);
+}
 
 __device__ inline _Float16 r32_prep_value(const MlpDesc& d, const _Float16* __restrict__ params, const uint32_t frag, const uint32_t lane, const uint32_t j) {
 	const R32Frags f(d);

@@ -281,6 +281,13 @@ bool mlp_train_r32ob_applies(const MlpDesc& d, uint32_t n, const MlpOneBlobInput
                              const void* dL_dx, const float* slabs);
 void mlp_train_r32ob(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const MlpOneBlobInput& oneblob, const float* target, uint32_t dims, LossType loss, float loss_scale,
                      void* out, void* dL_dout, float* L, float* slabs, uint32_t n_params);
+// ---- BASELINE config 5's MLP part, 64 -> 128 -> 128 -> 16 fed by level planes of 4 features, on the 32x32x16 matrix instruction
+// (k_train_r32w.hip): the weight-gradient tiles shared out over a workgroup's four waves, fragments from L2.  mlp_train_fused dispatches
+// to it with the grid of mlp_train_fused_grid.
+bool mlp_train_r32w_applies(const MlpDesc& d, uint32_t n, uint32_t x_plane_features, const float* data_pdf, const void* external_dL_dy, uint32_t dims, LossType loss, const void* out,
+                            const void* dL_dx, uint32_t dx_plane_features, const float* dx_record_x, const float* slabs, bool oneblob);
+void mlp_train_r32w(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, uint32_t dims, LossType loss, float loss_scale, void* out,
+                    void* dL_dout, float* L, void* dL_dx, float* slabs, uint32_t n_params, uint32_t grid);
 void mlp_expand_context(hipStream_t stream, uint32_t n, uint32_t dims, const void* compact_dL_dout, const float* compact_L, void* dL_dout, float* L);
 // grad[i] (=|+=) sum_k slabs[k][i], fixed order, rounded to half once
 // adam (optional, not with accumulate): the optimizer's update of these (matrix) weights is applied behind the reduction, bit-identical to adam_step run afterwards
