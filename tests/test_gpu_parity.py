@@ -418,6 +418,37 @@ def test_r32_kernels_other_output_counts_losses_and_batches(tcnn, oracle, monkey
     assert float(np.linalg.norm(g - g0)) <= 5e-3 * float(np.linalg.norm(g0))
 
 
+@pytest.mark.parametrize("n_out,loss,n", [(3, "RelativeL2", 1 << 14), (1, "L2", 256 * 33), (4, "L2", 256 * 5)])
+def test_r32a_kernel_agrees_with_r32(tcnn, monkeypatch, n_out, loss, n):
+    """k_mlp_train_r32a (TCNN_AMD_MLP_R32A=1: weights in registers, every weight-gradient tile summed by ONE wave of a workgroup over
+    the samples of all four, two workgroup barriers per trip) against k_mlp_train_r32: the chain is the same instruction sequence, so
+    outputs, loss values, dL/doutput and the grid's gradients (summed exactly from the same scatter records) are bit-identical; the
+    network's weight gradients differ in the order of the fp32 sums.  Batches: full trips, trips in which some waves of a workgroup
+    have no block (their images are zeros), fewer blocks than workgroups."""
+    cfg = {**CONFIG_C3B, "loss": {"otype": loss}}
+    rng = np.random.default_rng(5)
+    x = rng.random((n, 2), dtype=np.float32)
+    t = rng.random((n, n_out), dtype=np.float32)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, n_out, cfg, seed=1337)
+        ctx = tr.training_step(_t(x), _t(t), run_optimizer=False)
+        res = (_bits(ctx.output()).copy(), ctx.L().cpu().numpy().copy(), _bits(ctx.dL_doutput()).copy(), _bits(tr.param_gradients()).copy())
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
+
+    n_net = 32 * 64 + 64 * 64 + 64 * 16  # 32 -> 64 -> 64 -> 16 (padded output)
+    out, L, dy, g = run({})
+    out_a, L_a, dy_a, g_a = run({"TCNN_AMD_MLP_R32A": "1"})
+    assert np.array_equal(out, out_a) and np.array_equal(L, L_a) and np.array_equal(dy, dy_a)
+    assert np.array_equal(g[n_net:], g_a[n_net:])
+    gn, gn_a = _f32(g[:n_net]), _f32(g_a[:n_net])
+    assert np.any(gn != 0) and float(np.linalg.norm(gn - gn_a)) <= 2e-3 * float(np.linalg.norm(gn))
+
+
 @pytest.mark.parametrize("cfg,n_in", [(CONFIG_C3B, 2), (CONFIG_C1, 2)])
 def test_adam_step_matches_oracle(tcnn, oracle, cfg, n_in):
     """adam.h:48-119 on IDENTICAL gradients (copied into the trainer's gradient buffer): fp32 master weights within 1e-5

@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libtcnn_amd.so")
-SOURCES = ["k_grid.hip", "k_grid_planes.hip", "k_grid_scatter.hip", "k_grid_bin.hip", "k_grid_bwdbwd.hip", "k_encodings.hip", "k_ppng.hip", "k_mlp.hip", "k_train.hip", "k_train_regs.hip", "k_train_r32.hip", "k_train_r32ob.hip", "k_train_r32w.hip", "k_misc.hip", "capi.cpp"]
-HEADERS = ["tcnn_common.h", "grid_device.h", "grid_fixed.h", "mlp_device.h", "r32_device.h", "mlp_side_jobs.h", "adam_device.h", "oneblob_device.h", "model.h", "json_lite.h", os.path.join("..", "..", "include", "tcnn_amd.h"),
+SOURCES = ["k_grid.hip", "k_grid_planes.hip", "k_grid_scatter.hip", "k_grid_bin.hip", "k_grid_bwdbwd.hip", "k_encodings.hip", "k_ppng.hip", "k_mlp.hip", "k_train.hip", "k_train_regs.hip", "k_train_r32.hip", "k_train_r32a.hip", "k_train_r32ob.hip", "k_train_r32w.hip", "k_misc.hip", "capi.cpp"]
+HEADERS = ["tcnn_common.h", "grid_device.h", "grid_fixed.h", "mlp_device.h", "r32_device.h", "r32_train.h", "mlp_side_jobs.h", "adam_device.h", "oneblob_device.h", "model.h", "json_lite.h", os.path.join("..", "..", "include", "tcnn_amd.h"),
            os.path.join("..", "..", "include", "tiny-cuda-nn", "json_lite.h")]
 # -ffp-contract=off: fused multiply-adds only where the source says fma (bit-exact grid arithmetic, see k_grid.hip)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-unused-result",
@@ -31,6 +31,7 @@ def _newest(paths):
 EXTRA_FLAGS = {"k_train_regs.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "k_train_r32.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
                # k_train_r32ob.hip keeps its weight-gradient accumulators in AGPRs through inline assembly; the builtins' results must then stay in VGPRs
                "k_train_r32ob.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "k_train_r32a.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-mfma-vgpr-form"],
                "k_train_r32w.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 

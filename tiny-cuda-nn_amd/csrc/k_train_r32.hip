@@ -20,6 +20,7 @@
 //
 // Matrix work per 32 samples: 30 (chain) + 16 (weight gradients) instructions of 32 clocks.
 #include "r32_device.h"
+#include "r32_train.h"
 #include "mlp_side_jobs.h"
 
 #include <algorithm>
@@ -30,23 +31,6 @@
 namespace tcnn_amd {
 namespace {
 
-struct R32Args {
-	const half_t* x;        // level planes half2 [16][n]
-	const float* target;    // [n][dims]
-	half_t* out;            // [n][16]
-	half_t* dL_dout;        // compact [n][dims]
-	float* L;               // compact [n][dims]
-	u32x4* rec;             // scatter records [8][n]: {x, y, gradients of levels 2 p, 2 p + 1}
-	const float* rec_x;     // [n][2]
-	float* slabs;           // [gridDim.x][n_params]
-	const h8* image;        // R32 fragments
-	uint32_t n, dims, n_params;
-	uint32_t w_off[3];      // element offsets of W0, W1, Wout inside a slab
-	float loss_scale;
-	uint32_t stagger;        // TCNN_AMD_MLP_STAGGER: waves 4..7 start their first trip this many times 64 clocks late
-	uint32_t prio_mode;      // TCNN_AMD_MLP_PRIO: 0 no priorities, 1 the two waves of a SIMD alternate their priority per trip, 2 the younger half at priority 1, 3 a trip's matrix regions above its loss
-	unsigned long long* dbg; // TCNN_AMD_MLP_TIMING: per workgroup wave 0's clock at start / loop start / loop end / end, then every wave's loop end
-};
 
 constexpr int R32_NW = 8;                 // waves per workgroup
 constexpr int R32_NF = 30;                // weight fragments (R32Frags of 32 -> 64 -> 64 -> 16)
@@ -88,6 +72,9 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t c = lane & 31, h = lane >> 5;
 	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
+	if constexpr ((DIAG & 64) == 0) { // the device-wide 100 MHz clock (the cycle counter is per XCD), in the slots of the region stamps
+		if (a.dbg && tid == 0) a.dbg[(size_t)gridDim.x * (4 + R32_NW) + (size_t)blockIdx.x * 2 * R32_REGIONS] = __builtin_amdgcn_s_memrealtime();
+	}
 
 	const uint32_t n_blocks = a.n / 32;
 	const uint32_t first = blockIdx.x * R32_NW + wave, step = gridDim.x * R32_NW;
@@ -484,6 +471,9 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		if (pass == 0) __syncthreads(); // before the second pass overwrites the copies
 	}
 	if (a.dbg && tid == 0) a.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+	if constexpr ((DIAG & 64) == 0) {
+		if (a.dbg && tid == 0) a.dbg[(size_t)gridDim.x * (4 + R32_NW) + (size_t)blockIdx.x * 2 * R32_REGIONS + 1] = __builtin_amdgcn_s_memrealtime();
+	}
 }
 #undef R32_SB
 #undef R32_STAMP
@@ -508,6 +498,21 @@ bool mlp_train_r32_applies(const MlpDesc& d, uint32_t n, uint32_t x_plane_featur
 	       dL_dx != nullptr && dx_plane_features == 2 && dx_record_x != nullptr && dx_record_dims == 2;
 }
 
+// TCNN_AMD_MLP_R32A=1: k_mlp_train_r32a (k_train_r32a.hip: weights in registers, weight-gradient tiles shared out over a workgroup's
+// waves) instead of k_mlp_train_r32.  Measured equal (24.5 against 24.7 us on one device): kept for A/B runs
+static bool r32a_enabled() {
+	const char* e = getenv("TCNN_AMD_MLP_R32A");
+	return e && e[0] == '1';
+}
+// workgroups = weight-gradient slabs of the kernel mlp_train_r32 launches for this batch
+uint32_t mlp_train_r32_grid(uint32_t n) {
+	if (r32a_enabled()) {
+		static const uint32_t cap = getenv("TCNN_AMD_MLP_GRID") ? (uint32_t)std::max(1, atoi(getenv("TCNN_AMD_MLP_GRID"))) : 512u; // development knob
+		return std::max(1u, std::min(cap, div_round_up(n / 32, (uint32_t)R32A_NW))); // two workgroups of four waves per CU
+	}
+	return std::max(1u, std::min(256u, div_round_up(n / 32, (uint32_t)R32_NW)));
+}
+
 void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, uint32_t dims, LossType loss, float loss_scale, void* out,
                    void* compact_dL_dout, float* compact_L, void* dL_dx, const float* dx_record_x, float* slabs, uint32_t n_params, uint32_t grid) {
 	CHECK_THROW(slabs != nullptr && compact_dL_dout != nullptr && compact_L != nullptr && target != nullptr);
@@ -529,8 +534,8 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
 	static int timing_left = 5;
 	if (timing && timing_left > 0) {
-		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * (32 + 8 * R32_NW + 16 * R32_REGIONS)));
-		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * (32 + 8 * R32_NW + 16 * R32_REGIONS)));
+		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * 1024));
+		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * 1024));
 	}
 	auto go = [&](auto kernel) {
 		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R32_LDS_BYTES));
@@ -541,6 +546,59 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 	if (const char* e = getenv("TCNN_AMD_MLP_PRIO")) a.prio_mode = (uint32_t)atoi(e);
 	if (const char* e = getenv("TCNN_AMD_MLP_STAGGER")) a.stagger = (uint32_t)atoi(e);
 	static const int diag = getenv("TCNN_AMD_MLP_DIAG") ? atoi(getenv("TCNN_AMD_MLP_DIAG")) : 0;
+	CHECK_THROW(grid == mlp_train_r32_grid(n));
+	if (r32a_enabled()) {
+		mlp_train_r32a_launch(stream, a, grid, loss == LossType::L2 ? 1 : 2);
+		if (a.dbg) {
+			std::vector<unsigned long long> hst((size_t)grid * (7 + 4 * R32A_NW));
+			HIP_CHECK_THROW(hipMemcpy(hst.data(), a.dbg, hst.size() * 8, hipMemcpyDeviceToHost));
+			if (--timing_left == 0) {
+				double fill = 0, loop = 0, tail = 0;
+				unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+				for (uint32_t g = 0; g < grid; ++g) {
+					const unsigned long long t_fill = hst[(size_t)grid * (6 + 4 * R32A_NW) + g];
+					fill += (double)(t_fill - hst[g * 4]);
+					loop += (double)(hst[g * 4 + 2] - t_fill);
+					tail += (double)(hst[g * 4 + 3] - hst[g * 4 + 2]);
+					const unsigned long long st = hst[(size_t)grid * 4 + g * 2], en = hst[(size_t)grid * 4 + g * 2 + 1];
+					s0 = std::min(s0, st); s1 = std::max(s1, st);
+					e0 = std::min(e0, en); e1 = std::max(e1, en);
+				}
+				fprintf(stderr, "k_mlp_train_r32a wave 0 clocks, mean over %u workgroups: fill %.0f trips %.0f (%u blocks of 32 per wave) slab stores %.0f\n", grid, fill / grid, loop / grid,
+				        div_round_up(n / 32, grid * R32A_NW), tail / grid);
+				fprintf(stderr, "  workgroup starts spread over %.2f us, ends from %.2f to %.2f us after the first start\n", (s1 - s0) * 0.01, (e0 - s0) * 0.01, (e1 - s0) * 0.01);
+				{ // who ends when: by half of the grid (the two workgroups of a CU) and by XCD (workgroup b runs on XCD b % 8)
+					double by_half[2] = {}, by_xcd[8] = {};
+					for (uint32_t g = 0; g < grid; ++g) {
+						const double en = (hst[(size_t)grid * 4 + g * 2 + 1] - s0) * 0.01;
+						by_half[g >= grid / 2] += en / (grid / 2);
+						by_xcd[g % 8] += en / (grid / 8);
+					}
+					if (getenv("TCNN_AMD_MLP_WHERE")) { // one line per workgroup: XCC, SE, CU, start and end in us
+						for (uint32_t g = 0; g < grid; ++g) {
+							const unsigned long long hw = hst[g * 4 + 1];
+							fprintf(stderr, "  wg %u xcc %llu se %llu cu %llu start %.2f end %.2f\n", g, (hw >> 32) & 15, (hw >> 13) & 7, (hw >> 8) & 15, (hst[(size_t)grid * 4 + g * 2] - s0) * 0.01,
+							        (hst[(size_t)grid * 4 + g * 2 + 1] - s0) * 0.01);
+						}
+					}
+					fprintf(stderr, "  mean end: first half of the grid %.2f us, second half %.2f us; by XCD", by_half[0], by_half[1]);
+					for (int x = 0; x < 8; ++x) fprintf(stderr, " %.2f", by_xcd[x]);
+					fprintf(stderr, "\n");
+				}
+				for (int w = 0; w < R32A_NW; ++w) {
+					constexpr int NPH = 4;
+					double ph[NPH] = {};
+					for (uint32_t g = 0; g < grid; ++g)
+						for (int i = 0; i < NPH; ++i) ph[i] += (double)hst[(size_t)grid * 6 + ((size_t)g * R32A_NW + w) * NPH + i];
+					fprintf(stderr, "  wave %d clocks summed over its trips: chain %.0f, at the barrier %.0f, weight gradients %.0f, at the barrier %.0f", w, ph[0] / grid, ph[1] / grid, ph[2] / grid, ph[3] / grid);
+					for (int i = 4; i < NPH; ++i) fprintf(stderr, " %.0f", ph[i] / grid);
+					fprintf(stderr, "\n");
+				}
+			}
+			(void)hipFree(a.dbg);
+		}
+		return;
+	}
 	if (diag == 1) go(k_mlp_train_r32<2, 1>);
 	else if (diag == 2) go(k_mlp_train_r32<2, 2>);
 	else if (diag == 3) go(k_mlp_train_r32<2, 3>);
@@ -563,6 +621,15 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 			}
 			fprintf(stderr, "k_mlp_train_r32 wave 0 clocks, mean over %u workgroups: fill %.0f trips %.0f (%u blocks of 32 per wave) tail %.0f\n", grid, fill / grid, loop / grid,
 			        div_round_up(n / 32, grid * R32_NW), tail / grid);
+			if (diag != 64) { // the launch as a whole, on the device-wide 100 MHz clock
+				unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+				for (uint32_t g = 0; g < grid; ++g) {
+					const unsigned long long st = hst[(size_t)grid * (4 + R32_NW) + (size_t)g * 2 * R32_REGIONS], en = hst[(size_t)grid * (4 + R32_NW) + (size_t)g * 2 * R32_REGIONS + 1];
+					s0 = std::min(s0, st); s1 = std::max(s1, st);
+					e0 = std::min(e0, en); e1 = std::max(e1, en);
+				}
+				fprintf(stderr, "  workgroup starts spread over %.2f us, ends from %.2f to %.2f us after the first start\n", (s1 - s0) * 0.01, (e0 - s0) * 0.01, (e1 - s0) * 0.01);
+			}
 			double end_w[R32_NW] = {};
 			for (uint32_t g = 0; g < grid; ++g)
 				for (int w = 0; w < R32_NW; ++w) end_w[w] += (double)(hst[(size_t)grid * 4 + (size_t)g * R32_NW + w] - hst[g * 4]);

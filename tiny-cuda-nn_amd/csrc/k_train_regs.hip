@@ -638,7 +638,7 @@ void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uin
 	CHECK_THROW(external_dL_dy || (compact_dL_dout != nullptr && compact_L != nullptr));
 	// BASELINE configs 3 in the formats of the grid encoding's training step: the 32x32x16 kernel (k_train_r32.hip), same slabs
 	if (mlp_train_r32_applies(d, n, x_plane_features, data_pdf, external_dL_dy, dims, loss, out, dL_dx, dx_plane_features, dx_record_x, dx_record_dims)) {
-		return mlp_train_r32(stream, d, image, n, x, target, dims, loss, loss_scale, out, compact_dL_dout, compact_L, dL_dx, dx_record_x, slabs, n_params, mlp_train_regs_grid(d, n));
+		return mlp_train_r32(stream, d, image, n, x, target, dims, loss, loss_scale, out, compact_dL_dout, compact_L, dL_dx, dx_record_x, slabs, n_params, mlp_train_r32_grid(n));
 	}
 	RegsArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)compact_dL_dout, compact_L, (half_t*)dL_dx, slabs, (const h8*)image,
 	           dx_record_x, n, dims, dx_record_dims, x_plane_features, dx_plane_features, n_params, loss_scale, 1u, nullptr};

@@ -1664,7 +1664,10 @@ public:
 		uint32_t n_slabs = 0;
 		if (mode != GradientMode::Ignore) {
 			CHECK_THROW(gradients != nullptr);
-			n_slabs = mlp_train_fused_grid(d, n, ctx.oneblob_bins, ctx.oneblob_bins ? m_encoding->input_width() : 0u);
+			// the 32x32x16 kernels of BASELINE configs 3 have a grid of their own (k_train_r32.hip); the test is the one mlp_train_regs makes
+			const bool r32 = !ctx.oneblob_bins && mlp_train_regs_supported(d, n) && mlp_train_r32_applies(d, n, x_plane_f, data_pdf, external_dL_dy, m_network->output_width(), loss, out,
+			                                                           need_dx ? dL_dnetwork_input.data() : nullptr, plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u);
+			n_slabs = r32 ? mlp_train_r32_grid(n) : mlp_train_fused_grid(d, n, ctx.oneblob_bins, ctx.oneblob_bins ? m_encoding->input_width() : 0u);
 			slabs = ArenaBuf{stream, (size_t)n_slabs * n_net * sizeof(float)};
 		}
 		const MlpOneBlobInput oneblob_input{input, m_encoding->input_width(), ctx.oneblob_bins};

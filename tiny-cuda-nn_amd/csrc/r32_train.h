@@ -1,0 +1,32 @@
+// r32_train.h -- what k_train_r32.hip (host side, and the kernel with two waves per SIMD) and k_train_r32a.hip (the kernel with one wave per
+// SIMD and the weights in registers) share: the kernels' argument block and the second file's launch.
+#pragma once
+
+#include "r32_device.h"
+
+namespace tcnn_amd {
+
+struct R32Args {
+	const half_t* x;        // level planes half2 [16][n]
+	const float* target;    // [n][dims]
+	half_t* out;            // [n][16]
+	half_t* dL_dout;        // compact [n][dims]
+	float* L;               // compact [n][dims]
+	u32x4* rec;             // scatter records [8][n]: {x, y, gradients of levels 2 p, 2 p + 1}
+	const float* rec_x;     // [n][2]
+	float* slabs;           // [gridDim.x][n_params]
+	const h8* image;        // R32 fragments
+	uint32_t n, dims, n_params;
+	uint32_t w_off[3];      // element offsets of W0, W1, Wout inside a slab
+	float loss_scale;
+	uint32_t stagger;        // TCNN_AMD_MLP_STAGGER: waves 4..7 start their first trip this many times 64 clocks late
+	uint32_t prio_mode;      // TCNN_AMD_MLP_PRIO: 0 no priorities, 1 the two waves of a SIMD alternate their priority per trip, 2 the younger half at priority 1, 3 a trip's matrix regions above its loss
+	unsigned long long* dbg; // TCNN_AMD_MLP_TIMING: per workgroup wave 0's clock at start / loop start / loop end / end, then every wave's loop end
+};
+
+constexpr int R32A_NW = 4; // waves per workgroup of k_mlp_train_r32a: one per SIMD
+
+// loss_id 1: L2, 2: RelativeL2; grid = workgroups = slabs
+void mlp_train_r32a_launch(hipStream_t stream, const R32Args& a, uint32_t grid, int loss_id);
+
+} // namespace tcnn_amd

@@ -271,6 +271,7 @@ void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uin
 // LDS images.  mlp_train_regs dispatches to it (TCNN_AMD_MLP_R32=0: never); `grid` workgroups write one slab each.
 bool mlp_train_r32_applies(const MlpDesc& d, uint32_t n, uint32_t x_plane_features, const float* data_pdf, const void* external_dL_dy, uint32_t dims, LossType loss, const void* out,
                            const void* dL_dx, uint32_t dx_plane_features, const float* dx_record_x, uint32_t dx_record_dims);
+uint32_t mlp_train_r32_grid(uint32_t n); // workgroups (= slabs) of the launch: the caller sizes `slabs` with it
 void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint32_t n, const void* x, const float* target, uint32_t dims, LossType loss, float loss_scale, void* out,
                    void* compact_dL_dout, float* compact_L, void* dL_dx, const float* dx_record_x, float* slabs, uint32_t n_params, uint32_t grid);
 // ---- BASELINE config 2's step, OneBlob(64 bins, 2 dims) -> 64 -> 64 -> 16 with the encoding evaluated in the kernel, on the 32x32x16
