@@ -61,12 +61,12 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 
 	// ---- the weights.  Fragment slots (R32Frags of this network); resident: F1, FO, B1, B0 (24 fragments)
 	constexpr int F0 = 0, F1 = 4, FO = 12, BO = 16, B1 = 18, B0 = 26;
-	h8 w[30];
+	// The workgroup's four waves bring the 30 KiB from global memory ONCE, through LDS (the image area, not in use yet): every wave
+	// loading its own copy was 4 x the bytes through the L2 -> CU path, which set the length of this phase (5.4 k clocks)
+	constexpr int FILL = (30 * 64 + R32A_NW * 64 - 1) / (R32A_NW * 64);
+	h8 stage[FILL];
 #pragma unroll
-	for (int f = 0; f < 30; ++f) {
-		if ((f >= F0 && f < F1) || (f >= BO && f < B1)) continue;
-		w[f] = a.image[f * 64 + lane];
-	}
+	for (int k = 0; k < FILL; ++k) stage[k] = a.image[min(tid + k * R32A_NW * 64, 30u * 64u - 1u)];
 	// the other six: one 16-byte load per lane and use.  An opaque per-trip copy of the lane keeps the (loop-invariant) loads inside the trip loop
 	uint32_t lane_o = lane;
 	auto frag = [&](const int f) -> h8 { return a.image[f * 64 + lane_o]; };
@@ -107,10 +107,18 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 #pragma unroll
 	for (int i = 0; i < 4; ++i) f0[i] = frag(F0 + i);
 #pragma unroll
+	for (int k = 0; k < FILL; ++k) {
+		if (tid + k * R32A_NW * 64 < 30u * 64u) ((h8*)smem)[tid + k * R32A_NW * 64] = stage[k];
+	}
+	__syncthreads();
+	h8 w[30];
+#pragma unroll
 	for (int f = 0; f < 30; ++f) {
 		if ((f >= F0 && f < F1) || (f >= BO && f < B1)) continue;
+		w[f] = ((const h8*)smem)[f * 64 + lane];
 		asm volatile("" : "+a"(w[f]));
 	}
+	__syncthreads(); // the first trip's images overwrite the staging copy
 	const unsigned long long t_fill = a.dbg ? __builtin_readcyclecounter() : 0ull;
 
 	// ---- images (k_train_r32.hip): per wave and 32-feature tile 2 KiB, plane g (4 features) at 256 g, sample n inside it at 8 ((n + 4 g) & 31)
