@@ -184,6 +184,12 @@ int  tcnn_trainer_profile_collect(tcnn_trainer_t t, tcnn_stream_t stream, float*
  * the optimizer the usual way (the default; TCNN_AMD_ADAM_IN_FLUSH=1 asks for the fused form, which needs plain Adam, GradientMode
  * Overwrite, run_optimizer=true and a grid whose scatter runs in record form). */
 size_t tcnn_trainer_params_updated_in_flush(tcnn_trainer_t t);
+/* Introspection (no counterpart in the reference): how many times training_step() calls of this trainer have launched the kernel
+ * that rearranges the network's weights into matrix-instruction fragments.  A model without encoding parameters trained with plain
+ * Adam keeps those fragments current from inside its optimizer kernel, so the count stops growing after the first step -- until
+ * the parameters are set, restored, stepped by optimizer_step(), or a pointer to them has been handed out
+ * (tcnn_trainer_params / tcnn_trainer_params_full_precision: from then on every step rearranges them again). */
+size_t tcnn_trainer_image_preps(tcnn_trainer_t t);
 
 #ifdef __cplusplus
 }

@@ -827,6 +827,49 @@ def test_adam_behind_the_slab_reduction_is_bit_identical(tcnn, oracle, cfg, n, m
         assert opt_a[key] == opt_b[key], key
 
 
+def test_live_fragment_image_is_kept_current_by_the_optimizer_kernel(tcnn, oracle, monkeypatch):
+    """BASELINE config 2 (no encoding parameters, plain Adam): k_wgrad_reduce_adam writes every updated weight into the elements of the
+    network's fragment images that hold it, so only the first training step launches k_mlp_prep (Trainer.image_preps()).  Against
+    TCNN_AMD_LIVE_IMAGE=0 (k_mlp_prep every step): weights bit-identical over several steps, also across everything that changes the
+    parameters behind the image's back -- a step without the optimizer, set_params_full_precision(), optimizer_step() on its own, and a
+    parameter pointer handed out (after which no image is trusted beyond its step)."""
+    n = 2048
+    batches = [oracle.synthetic_batch(n, 2, 3, seed=60 + i) for i in range(9)]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, CONFIG_C2, seed=1337)
+        preps = []
+        for i, (x, t) in enumerate(batches):
+            if i == 2:
+                tr.training_step(_t(x), _t(t), run_optimizer=False)  # gradients only: the parameters stay, the image stays current
+                tr.optimizer_step()                                  # ... and now they change without the image
+            elif i == 4:
+                fp = _t(oracle.Pcg32(99).uniform_strided(tr.n_params, -0.3, 0.3).astype(np.float32))
+                tr.set_params_full_precision(fp)
+                tr.training_step(_t(x), _t(t))
+            elif i == 7:
+                first = _bits(tr.params()).copy()  # a pointer to the parameters leaves the library
+                tr.training_step(_t(x), _t(t))
+                assert np.any(_bits(tr.params()) != first)
+            else:
+                tr.training_step(_t(x), _t(t))
+            preps.append(tr.image_preps())
+        out = (_bits(tr.params()).copy(), tr.params_full_precision().cpu().numpy().view(np.uint32).copy(), preps)
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    half_a, fp_a, preps_a = run({})
+    half_b, fp_b, preps_b = run({"TCNN_AMD_LIVE_IMAGE": "0"})
+    assert np.array_equal(half_a, half_b) and np.array_equal(fp_a, fp_b)
+    assert preps_b == list(range(1, 10)), preps_b
+    # steps 0, 1: one launch; step 2 (no optimizer in the step): one more, and optimizer_step() invalidates; 3: one more; 4: set_params: one
+    # more; 5, 6: none; from step 7 on a pointer is out: one per step
+    assert preps_a == [1, 1, 2, 3, 4, 4, 4, 5, 6], preps_a
+
+
 def test_adam_step_counts_are_kept_narrow_and_widened_losslessly(tcnn, oracle, monkeypatch):
     """The per-parameter update counts live as uint16 while the optimizer's own step count is below 65 535 and are widened to uint32
     before one could overflow (AdamOptimizer::ensure_step_width): weights, moments and the counts a snapshot reports are bit-identical

@@ -125,6 +125,9 @@ __device__ inline void activate_pack(const f4 (&acc)[T][NB], h8 (&hf)[KS][NB], u
 // MFMA otherwise waits on a 1 KB fetch from L2.  Used for inference with NB = 4 column blocks per wave (one fragment read
 // feeds 4 MFMAs) and 8 waves per workgroup (2 per SIMD: one wave's activation VALU work under the other's MFMAs).
 // OB: the input is the OneBlob encoding of a.x_f32, evaluated in the layer-0 loop (a.oneblob_log2; instantiated for widths 64 and 128).
+#ifndef TCNN_MLP_FWD_PF
+#define TCNN_MLP_FWD_PF 3
+#endif
 template <int W, int NB, int ACT, bool IMG_LDS = false, int THREADS = 256, bool OB = false>
 __global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
 	constexpr int T = W / 16;
@@ -255,15 +258,18 @@ __global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdA
 			// fragment i are issued, in a second register set.  Written out in this order the compiler waits with lgkmcnt(1); as a
 			// plain "load, use" loop it reused ONE register quad and exposed the whole LDS latency before every group of MFMAs
 			// (measured on C4: the MFMA pipe 36 % busy).
-			h8 af_cur = frag(img);
+			// (PF = 1 fragment ahead covers 4 MFMAs = 64 clocks of a ~130-clock LDS read; TCNN_MLP_FWD_PF fragments ahead cover it whole)
+			constexpr int PF = IMG_LDS ? TCNN_MLP_FWD_PF : 1;
+			auto frag_of = [&](const int i) -> h8 { return frag(img + (i % T) * KS + i / T); };
+			h8 af[PF + 1];
+#pragma unroll
+			for (int i = 0; i < PF; ++i) af[i] = frag_of(i);
 #pragma unroll
 			for (int i = 0; i < KS * T; ++i) {
 				const int s = i / T, t = i % T;
-				h8 af_next = af_cur;
-				if (i + 1 < KS * T) af_next = frag(img + ((i + 1) % T) * KS + (i + 1) / T);
+				if (i + PF < KS * T) af[(i + PF) % (PF + 1)] = frag_of(i + PF);
 #pragma unroll
-				for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af_cur, hf[s][b], s == 0 ? f4{0, 0, 0, 0} : acc[t][b]); // first k-step: C = inline 0, no register clearing
-				af_cur = af_next;
+				for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af[i % (PF + 1)], hf[s][b], s == 0 ? f4{0, 0, 0, 0} : acc[t][b]); // first k-step: C = inline 0, no register clearing
 			}
 			activate_pack<T, KS, NB, ACT>(acc, hf, d.activation);
 			store_hidden(l);
@@ -556,6 +562,14 @@ __global__ void __launch_bounds__(WR_ELEMS * WR_GROUPS) k_wgrad_reduce_adam(cons
 		adam.m1[i] = m1;
 		adam.m2[i] = m2;
 		steps[i] = (STEP_T)step;
+		if (adam.image) { // keep the fragment images current (AdamInFlush::image): what k_mlp_prep would gather at the start of the next step
+			const uint4 where = *(const uint4*)(adam.image_inv + (size_t)IMAGE_INV_WIDTH * i);
+			half_t* image = (half_t*)adam.image;
+			if (where.x != 0xffffffffu) image[where.x] = w_h;
+			if (where.y != 0xffffffffu) image[where.y] = w_h;
+			if (where.z != 0xffffffffu) image[where.z] = w_h;
+			if (where.w != 0xffffffffu) image[where.w] = w_h;
+		}
 	}
 }
 

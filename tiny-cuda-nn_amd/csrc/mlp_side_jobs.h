@@ -42,52 +42,52 @@ __host__ __device__ inline bool r32_shape_ok(const MlpDesc& d) {
 	return (d.width == 64 && (d.in_width == 16 || d.in_width == 32 || d.in_width == 128)) || (d.width == 128 && d.in_width == 64 && d.n_hidden == 2);
 }
 
-__device__ inline _Float16 r32_prep_value(const MlpDesc& d, const _Float16* __restrict__ params, const uint32_t frag, const uint32_t lane, const uint32_t j) {
+// index into `params` of the weight that element (frag, lane, j) of the third section holds, -1: the element is zero
+__host__ __device__ inline int32_t r32_prep_source(const MlpDesc& d, const uint32_t frag, const uint32_t lane, const uint32_t j) {
 	const R32Frags f(d);
 	const uint32_t r = lane & 31, h = lane >> 5;
 	const MlpLayer L0 = d.layers[0], LO = d.layers[d.n_hidden];
 	if (frag < f.fwd_hidden(1)) { // layer 0, natural k
 		const uint32_t t = frag / f.ks0, s = frag - t * f.ks0;
-		return params[L0.w_off + (size_t)(32 * t + r) * L0.cols + 16 * s + 8 * h + j];
+		return (int32_t)(L0.w_off + (32 * t + r) * L0.cols + 16 * s + 8 * h + j);
 	}
 	if (frag < f.fwd_out()) {
 		const uint32_t local = frag - f.fwd_hidden(1), per = f.wt * f.ksw;
 		const uint32_t l = 1 + local / per, rem = local - (l - 1) * per, t = rem / f.ksw, ks = rem - t * f.ksw;
 		const MlpLayer L = d.layers[l];
-		return params[L.w_off + (size_t)(32 * t + r) * L.cols + r32_chain_k(ks, h, j)];
+		return (int32_t)(L.w_off + (32 * t + r) * L.cols + r32_chain_k(ks, h, j));
 	}
 	if (frag < f.bwd_out()) { // output layer: row = position
 		const uint32_t ks = frag - f.fwd_out();
-		if (r >= 16) return (_Float16)0.0f;
+		if (r >= 16) return -1;
 		const uint32_t o = 2 * ((r & 3) + 4 * (r >> 3)) + ((r >> 2) & 1);
-		return params[LO.w_off + (size_t)o * LO.cols + r32_chain_k(ks, h, j)];
+		return (int32_t)(LO.w_off + o * LO.cols + r32_chain_k(ks, h, j));
 	}
 	if (frag < f.bwd_hidden(1)) { // Wout^T: k = position (h, j) <-> output 2 j + h
 		const uint32_t t = frag - f.bwd_out();
-		return params[LO.w_off + (size_t)(2 * j + h) * LO.cols + 32 * t + r];
+		return (int32_t)(LO.w_off + (2 * j + h) * LO.cols + 32 * t + r);
 	}
 	if (frag < f.bwd0()) {
 		const uint32_t local = frag - f.bwd_hidden(1), per = f.wt * f.ksw;
 		const uint32_t l = 1 + local / per, rem = local - (l - 1) * per, t = rem / f.ksw, ks = rem - t * f.ksw;
 		const MlpLayer L = d.layers[l];
-		return params[L.w_off + (size_t)r32_chain_k(ks, h, j) * L.cols + 32 * t + r];
+		return (int32_t)(L.w_off + r32_chain_k(ks, h, j) * L.cols + 32 * t + r);
 	}
 	const uint32_t local = frag - f.bwd0(), t = local / f.ksw, ks = local - t * f.ksw;
 	const uint32_t col = 32 * t + r;
-	return col < L0.cols ? params[L0.w_off + (size_t)r32_chain_k(ks, h, j) * L0.cols + col] : (_Float16)0.0f;
+	return col < L0.cols ? (int32_t)(L0.w_off + r32_chain_k(ks, h, j) * L0.cols + col) : -1;
 }
 
 // weights (row-major half) -> fragment images, element gid of n_frags_total * 512:
 // forward fragment (layer l, row tile t, k-step s), lane (r = lane & 15, q = lane >> 4), element j:  W_l[16 t + r][k], 0 beyond the matrix
 // backward fragment (A = W_l^T; row tile t over the COLUMNS of W_l, k over its ROWS):              W_l[k_chain(s, q, j)][16 t + r]
-__device__ inline void mlp_prep_element(const MlpDesc& d, const _Float16* __restrict__ params, _Float16* __restrict__ image, const uint32_t gid) {
+// mlp_prep_source: the index into `params` of the weight element gid holds, -1 for the zeros.  (Host-callable: Network::image_inverse
+// turns it round into "which image elements hold parameter i", so that an optimizer kernel can keep an image current.)
+__host__ __device__ inline int32_t mlp_prep_source(const MlpDesc& d, const uint32_t gid) {
 	uint32_t frag = gid >> 9;
 	const uint32_t lane = (gid >> 3) & 63;
 	const uint32_t j = gid & 7;
-	if (frag >= d.n_frags_fwd + d.n_frags_bwd) { // third section
-		image[gid] = r32_prep_value(d, params, frag - (d.n_frags_fwd + d.n_frags_bwd), lane, j);
-		return;
-	}
+	if (frag >= d.n_frags_fwd + d.n_frags_bwd) return r32_prep_source(d, frag - (d.n_frags_fwd + d.n_frags_bwd), lane, j); // third section
 	const uint32_t r = lane & 15, q = lane >> 4;
 	const bool bwd = frag >= d.n_frags_fwd;
 	if (bwd) frag -= d.n_frags_fwd;
@@ -96,22 +96,22 @@ __device__ inline void mlp_prep_element(const MlpDesc& d, const _Float16* __rest
 		if (frag >= (bwd ? d.layers[i].bwd_off : d.layers[i].fwd_off)) l = i;
 	}
 	const MlpLayer L = d.layers[l];
-	const _Float16* W = params + L.w_off;
-	_Float16 v = (_Float16)0.0f;
 	if (!bwd) {
 		const uint32_t local = frag - L.fwd_off;
 		const uint32_t t = local / L.ks_fwd, s = local - t * L.ks_fwd;
 		const uint32_t row = 16 * t + r;
 		const uint32_t k = L.natural_k ? frag_k_natural(s, q, j) : frag_k_chain(s, q, j);
-		if (row < L.rows && k < L.cols) v = W[(size_t)row * L.cols + k];
-	} else {
-		const uint32_t local = frag - L.bwd_off;
-		const uint32_t t = local / L.ks_bwd, s = local - t * L.ks_bwd;
-		const uint32_t col = 16 * t + r;
-		const uint32_t k = frag_k_chain(s, q, j);
-		if (col < L.cols && k < L.rows) v = W[(size_t)k * L.cols + col];
+		return (row < L.rows && k < L.cols) ? (int32_t)(L.w_off + row * L.cols + k) : -1;
 	}
-	image[gid] = v;
+	const uint32_t local = frag - L.bwd_off;
+	const uint32_t t = local / L.ks_bwd, s = local - t * L.ks_bwd;
+	const uint32_t col = 16 * t + r;
+	const uint32_t k = frag_k_chain(s, q, j);
+	return (col < L.cols && k < L.rows) ? (int32_t)(L.w_off + k * L.cols + col) : -1;
+}
+__device__ inline void mlp_prep_element(const MlpDesc& d, const _Float16* __restrict__ params, _Float16* __restrict__ image, const uint32_t gid) {
+	const int32_t src = mlp_prep_source(d, gid);
+	image[gid] = src < 0 ? (_Float16)0.0f : params[src];
 }
 
 // side job of the encoding's forward kernel: build the fragment images of `params` (all n_frags_fwd + n_frags_bwd + n_frags_r32 fragments)

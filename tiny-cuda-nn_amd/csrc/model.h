@@ -1249,6 +1249,37 @@ public:
 		HIP_CHECK_THROW(hipMemcpy(params_full_precision, host.data(), m_n_params * sizeof(float), hipMemcpyHostToDevice));
 	}
 
+	// ---- A fragment image that lives across training steps, for models whose optimizer step rides on the weight gradients' slab
+	// reduction (BASELINE config 2).  k_wgrad_reduce_adam writes every weight it updates into the image elements that hold it
+	// (AdamInFlush::image / image_inv), so the next step starts with a current image instead of a k_mlp_prep launch -- 4.5 of config 2's
+	// 27 us.  The image is current for the parameter vector `live_params()`; whoever changes those parameters any other way calls
+	// invalidate_live_image() (the Trainer does, and stops using the image for good once it has handed out a pointer to its parameters).
+	struct LiveImage {
+		DeviceBuf image, inverse;       // inverse: uint32 [n_params][IMAGE_INV_WIDTH], the image elements that hold a weight (0xffffffff: none)
+		const void* params = nullptr;   // what the image is current for
+	};
+	// nullptr: a weight of this network sits in more than IMAGE_INV_WIDTH image elements (no supported shape does)
+	LiveImage* live_image() const {
+		if (m_live_state == 0) {
+			const uint32_t total = (m_desc.n_frags_fwd + m_desc.n_frags_bwd + m_desc.n_frags_r32) * 512;
+			std::vector<uint32_t> inv(m_n_params * IMAGE_INV_WIDTH, 0xffffffffu), count(m_n_params, 0);
+			m_live_state = 1;
+			for (uint32_t gid = 0; gid < total && m_live_state == 1; ++gid) {
+				const int32_t src = mlp_prep_source(m_desc, gid);
+				if (src < 0) continue;
+				if ((size_t)src >= m_n_params || count[src] == IMAGE_INV_WIDTH) m_live_state = -1;
+				else inv[(size_t)src * IMAGE_INV_WIDTH + count[src]++] = gid;
+			}
+			if (m_live_state == 1) {
+				m_live.image.resize(mlp_image_bytes(m_desc));
+				m_live.inverse.resize(inv.size() * sizeof(uint32_t));
+				HIP_CHECK_THROW(hipMemcpy(m_live.inverse.data(), inv.data(), inv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+			}
+		}
+		return m_live_state == 1 ? &m_live : nullptr;
+	}
+	void invalidate_live_image() const { m_live.params = nullptr; }
+
 	// images: [fwd][bwd] fragment images of `params`
 	ArenaBuf prepare(hipStream_t stream, const void* params, bool want_bwd) const {
 		ArenaBuf image{stream, mlp_image_bytes(m_desc)};
@@ -1331,6 +1362,8 @@ private:
 	Activation m_activation, m_output_activation;
 	MlpDesc m_desc;
 	size_t m_n_params;
+	mutable LiveImage m_live;
+	mutable int m_live_state = 0; // 0: not built yet, 1: usable, -1: not usable for this network
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1578,6 +1611,15 @@ public:
 	bool fused_step_supported(uint32_t n) const { return use_fused_step() && mlp_train_fused_supported(m_network->desc(), n); }
 	// the fused step of a model without encoding parameters hands its weight gradients to the optimizer inside the slab reduction
 	bool optimizer_rides_on_reduce() const { return m_encoding->n_params() == 0; }
+	// TCNN_AMD_LIVE_IMAGE=0: every step builds its fragment images with k_mlp_prep again instead of keeping one current (Network::live_image;
+	// bit-identical, one ~4.5 us launch more per step of a model without encoding parameters)
+	static bool live_image_enabled() {
+		const char* e = getenv("TCNN_AMD_LIVE_IMAGE");
+		return !(e && e[0] == '0');
+	}
+	bool live_image_kept() const { return m_live_image_kept; }           // the last fused step's optimizer launch left the live image current
+	void invalidate_live_image() { m_network->invalidate_live_image(); } // the parameters change(d) some other way
+	size_t image_preps() const { return m_image_preps; }                 // k_mlp_prep launches of fused steps so far (a test's view of the above)
 	// the register-resident fused kernel (k_train_regs.hip) writes dL_doutput / L as compact [n][dims] matrices (TrainContext::compact)
 	bool fused_compact_context_supported(uint32_t n) const {
 		const bool ok = use_fused_step() && mlp_train_regs_supported(m_network->desc(), n) && m_network->padded_output_width() == 16;
@@ -1656,10 +1698,26 @@ public:
 		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, records ? (size_t)n * m_encoding->scatter_record_planes() * 16 : (size_t)n * m_encoding->padded_output_width() * 2};
 		ctx.encoding_ctx.dy_records = records;
 
-		ArenaBuf prepared;
-		if (!ctx.image) prepared = m_network->prepare(stream, params, true);
-		const ArenaBuf& image = ctx.image ? ctx.image : prepared;
 		const MlpDesc& d = m_network->desc();
+		// a model whose only parameters are the network's: the optimizer's update rides on the slab reduction (k_wgrad_reduce_adam), which
+		// then also keeps the network's live image current (Network::live_image)
+		const bool with_adam = adam && adam_done && !need_dx && m_encoding->n_params() == 0 && mode == GradientMode::Overwrite;
+		Network::LiveImage* live = with_adam && !ctx.image && live_image_enabled() ? m_network->live_image() : nullptr;
+		m_live_image_kept = false;
+		ArenaBuf prepared;
+		const void* image_data;
+		if (ctx.image) image_data = ctx.image.data();
+		else if (live) {
+			if (live->params != params) { // first step, or the parameters were changed behind the image's back
+				mlp_prepare_weights(stream, d, params, live->image.data(), true);
+				++m_image_preps;
+			}
+			image_data = live->image.data();
+		} else {
+			prepared = m_network->prepare(stream, params, true);
+			++m_image_preps;
+			image_data = prepared.data();
+		}
 		ArenaBuf slabs;
 		uint32_t n_slabs = 0;
 		if (mode != GradientMode::Ignore) {
@@ -1672,7 +1730,7 @@ public:
 		}
 		const MlpOneBlobInput oneblob_input{input, m_encoding->input_width(), ctx.oneblob_bins};
 		if (profile) profile->mark(stream, StepProfile::MlpKernel, false);
-		mlp_train_fused(stream, d, image.data(), n, ctx.network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L, compact_context,
+		mlp_train_fused(stream, d, image_data, n, ctx.network_input.data(), x_plane_f, target, data_pdf, external_dL_dy, m_network->output_width(), loss, loss_scale, out, dL_dout, L, compact_context,
 		                dL_dnetwork_input.data(), plane_f, records ? input.data : nullptr, records ? m_encoding->input_width() : 0u, slabs.as<float>(), n_net,
 		                ctx.oneblob_bins ? &oneblob_input : nullptr);
 		if (profile) profile->mark(stream, StepProfile::MlpKernel, true);
@@ -1689,12 +1747,22 @@ public:
 			reduce_job.grad = g;
 			reduce_job.accumulate = mode == GradientMode::Accumulate ? 1 : 0;
 			if (!(need_dx && side_jobs_enabled())) {
-				// a model whose only parameters are the network's: the optimizer's update rides on the reduction (k_wgrad_reduce_adam)
-				const bool with_adam = adam && adam_done && !need_dx && m_encoding->n_params() == 0 && mode == GradientMode::Overwrite;
-				mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate, with_adam ? adam : nullptr);
+				AdamInFlush adam_here;
+				if (with_adam) {
+					adam_here = *adam;
+					if (live) {
+						adam_here.image = live->image.data();
+						adam_here.image_inv = live->inverse.as<uint32_t>();
+					}
+				}
+				mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate, with_adam ? &adam_here : nullptr);
 				if (with_adam) {
 					adam_done->clear();
 					adam_done->emplace_back((size_t)0, (size_t)n_net);
+					if (live) {
+						live->params = params; // current again once this launch has run
+						m_live_image_kept = true;
+					}
 				}
 			} else ctx.encoding_ctx.reduce_job = &reduce_job;
 		}
@@ -1729,6 +1797,8 @@ public:
 	}
 
 private:
+	bool m_live_image_kept = false;
+	size_t m_image_preps = 0;
 	std::unique_ptr<Encoding> m_encoding;
 	std::unique_ptr<Network> m_network;
 };
@@ -2736,6 +2806,7 @@ public:
 	}
 
 	void optimizer_step(hipStream_t stream, float loss_scale) { // trainer.h:155-157
+		m_model->invalidate_live_image();
 		m_optimizer->step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data());
 	}
 
@@ -2777,6 +2848,7 @@ public:
 			ParamRanges adam_done;
 			const bool split = run_optimizer && mode == GradientMode::Overwrite && (adam_in_flush_enabled() || (adam_in_reduce_enabled() && m_model->optimizer_rides_on_reduce())) &&
 			                   m_optimizer->begin_split_step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), adam);
+			if (m_params_exposed) m_model->invalidate_live_image(); // somebody holds a pointer to the parameters: no image outlives a step
 			ctx->model_ctx = m_model->fused_step(stream, n, input, target, data_pdf, external_dL_dy, m_loss, loss_scale, ctx->output.data(),
 			                                     ctx->compact ? ctx->compact_dL_doutput.data() : ctx->dL_doutput.data(),
 			                                     ctx->compact ? ctx->compact_L.as<float>() : ctx->L.as<float>(), ctx->compact, dL_dinput, m_params.data(), m_grads.data(), mode,
@@ -2785,8 +2857,10 @@ public:
 				m_profile.mark(stream, StepProfile::Optimizer, false);
 				m_params_updated_in_flush = 0;
 				for (const auto& r : adam_done) m_params_updated_in_flush += r.second - r.first;
-				if (split) m_optimizer->finish_split_step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data(), adam_done);
-				else optimizer_step(stream, loss_scale);
+				if (split) {
+					if (!m_model->live_image_kept()) m_model->invalidate_live_image(); // the update below (or the gradient kernels') changes network weights
+					m_optimizer->finish_split_step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data(), adam_done);
+				} else optimizer_step(stream, loss_scale);
 				m_profile.mark(stream, StepProfile::Optimizer, true);
 			}
 			m_profile.end_step();
@@ -2826,6 +2900,7 @@ public:
 
 	void set_params_full_precision(const float* params, size_t n_params, bool device_ptr) { // trainer.h:242-254
 		if (n_params != m_model->n_params()) throw std::runtime_error{"Can't set fp params because buffer has the wrong size."};
+		m_model->invalidate_live_image();
 		HIP_CHECK_THROW(hipMemcpy(m_params_fp.data(), params, sizeof(float) * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 		cast_float_to_half(nullptr, n_params, m_params_fp.as<float>(), m_params.data());
 		if (params_inference() != m_params.data()) HIP_CHECK_THROW(hipMemcpy(params_inference(), m_params.data(), 2 * n_params, hipMemcpyDeviceToDevice));
@@ -2834,6 +2909,7 @@ public:
 
 	void set_params(const void* params, size_t n_params, bool device_ptr) { // trainer.h:256-269
 		if (n_params != m_model->n_params()) throw std::runtime_error{"Can't set params because buffer has the wrong size."};
+		m_model->invalidate_live_image();
 		HIP_CHECK_THROW(hipMemcpy(m_params.data(), params, 2 * n_params, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
 		cast_half_to_float(nullptr, n_params, m_params.data(), m_params_fp.as<float>());
 		if (params_inference() != m_params.data()) HIP_CHECK_THROW(hipMemcpy(params_inference(), m_params.data(), 2 * n_params, hipMemcpyDeviceToDevice));
@@ -2890,8 +2966,11 @@ public:
 	// trainer.h:329-333: the optimizer's own weights (EMA) if it keeps any, else the training parameters
 	void* params_inference() const { void* custom = m_optimizer->custom_weights(); return custom ? custom : m_params.data(); }
 	size_t n_params() const { return m_model->n_params(); }
-	float* params_full_precision() const { return m_params_fp.as<float>(); }
-	void* params() const { return m_params.data(); }
+	// The reference hands out mutable pointers here (trainer.h:226-232).  A caller may write through them at any later time, so from the
+	// first call on no fragment image of the half parameters is trusted beyond the step that built it (Network::live_image)
+	float* params_full_precision() { expose_params(); return m_params_fp.as<float>(); }
+	void* params() { expose_params(); return m_params.data(); }
+	size_t image_preps() const { return m_model->image_preps(); }
 	void* param_gradients() const { return m_grads.data(); }
 
 private:
@@ -2902,6 +2981,11 @@ private:
 	DeviceBuf m_params_fp, m_params, m_grads, m_scalar;
 	StepProfile m_profile;
 	size_t m_params_updated_in_flush = 0;
+	bool m_params_exposed = false;
+	void expose_params() {
+		m_params_exposed = true;
+		m_model->invalidate_live_image();
+	}
 };
 
 } // namespace tcnn_amd

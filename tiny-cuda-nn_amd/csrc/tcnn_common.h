@@ -327,6 +327,7 @@ AdamArgs make_adam_args(const AdamHyper& h, float loss_scale, uint32_t current_s
 // Adam applied by a gradient kernel: the owner of a chunk of the gradient has its final value in LDS when it flushes and updates
 // those parameters on the spot (k_grid_scatter.hip) -- the 34 B/param of optimizer state stream under the latency-bound phases of
 // the other workgroups instead of in a kernel of their own.  Arrays are indexed like the gradient array the kernel writes.
+constexpr uint32_t IMAGE_INV_WIDTH = 4; // a weight sits in at most 4 image elements: forward and transposed fragments of the 16x16x32 and of the 32x32x16 sections
 struct AdamInFlush {
 	AdamArgs args;
 	float* w_fp = nullptr;
@@ -336,6 +337,10 @@ struct AdamInFlush {
 	void* steps = nullptr; // uint32, or uint16 if steps16
 	uint32_t steps16 = 0;
 	const float* debias_table = nullptr;
+	// k_wgrad_reduce_adam only (Network::live_image): the network's fragment images and, per parameter, the IMAGE_INV_WIDTH image elements that
+	// hold it (0xffffffff: none) -- the kernel writes an updated weight there too, so that the next step needs no k_mlp_prep launch
+	void* image = nullptr;
+	const uint32_t* image_inv = nullptr;
 	AdamInFlush advanced(size_t n) const { // the same arrays seen from parameter n on
 		AdamInFlush r = *this;
 		r.w_fp += n; r.w_half = (char*)w_half + 2 * n; r.m1 += n; r.m2 += n; r.steps = (char*)steps + (steps16 ? 2 : 4) * n;

@@ -98,6 +98,10 @@ class Trainer:
         """parameters whose optimizer update the last training_step's gradient kernels applied themselves (0: the usual k_adam)"""
         return int(_C.lib.tcnn_trainer_params_updated_in_flush(self._h))
 
+    def image_preps(self):
+        """launches of the weight-rearranging kernel by this trainer's training steps so far (tcnn_amd.h: tcnn_trainer_image_preps)"""
+        return int(_C.lib.tcnn_trainer_image_preps(self._h))
+
     def profile_collect(self, stream=None):
         """-> ({piece: mean milliseconds per profiled step}, number of profiled steps)"""
         ms = (C.c_float * 4)()
