@@ -306,7 +306,10 @@ size_t tcnn_trainer_image_preps(tcnn_trainer_t t) { return t->trainer->image_pre
 uint32_t tcnn_trainer_padded_output_width(tcnn_trainer_t t) { return t->trainer->model().padded_output_width(); }
 float* tcnn_trainer_params_full_precision(tcnn_trainer_t t) { return t->trainer->params_full_precision(); }
 void* tcnn_trainer_params(tcnn_trainer_t t) { return t->trainer->params(); }
-void* tcnn_trainer_params_inference(tcnn_trainer_t t) { return t->trainer->params_inference(); }
+void* tcnn_trainer_params_inference(tcnn_trainer_t t) {
+	void* p = t->trainer->params_inference();
+	return p == t->trainer->params_unexposed() ? t->trainer->params() : p; // the training parameters themselves: handed out like tcnn_trainer_params
+}
 void* tcnn_trainer_param_gradients(tcnn_trainer_t t) { return t->trainer->param_gradients(); }
 
 int tcnn_trainer_set_params_full_precision(tcnn_trainer_t t, const float* params, size_t n_params, int device_ptr) {

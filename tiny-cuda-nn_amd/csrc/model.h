@@ -2970,6 +2970,7 @@ public:
 	// first call on no fragment image of the half parameters is trusted beyond the step that built it (Network::live_image)
 	float* params_full_precision() { expose_params(); return m_params_fp.as<float>(); }
 	void* params() { expose_params(); return m_params.data(); }
+	const void* params_unexposed() const { return m_params.data(); } // for comparisons only
 	size_t image_preps() const { return m_model->image_preps(); }
 	void* param_gradients() const { return m_grads.data(); }
 
