@@ -303,7 +303,8 @@ def other_configs(tcnn, torch):
             mlp_ms = m["pieces"]["mlp_kernel"]
             tf = FLOP_PER_SAMPLE[name] * batch / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
             out[name] = {"metric": METRIC[name], "ms_per_step": ms, "value": batch * steps / m["elapsed"], "unit": "samples/s", "batch": batch, "steps": steps,
-                         "roofline": {"bound": "mfma", "kernel": MLP_KERNEL[name], "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "avg_launch_ms": mlp_ms},
+                         "roofline": {"bound": "mfma", "kernel": MLP_KERNEL[name], "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "avg_launch_ms": mlp_ms,
+                                      "traffic": pmc_traffic(MLP_KERNEL[name], name)[0], "traffic_source": pmc_traffic(MLP_KERNEL[name], name)[1]},
                          "pieces_ms": {k: m["pieces"][k] for k in ("encode", "mlp_kernel", "encoding_backward", "optimizer")}}
         except Exception as e:  # the headline line must not die with an extra measurement
             out[name] = {"error": repr(e)[:200]}
