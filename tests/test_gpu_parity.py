@@ -378,13 +378,14 @@ def test_training_step_matches_oracle(tcnn, oracle, cfg, n_in, n):
 
 
 @pytest.mark.parametrize("base,n_out,loss,n", [(CONFIG_C3B, 1, "L2", 256), (CONFIG_C3B, 2, "RelativeL2", 512), (CONFIG_C3A, 4, "L2", 2048), (CONFIG_C3B, 3, "L2", 256 * 33),
-                                               (CONFIG_C2, 1, "L2", 256), (CONFIG_C2, 4, "RelativeL2", 2048), (CONFIG_C2, 2, "L2", 256 * 9),
+                                               (CONFIG_C2, 1, "L2", 256), (CONFIG_C2, 4, "RelativeL2", 2048), (CONFIG_C2, 2, "L2", 256 * 9), (CONFIG_C2, 3, "RelativeL2", 256 * 641),
                                                (CONFIG_C5_SMALL, 1, "RelativeL2", 256), (CONFIG_C5_SMALL, 4, "L2", 1024), (CONFIG_C5_SMALL, 3, "RelativeL2", 256 * 129)])
 def test_r32_kernels_other_output_counts_losses_and_batches(tcnn, oracle, monkeypatch, base, n_out, loss, n):
     """The 32x32x16 training kernels (k_mlp_train_r32: 2-D grid configs; k_mlp_train_r32ob: OneBlob config; k_mlp_train_r32w: the
     128-wide network behind a 3-D grid with 4 features per level) beyond BASELINE's 3 outputs and RelativeL2: 1, 2 and 4 outputs
     (their two output slots per lane: both live, one dead, the odd lane half dead), the L2 loss, batches that leave most waves
-    without a block (256 = 8 blocks of 32), give the waves unequal trip counts, or -- 256 x 129 with k_mlp_train_r32w, whose waves
+    without a block (256 = 8 blocks of 32), give the waves unequal trip counts (256 x 641 with the OneBlob network: 6 trips, the form
+    of k_mlp_train_r32ob with per-wave accumulators), or -- 256 x 129 with k_mlp_train_r32w, whose waves
     exchange images under workgroup barriers -- leave most waves of the last trip with a block of zeros.  Against the oracle like
     test_training_step_matches_oracle, and against the other kernel of the same step (TCNN_AMD_MLP_R32=0) within fp16 rounding."""
     n_in = 3 if base is CONFIG_C5_SMALL else 2
