@@ -421,7 +421,7 @@ def test_r32_kernels_other_output_counts_losses_and_batches(tcnn, oracle, monkey
 
 @pytest.mark.parametrize("n_out,loss,n", [(3, "RelativeL2", 1 << 14), (1, "L2", 256 * 33), (4, "L2", 256 * 5)])
 def test_r32a_kernel_agrees_with_r32(tcnn, monkeypatch, n_out, loss, n):
-    """k_mlp_train_r32a (TCNN_AMD_MLP_R32A=1: weights in registers, every weight-gradient tile summed by ONE wave of a workgroup over
+    """k_mlp_train_r32a (the default up to 131 072 samples, TCNN_AMD_MLP_R32A=1 forces it: weights in registers, every weight-gradient tile summed by ONE wave of a workgroup over
     the samples of all four, two workgroup barriers per trip) against k_mlp_train_r32: the chain is the same instruction sequence, so
     outputs, loss values, dL/doutput and the grid's gradients (summed exactly from the same scatter records) are bit-identical; the
     network's weight gradients differ in the order of the fp32 sums.  Batches: full trips, trips in which some waves of a workgroup
@@ -442,7 +442,7 @@ def test_r32a_kernel_agrees_with_r32(tcnn, monkeypatch, n_out, loss, n):
         return res
 
     n_net = 32 * 64 + 64 * 64 + 64 * 16  # 32 -> 64 -> 64 -> 16 (padded output)
-    out, L, dy, g = run({})
+    out, L, dy, g = run({"TCNN_AMD_MLP_R32A": "0"})  # (the default chooses by the batch size: k_mlp_train_r32a up to 131 072 samples)
     out_a, L_a, dy_a, g_a = run({"TCNN_AMD_MLP_R32A": "1"})
     assert np.array_equal(out, out_a) and np.array_equal(L, L_a) and np.array_equal(dy, dy_a)
     assert np.array_equal(g[n_net:], g_a[n_net:])

@@ -498,15 +498,18 @@ bool mlp_train_r32_applies(const MlpDesc& d, uint32_t n, uint32_t x_plane_featur
 	       dL_dx != nullptr && dx_plane_features == 2 && dx_record_x != nullptr && dx_record_dims == 2;
 }
 
-// TCNN_AMD_MLP_R32A=1: k_mlp_train_r32a (k_train_r32a.hip: weights in registers, weight-gradient tiles shared out over a workgroup's
-// waves) instead of k_mlp_train_r32.  Measured equal (24.5 against 24.7 us on one device): kept for A/B runs
-static bool r32a_enabled() {
+// Which of the two kernels: k_mlp_train_r32a (k_train_r32a.hip: weights in registers, weight-gradient tiles shared out over a workgroup's
+// waves, no final sum over waves) is the faster one while that final sum is a large part of the launch -- up to 2 trips per wave,
+// 131 072 samples (MLP kernel at 2^14 / 2^16 / 2^17 samples: 7.9 / 12.0 / 16.0 us against 10.1 / 12.6 / 16.7); at 2^18 the two are equal
+// (24.7 us) and k_mlp_train_r32 stays.  TCNN_AMD_MLP_R32A=1 / 0 forces one (A/B runs, tests).
+static bool r32a_chosen(uint32_t n) {
 	const char* e = getenv("TCNN_AMD_MLP_R32A");
-	return e && e[0] == '1';
+	if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+	return n <= 131072u;
 }
 // workgroups = weight-gradient slabs of the kernel mlp_train_r32 launches for this batch
 uint32_t mlp_train_r32_grid(uint32_t n) {
-	if (r32a_enabled()) {
+	if (r32a_chosen(n)) {
 		static const uint32_t cap = getenv("TCNN_AMD_MLP_GRID") ? (uint32_t)std::max(1, atoi(getenv("TCNN_AMD_MLP_GRID"))) : 512u; // development knob
 		return std::max(1u, std::min(cap, div_round_up(n / 32, (uint32_t)R32A_NW))); // two workgroups of four waves per CU
 	}
@@ -547,7 +550,7 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 	if (const char* e = getenv("TCNN_AMD_MLP_STAGGER")) a.stagger = (uint32_t)atoi(e);
 	static const int diag = getenv("TCNN_AMD_MLP_DIAG") ? atoi(getenv("TCNN_AMD_MLP_DIAG")) : 0;
 	CHECK_THROW(grid == mlp_train_r32_grid(n));
-	if (r32a_enabled()) {
+	if (r32a_chosen(n)) {
 		mlp_train_r32a_launch(stream, a, grid, loss == LossType::L2 ? 1 : 2);
 		if (a.dbg) {
 			std::vector<unsigned long long> hst((size_t)grid * (7 + 4 * R32A_NW));
