@@ -2,8 +2,8 @@
 // network's weights in REGISTERS and the weight-gradient tiles shared out over a workgroup's waves.
 //
 // Why: k_mlp_train_r32 keeps per wave all 8 weight-gradient tiles (112 of its 256 registers), so its 30 weight fragments live in LDS
-// and every use is a 16-byte LDS read -- 240 of the ~580 LDS clocks a wave's trip costs on a CU whose LDS pipe the 8 waves keep
-// 75 % busy -- and the eight waves' tiles are summed through LDS at the end (17 % of the kernel), after a fill phase (9 %).  Here:
+// and every use is a 16-byte LDS read -- 30 KiB per wave and trip on a CU whose LDS pipe the 8 waves keep
+// busy -- and the eight waves' tiles are summed through LDS at the end (17 % of the kernel), after a fill phase (9 %).  Here:
 //   * 4 waves per workgroup, 2 workgroups per CU (still two waves per SIMD, of DIFFERENT workgroups, each in its own phase);
 //   * wave w owns dW1's tile (w >> 1, w & 1); waves 0 / 1 also dW0's row tiles 0 / 1, waves 2 / 3 two of dWout's 16-column tiles
 //     each (as the upper half of a 32 x 32 tile: every wave runs the same instructions): 32 accumulator registers, FINAL for the workgroup -- stored into the slab as they stand, no sum over waves;
@@ -15,6 +15,9 @@
 //     ordinary registers the conversions read).  The other 6 fragments (layer 0's four, Wout^T's two) are 16-byte loads from the
 //     image in global memory (L1-resident), requested a phase ahead.  (All 30 from global: the CU's L1 path -- 64 bytes per
 //     clock -- is the wall, 30 KiB per wave and trip; measured 9.6 k clocks per trip against k_mlp_train_r32's 6.2 k.)
+// Measured ("The 32x32x16 kernels"): what the missing fill and final sum save, the two barriers per trip and the doubled
+// transposing reads give back at 4 trips per wave (24.7 us both at 2^18 samples); with fewer trips this kernel is the faster one
+// (2^14 / 2^16 / 2^17 samples: 7.9 / 12.0 / 16.0 us against 10.1 / 12.6 / 16.7) and mlp_train_r32 launches it up to 131 072 samples.
 // The chain's instructions and their order are k_mlp_train_r32's: outputs, context matrices and scatter records are bit-identical;
 // the weight gradients differ in the order of the fp32 sum (per slab 4 x trips blocks in tile order instead of 8 waves' partial sums).
 #include "r32_train.h"
