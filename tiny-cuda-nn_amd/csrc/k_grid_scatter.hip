@@ -702,10 +702,26 @@ static void tuned_splits(const GridMeta& meta, uint32_t n, const std::vector<flo
 		}
 		return;
 	}
+	// Only coarse levels: ONE round of tasks, as equal as the levels allow -- start from one task per chunk and keep splitting the level
+	// whose tasks are longest while all tasks still fit the CUs at once.  (Rounding level time / target time per level, as before,
+	// sat on a knife-edge here too: the sum came out at 240 or at 280 tasks depending on a per cent of measurement noise, and 280 tasks
+	// on 256 CUs are two rounds -- C3b's scatter took 60 us in one process and 86 us in the next.)
+	uint32_t n_tasks = 0;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
-		if (is_fine(l) || meta.levels[l].scatter_binned) { splits[l] = 1; continue; }
-		const double per_chunk_us = level_us[l] / meta.levels[l].scatter_n_chunks;
-		splits[l] = std::min(max_splits, std::max(1u, (uint32_t)(per_chunk_us / task_us + 0.5)));
+		splits[l] = 1;
+		if (!is_fine(l) && !meta.levels[l].scatter_binned) n_tasks += meta.levels[l].scatter_n_chunks;
+	}
+	while (true) {
+		uint32_t longest = meta.n_levels;
+		double t_longest = 0;
+		for (uint32_t l = 0; l < meta.n_levels; ++l) {
+			if (is_fine(l) || meta.levels[l].scatter_binned) continue;
+			const double t = level_us[l] / (meta.levels[l].scatter_n_chunks * splits[l]);
+			if (t > t_longest) { t_longest = t; longest = l; }
+		}
+		if (longest == meta.n_levels || splits[longest] >= max_splits || n_tasks + meta.levels[longest].scatter_n_chunks > n_cus || t_longest <= std::max(0.25 * task_us, 4.0)) break;
+		++splits[longest];
+		n_tasks += meta.levels[longest].scatter_n_chunks;
 	}
 }
 
