@@ -33,6 +33,16 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
 
 
+def elem_close(a, b, rtol=1e-2, floor=1e-3):
+    """element-wise form of the 1e-2 bar: |a - b| <= rtol * |b| + floor * max|b| for EVERY element.  rel_err above is norm-wise -- an
+    output 100x below the tensor's maximum could be 100 % off and pass it; this one bounds each output by its own size, with an absolute
+    floor of a thousandth of the tensor's range (fp16 rounding of values near zero).  Returns the worst ratio (<= 1 passes)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    bound = rtol * np.abs(b) + floor * max(float(np.max(np.abs(b))), 1e-30)
+    return float(np.max(np.abs(a - b) / bound))
+
+
 # ---------------------------------------------------------------------------------------------------- init
 @pytest.mark.parametrize("cfg,n_in", [(CONFIG_C3B, 2), (CONFIG_C2, 2), (CONFIG_C1, 2), (CONFIG_C5_SMALL, 3)])
 def test_initial_params_bit_exact(tcnn, oracle, cfg, n_in):
@@ -316,6 +326,7 @@ def test_network_forward_backward(tcnn, oracle, n_in, n_out, net_cfg):
     assert out.shape == (n, n_out)
     got = out.detach().float().cpu().numpy()
     assert rel_err(got, _f32(want_out)[:, :n_out]) < 1e-2
+    assert elem_close(got, _f32(want_out)[:, :n_out]) <= 1.0  # every output within 1e-2 of its own size (+ 1e-3 of the range)
 
     # backward: random upstream gradient on the real outputs
     dy = oracle.Pcg32(5).uniform_strided(n * n_out, -1.0, 1.0).reshape(n, n_out)
@@ -350,10 +361,13 @@ def test_training_step_matches_oracle(tcnn, oracle, cfg, n_in, n):
     got_out = _f32(_bits(ctx.output()))
     want_out = _f32(want["output"])
     assert rel_err(got_out[:, :3], want_out[:, :3]) < 1e-2
+    assert elem_close(got_out[:, :3], want_out[:, :3]) <= 1.0  # per output: |a - b| <= 1e-2 |b| + 1e-3 max|b|
     assert np.all(got_out[:, 3:] == 0) or rel_err(got_out[:, 3:], want_out[:, 3:]) < 1e-2  # padded rows follow the padded weights
     assert abs(loss - want["loss"]) <= 2e-2 * abs(want["loss"])
     L = ctx.L().cpu().numpy()
     assert rel_err(L, want["L"]) < 3e-2
+    got_dy, want_dy = _f32(_bits(ctx.dL_doutput())).reshape(n, -1), _f32(want["dL_doutput"]).reshape(n, -1)
+    assert elem_close(got_dy[:, :3], want_dy[:, :3], rtol=3e-2) <= 1.0  # RelativeL2 divides by prediction^2: 3 x the output's error
     assert np.all(L[:, 3:] == 0)
 
     n_net = ref.model.network.n_params
@@ -419,13 +433,14 @@ def test_r32_kernels_other_output_counts_losses_and_batches(tcnn, oracle, monkey
     assert float(np.linalg.norm(g - g0)) <= 5e-3 * float(np.linalg.norm(g0))
 
 
-@pytest.mark.parametrize("n_out,loss,n", [(3, "RelativeL2", 1 << 14), (1, "L2", 256 * 33), (4, "L2", 256 * 5)])
+@pytest.mark.parametrize("n_out,loss,n", [(3, "RelativeL2", 1 << 14), (1, "L2", 256 * 33), (4, "L2", 256 * 5), (3, "RelativeL2", 1 << 17)])
 def test_r32a_kernel_agrees_with_r32(tcnn, monkeypatch, n_out, loss, n):
     """k_mlp_train_r32a (the default up to 131 072 samples, TCNN_AMD_MLP_R32A=1 forces it: weights in registers, every weight-gradient tile summed by ONE wave of a workgroup over
     the samples of all four, two workgroup barriers per trip) against k_mlp_train_r32: the chain is the same instruction sequence, so
     outputs, loss values, dL/doutput and the grid's gradients (summed exactly from the same scatter records) are bit-identical; the
     network's weight gradients differ in the order of the fp32 sums.  Batches: full trips, trips in which some waves of a workgroup
-    have no block (their images are zeros), fewer blocks than workgroups."""
+    have no block (their images are zeros), fewer blocks than workgroups, and 131 072 samples = two full trips of every wave of all 512
+    workgroups (the largest batch the default hands to this kernel)."""
     cfg = {**CONFIG_C3B, "loss": {"otype": loss}}
     rng = np.random.default_rng(5)
     x = rng.random((n, 2), dtype=np.float32)
@@ -575,6 +590,57 @@ def test_oneblob_inside_the_training_kernel_is_bit_identical(tcnn, oracle, monke
     for k in (3, 4):  # gradients of the third step, parameters after it
         a, b = _f32(new[k]), _f32(plain[k])
         assert float(np.linalg.norm(a - b)) <= 1e-2 * float(np.linalg.norm(b)), k
+
+
+def test_c2_full_batch_two_trips_per_wave(tcnn, oracle, monkeypatch):
+    """BASELINE config 2 at ITS batch size, 65 536 samples: the form bench.py runs -- k_mlp_train_r32ob's shared-tiles kernel with two
+    trips on every wave of all 256 workgroups (the smaller test batches give a wave at most one trip, the larger ones go to the
+    per-wave-accumulator kernel).  Trip-to-trip state is what this covers: the images reused under the two workgroup barriers, the
+    prefetch of the next trip's input, and -- over three optimizer steps -- the live fragment image kept current by the optimizer
+    kernel.  Against the LDS-image kernel of the same step (TCNN_AMD_MLP_R32=0) within fp16 rounding, and against the oracle."""
+    n = 65536
+    batches = [oracle.synthetic_batch(n, 2, 3, seed=70 + i) for i in range(3)]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, CONFIG_C2, seed=1337)
+        first = None
+        for x, t in batches:
+            ctx = tr.training_step(_t(x), _t(t))
+            if first is None:
+                first = (_f32(_bits(ctx.output())).reshape(n, 16), ctx.L().cpu().numpy().reshape(n, 16).copy(), _f32(_bits(ctx.dL_doutput())).reshape(n, 16), _f32(_bits(tr.param_gradients())), tr.loss(ctx))
+        last = (_f32(_bits(ctx.output())).reshape(n, 16), _f32(_bits(tr.param_gradients())), _f32(_bits(tr.params())), tr.params_full_precision().cpu().numpy(), tr.loss(ctx))
+        for k in env:
+            monkeypatch.delenv(k)
+        return first, last
+
+    (out, L, dy, g, l), (out3, g3, p3, pf3, l3) = run({})
+    (out0, L0, dy0, g0, l0), (out30, g30, p30, pf30, l30) = run({"TCNN_AMD_MLP_R32": "0"})
+    # the two kernels of the same step: other fp32 summation order, everything within fp16 rounding (bounds of the smaller tests)
+    assert float(np.max(np.abs(out - out0))) <= 4e-3 * max(1.0, float(np.max(np.abs(out0)))) and abs(l - l0) <= 1e-4 * abs(l0)
+    assert np.all(L[:, 3:] == 0) and np.all(dy[:, 3:] == 0) and np.any(dy[:, :3] != 0)
+    assert float(np.linalg.norm(dy - dy0)) <= 5e-3 * float(np.linalg.norm(dy0))
+    assert float(np.linalg.norm(g - g0)) <= 5e-3 * float(np.linalg.norm(g0))
+    # after three optimizer steps (the third step ran on weights the optimizer kernel wrote into the fragment image twice)
+    assert float(np.max(np.abs(out3 - out30))) <= 1e-2 * max(1.0, float(np.max(np.abs(out30)))) and abs(l3 - l30) <= 1e-2 * abs(l30)
+    assert float(np.linalg.norm(g3 - g30)) <= 2e-2 * float(np.linalg.norm(g30))
+    assert float(np.linalg.norm(pf3 - pf30)) <= 1e-2 * float(np.linalg.norm(pf30))
+
+    # the oracle: three steps on the same batches; the first step's rows element-wise, on 1 024 sampled rows and over the whole batch
+    ref = oracle.Trainer(2, 3, CONFIG_C2, seed=1337)
+    grads32 = np.zeros(ref.model.n_params, dtype=np.float32)
+    want = ref.training_step(batches[0][0], batches[0][1], grads_f32=grads32)
+    rows = np.random.default_rng(3).choice(n, 1024, replace=False)
+    want_out, want_dy = _f32(want["output"]).reshape(n, 16), _f32(want["dL_doutput"]).reshape(n, 16)
+    assert elem_close(out[rows, :3], want_out[rows, :3]) <= 1.0 and rel_err(out[:, :3], want_out[:, :3]) < 1e-2
+    assert rel_err(L[rows], want["L"].reshape(n, 16)[rows]) < 3e-2 and rel_err(dy[rows, :3], want_dy[rows, :3]) < 3e-2
+    assert abs(l - want["loss"]) <= 2e-2 * abs(want["loss"])
+    assert rel_err(g, grads32) < 3e-2
+    for x, t in batches[1:]:
+        want = ref.training_step(x, t)
+    assert abs(l3 - want["loss"]) <= 2e-2 * abs(want["loss"])
+    assert rel_err(out3[:, :3], _f32(want["output"]).reshape(n, 16)[:, :3]) < 2e-2  # three steps of Adam on fp16 weights apart
 
 
 def test_batch_size_granularity_error(tcnn):
