@@ -263,8 +263,9 @@ def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=N
     loss1 = tr.loss(ctx)
     pieces, n_profiled = tr.profile_collect()
     n_params = tr.n_params
+    wide = tr.scatter_wide_fallbacks()  # grid gradient tasks that could not prove their packed 32-bit sums (they then sum in 64 bits: slower, same bits)
     del tr, xs, ts, ctx
-    return {"elapsed": elapsed, "n_params": n_params, "pieces": pieces, "n_profiled": n_profiled, "loss0": loss0, "loss1": loss1}
+    return {"elapsed": elapsed, "n_params": n_params, "pieces": pieces, "n_profiled": n_profiled, "loss0": loss0, "loss1": loss1, "scatter_wide_tasks": wide}
 
 
 def mlp_param_count(name):
@@ -386,6 +387,7 @@ def main():
 
     m = measure_training(tcnn, torch, args.workload, batch, args.steps, args.warmup, seed=42 + rank, barrier=barrier)
     elapsed, n_params, pieces, n_profiled, loss0, loss1 = m["elapsed"], m["n_params"], m["pieces"], m["n_profiled"], m["loss0"], m["loss1"]
+    scatter_wide_tasks = m.get("scatter_wide_tasks")
     if world > 1:
         el = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -443,7 +445,8 @@ def main():
                                    f"RelativeL2 + Adam, n_params={n_params}",
                        "batch_per_gpu": batch, "global_batch": world * batch,
                        "parallelism": f"independent replicas x{world}, no gradient exchange (training does not shard in the reference)" if world > 1 else "single GPU",
-                       "batches": f"{POOL} pre-generated batches visited in turn", "loss_first_last": [loss0, loss1]},
+                       "batches": f"{POOL} pre-generated batches visited in turn", "loss_first_last": [loss0, loss1],
+                       "scatter_tasks_summed_in_64_bits": scatter_wide_tasks},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flops, "avg_launch_ms": mlp_ms, "profiled_steps": n_profiled,
                          "share_of_step": mlp_ms / step_ms if step_ms > 0 else None,

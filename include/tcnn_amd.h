@@ -190,6 +190,11 @@ size_t tcnn_trainer_params_updated_in_flush(tcnn_trainer_t t);
  * the parameters are set, restored, stepped by optimizer_step(), or a pointer to them has been handed out
  * (tcnn_trainer_params / tcnn_trainer_params_full_precision: from then on every step rearranges them again). */
 size_t tcnn_trainer_image_preps(tcnn_trainer_t t);
+/* Introspection (no counterpart in the reference): the grid encoding's gradient kernel (replacing kernel_grid_backward, grid.h:215-320)
+ * sums a chunk's fp16 products as exact integers, two 32-bit sums per 64-bit LDS add while a per-task bound on sum |product| proves
+ * that neither can overflow; a task whose bound fails runs again with 64-bit sums (same result, slower).  This counts those tasks since
+ * the trainer was built; (size_t)-1 on error.  Synchronises with the device. */
+size_t tcnn_trainer_scatter_wide_fallbacks(tcnn_trainer_t t);
 
 #ifdef __cplusplus
 }

@@ -762,7 +762,11 @@ def test_training_step_variants_agree_bitwise(tcnn, oracle, cfg, n_in, monkeypat
     assert np.any(base_g[n_net:] != 0)
     # TCNN_AMD_SIDE_JOBS=0: the fragment images and the slab reduction as launches of their own instead of riding on the encoding's
     # forward kernel and the grid scatter (mlp_side_jobs.h): the same arithmetic
-    for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_SCATTER_RECORDS": "0", "TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_SIDE_JOBS": "0"}):
+    # TCNN_AMD_SCATTER_LISTS=0 / 1: the bit-plane filter and k_grid_scatter / hit lists and k_grid_scatter_lists (unset: lists where the grid has
+    # levels of many chunks); TCNN_AMD_SCATTER_WIDE=1: every task of the latter through its 64-bit passes
+    for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_SCATTER_RECORDS": "0", "TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_SIDE_JOBS": "0"},
+                {"TCNN_AMD_SCATTER_LISTS": "0"}, {"TCNN_AMD_SCATTER_LISTS": "0", "TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_LISTS": "1"}, {"TCNN_AMD_SCATTER_LISTS": "1", "TCNN_AMD_SCATTER_RECORDS": "0"},
+                {"TCNN_AMD_SCATTER_LISTS": "1", "TCNN_AMD_SCATTER_WIDE": "1"}, {"TCNN_AMD_SCATTER_LISTS": "1", "TCNN_AMD_SCATTER_WIDE": "1", "TCNN_AMD_SCATTER_RECORDS": "0"}):
         g, out = grads({**fixed, **env})
         assert np.array_equal(out, base_out), env
         assert np.array_equal(g, base_g), env
@@ -804,7 +808,7 @@ def test_bench_configuration_scatter_forms_agree_at_full_batch(tcnn, oracle, mon
     # the default MLP kernel of this shape (k_mlp_train_r32) only takes level planes in and records out: its own variants first ...
     r32_g, r32_out = grads({})
     assert np.count_nonzero(r32_g) > 5_000_000
-    for env, steps in (({}, 1), ({"TCNN_AMD_SCATTER_TUNE": "0"}, 3)):
+    for env, steps in (({}, 1), ({"TCNN_AMD_SCATTER_TUNE": "0"}, 3), ({"TCNN_AMD_SCATTER_LISTS": "0"}, 3), ({"TCNN_AMD_SCATTER_WIDE": "1"}, 1)):
         g, out = grads(env, steps=steps)
         assert np.array_equal(g, r32_g) and np.array_equal(out, r32_out), (env, steps)
     # ... then every form of the encoding's kernels behind ONE MLP kernel that takes them all (another MLP kernel is another fp32
@@ -814,7 +818,7 @@ def test_bench_configuration_scatter_forms_agree_at_full_batch(tcnn, oracle, mon
     assert np.count_nonzero(base_g) > 5_000_000
     first_g, first_out = grads(fixed, steps=1)
     assert np.array_equal(first_g, base_g) and np.array_equal(first_out, base_out)
-    for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_GRID_PLANES": "0"}):
+    for env in ({"TCNN_AMD_SCATTER_RECORDS": "0"}, {"TCNN_AMD_SCATTER_TUNE": "0"}, {"TCNN_AMD_GRID_PLANES": "0"}, {"TCNN_AMD_SCATTER_LISTS": "0"}, {"TCNN_AMD_SCATTER_LISTS": "0", "TCNN_AMD_SCATTER_RECORDS": "0"}):
         g, out = grads({**fixed, **env})
         assert np.array_equal(out, base_out), env
         assert np.array_equal(g, base_g), env
@@ -823,6 +827,81 @@ def test_bench_configuration_scatter_forms_agree_at_full_batch(tcnn, oracle, mon
     a, b = _f32(g), _f32(base_g)
     assert float(np.linalg.norm(a - b)) <= 2e-2 * float(np.linalg.norm(b))
     assert np.array_equal(g == 0, base_g == 0) or np.count_nonzero((g == 0) != (base_g == 0)) < 1000  # the same entries are touched (an fp16 sum may cancel to zero)
+
+
+LIST_SCATTER_CASES = [
+    # (n_in, n, encoding): 2-D / 3-D, 2 / 4 features, hashed, dense and tiled levels, Nearest / Smoothstep, tables of one chunk up to 64
+    (2, 16384, CONFIG_C3A["encoding"]),
+    (2, 4096 + 256, CONFIG_C3B["encoding"]),
+    (3, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 18, "base_resolution": 8, "per_level_scale": 2.0}),
+    (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 17, "base_resolution": 16, "per_level_scale": 2.0}),
+    (2, 4096, {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 8, "log2_hashmap_size": 14, "base_resolution": 16, "per_level_scale": 2.0}),
+    (2, 8192, {"otype": "DenseGrid", "n_levels": 6, "n_features_per_level": 2, "base_resolution": 16, "per_level_scale": 2.0}),
+    (2, 8192, {"otype": "TiledGrid", "n_levels": 8, "n_features_per_level": 2, "base_resolution": 128, "per_level_scale": 1.5}),
+    (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 16, "per_level_scale": 2.0, "interpolation": "Nearest"}),
+    (3, 4096, {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 8, "per_level_scale": 2.0, "interpolation": "Smoothstep"}),
+    (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 16, "per_level_scale": 2.0, "hash": "Prime"}),
+]
+
+
+@pytest.mark.parametrize("n_in,n,enc_cfg", LIST_SCATTER_CASES)
+def test_hit_list_scatter_is_exact(tcnn, oracle, monkeypatch, n_in, n, enc_cfg):
+    """k_grid_scatter_lists (hit lists written by the forward kernel, two 32-bit sums per 64-bit LDS add) inside training_step():
+    the grid's gradients bit-identical to the bit-plane form (TCNN_AMD_SCATTER_LISTS=0: k_grid_scatter), to its own 64-bit passes
+    (TCNN_AMD_SCATTER_WIDE=1) and -- given the same dL/d(encoded input), which the record form's scatter reads back out of the MLP kernel's
+    output -- to the oracle's exact sum; over three steps (the task list is re-cut from measured timings after the second), in Overwrite mode."""
+    cfg = {**CONFIG_C3B, "encoding": enc_cfg}
+    x, t = oracle.synthetic_batch(n, n_in, 3, seed=23)
+    x[:8] = np.float32([[0.0] * n_in, [1.0] * n_in, [0.5] * n_in, [0.999999] * n_in, [1e-7] * n_in, [0.25] * n_in, [0.75] * n_in, [0.125] * n_in])  # cell corners and edges
+    n_net = oracle.Trainer(n_in, 3, cfg, seed=1337).model.network.n_params
+
+    def grads(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(n_in, 3, cfg, seed=1337)
+        for _ in range(3):
+            ctx = tr.training_step(_t(x), _t(t), run_optimizer=False)
+        res = _bits(tr.param_gradients())[n_net:].copy(), _bits(ctx.output()).copy(), tr.scatter_wide_fallbacks()
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
+
+    g, out, fb = grads({"TCNN_AMD_SCATTER_LISTS": "1"})  # (1: also for grids of few chunks per level, where the default keeps the bit planes)
+    assert np.any(g != 0)  # (fb: tasks whose bound on sum |product| failed -- at small batches each sample's gradient is large -- took the 64-bit passes: same bits)
+    for env in ({"TCNN_AMD_SCATTER_LISTS": "0"}, {"TCNN_AMD_SCATTER_LISTS": "1", "TCNN_AMD_SCATTER_WIDE": "1"}, {}):
+        g2, out2, _ = grads(env)
+        assert np.array_equal(out2, out), env
+        assert np.array_equal(g2, g), env
+
+
+def test_hit_list_scatter_falls_back_to_wide_sums(tcnn, oracle, monkeypatch):
+    """Targets of 1e4 make dL/d(encoding) large enough that sum |product| of a task exceeds what 32-bit sums are proven to hold
+    (128 in loss-scaled units): those tasks must notice, discard their packed sums and run the 64-bit passes -- same gradients as the
+    bit-plane kernel, which always sums in 64 bits.  Accumulate mode on top (the packed sums start from the existing gradient)."""
+    n = 16384
+    cfg = {**CONFIG_C3A, "loss": {"otype": "L2"}}
+    x, t = oracle.synthetic_batch(n, 2, 3, seed=29)
+    t = (t * 1e4).astype(np.float32)
+    n_net = oracle.Trainer(2, 3, cfg, seed=1337).model.network.n_params
+
+    def grads(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, cfg, seed=1337)
+        for _ in range(2):
+            ctx = tr.training_step(_t(x), _t(t), run_optimizer=False)
+        g1 = _bits(tr.param_gradients())[n_net:].copy()
+        ctx = tr.training_step(_t(x), _t(t), run_optimizer=False, gradient_mode=2)  # on top of the existing gradients (GradientMode::Accumulate)
+        res = g1, _bits(tr.param_gradients())[n_net:].copy(), tr.scatter_wide_fallbacks()
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
+
+    g, g_acc, fb = grads({})
+    assert fb > 0 and np.any(g != 0)
+    g0, g0_acc, fb0 = grads({"TCNN_AMD_SCATTER_LISTS": "0"})
+    assert fb0 == 0
+    assert np.array_equal(g, g0) and np.array_equal(g_acc, g0_acc)
 
 
 CONFIG_3D_F2 = dict(CONFIG_C3B, encoding={"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 18, "base_resolution": 8, "per_level_scale": 2.0})

@@ -303,6 +303,9 @@ int tcnn_trainer_inference_mixed_precision(tcnn_trainer_t t, tcnn_stream_t strea
 size_t tcnn_trainer_n_params(tcnn_trainer_t t) { return t->trainer->n_params(); }
 size_t tcnn_trainer_params_updated_in_flush(tcnn_trainer_t t) { return t->trainer->params_updated_in_flush(); }
 size_t tcnn_trainer_image_preps(tcnn_trainer_t t) { return t->trainer->image_preps(); }
+size_t tcnn_trainer_scatter_wide_fallbacks(tcnn_trainer_t t) {
+	try { return (size_t)t->trainer->scatter_wide_fallbacks(); } catch (const std::exception& e) { g_last_error = e.what(); return (size_t)-1; }
+}
 uint32_t tcnn_trainer_padded_output_width(tcnn_trainer_t t) { return t->trainer->model().padded_output_width(); }
 float* tcnn_trainer_params_full_precision(tcnn_trainer_t t) { return t->trainer->params_full_precision(); }
 void* tcnn_trainer_params(tcnn_trainer_t t) { return t->trainer->params(); }

@@ -66,11 +66,12 @@ __device__ inline uint32_t rng_hash_device(const uint32_t* pos, int n_dims) {
 }
 
 // grid_index (common_device.h:690-707) with the stride loop folded into GridLevel::stride / ::hashed on the host
-template <int D>
+// RNG = false: the caller has excluded HashType::Rng on the host (its pcg32 advance is a loop; k_grid_scatter_lists wants loop-free code between its loads and their uses)
+template <int D, bool RNG = true>
 __device__ inline uint32_t level_index(const GridLevel& lv, const uint32_t* primes, uint32_t hash_type, const uint32_t* cell) {
 	uint32_t index;
 	if (lv.hashed) {
-		if (hash_type == (uint32_t)HashType::Rng) {
+		if (RNG && hash_type == (uint32_t)HashType::Rng) {
 			index = rng_hash_device(cell, D);
 		} else {
 			index = 0;

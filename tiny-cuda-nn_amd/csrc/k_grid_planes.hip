@@ -7,9 +7,12 @@
 //     that XCD's run in order, so an XCD gathers from one or two tables at a time and they stay in its L2;
 //   * a thread owns ONE level of SPT samples (8 x 4 gathers in flight), and the output is written as level planes
 //     half [L][n][F] (dense 256-B stores per wave) which the fused MLP kernel reads directly;
-//   * the sample filter of the owner-computes scatter (bit planes over samples per (level, table chunk)) is produced
-//     here, in LDS with integer ORs (or ballots for levels with few chunks), instead of a uint64 mask per (sample, level)
-//     in HBM plus a transposition kernel.
+//   * the sample filter of the owner-computes scatter is produced here.  Round 4 (LISTS): as HIT LISTS (GridHitLists, tcnn_common.h) --
+//     a workgroup's item (FP_THREADS x FP_SPT samples of one level) is counting-sorted by chunk in LDS -- a rank per element from one
+//     returning LDS add on the chunk's counter, a 64-lane scan for the chunks' offsets -- and leaves as ONE contiguous, chunk-sorted run
+//     in the item's own region of the level's pool (coalesced stores) with its 65 offsets beside it.  No global atomics.  The scatter
+//     then walks the items' runs of its chunk instead of scanning a bit plane.  Before: bit planes over samples per (level, chunk),
+//     built in LDS with integer ORs (or ballots for levels with few chunks); kept for callers without lists.
 #include "grid_device.h"
 #include "mlp_side_jobs.h"
 
@@ -29,10 +32,10 @@ constexpr int FP_PER_LANE = FP_MAX_CHUNKS / 64;       // chunks whose words one 
 // FP_SPT = samples per thread = consecutive 64-sample groups per wave; a work item is FP_THREADS * FP_SPT samples of one level.
 // Shapes: 4 (16 gathers in flight per thread; 8 is kept for A/B runs), and 2 for the big 3-D grids whose 8 corners x 4 features would
 // not fit the registers.
-template <int D, int F, int FP_SPT>
+template <int D, int F, int FP_SPT, bool LISTS>
 __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 	const GridMeta* __restrict__ meta, const uint32_t* __restrict__ work, const uint32_t max_items, const uint32_t blocks_per_xcd, const uint32_t n, const MatView x,
-	const half_t* __restrict__ grid, half_t* __restrict__ out, unsigned long long* __restrict__ bits, const MlpPrepJob prep
+	const half_t* __restrict__ grid, half_t* __restrict__ out, unsigned long long* __restrict__ bits, const MlpPrepJob prep, const GridHitLists lists
 ) {
 	typedef typename VecOf<half_t, F>::type vecF;
 	if (prep.image) { // side job (mlp_side_jobs.h): the fragment images of the network this batch is encoded for; independent of everything below
@@ -41,7 +44,25 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 	}
 	constexpr int FP_WAVE_SAMPLES = 64 * FP_SPT;
 	constexpr int FP_ITEM_SAMPLES = FP_THREADS * FP_SPT;
-	__shared__ unsigned long long planes[FP_THREADS / 64][FP_SPT][FP_MAX_CHUNKS];
+	constexpr int STAGE_ELEMS = FP_ITEM_SAMPLES << (D - 1); // one element per (sample, row) of an item
+	// bit planes (!LISTS) or the item's counting sort (LISTS): the staged elements, counters, offsets
+	__shared__ __attribute__((aligned(16))) unsigned long long lds_raw[LISTS ? STAGE_ELEMS / 2 + 72 : (FP_THREADS / 64) * FP_SPT * FP_MAX_CHUNKS];
+	typedef unsigned long long plane_row[FP_SPT][FP_MAX_CHUNKS];
+	plane_row* planes = (plane_row*)lds_raw; // [FP_THREADS / 64][FP_SPT][FP_MAX_CHUNKS]
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	uint32_t* l_stage = (uint32_t*)lds_raw;                 // [STAGE_ELEMS] the item's elements in chunk order
+	uint32_t* l_cnt = (uint32_t*)(lds_raw + STAGE_ELEMS / 2); // [64] elements of this item per chunk (zero between items)
+	uint32_t* l_off = l_cnt + 64;                           // [64] first staged position of the chunk
+	uint32_t* l_total = l_cnt + 128;
+	static_assert(FP_MAX_CHUNKS == 64, "one lane per chunk");
+	if constexpr (LISTS) {
+		if (threadIdx.x < 64) l_cnt[threadIdx.x] = 0;
+		// the counter set of the next forward launch on this stream (nobody reads it any more: the scatter that did has finished)
+		if (blockIdx.x == gridDim.x - 1 && lists.zero_counts) {
+			for (uint32_t e = threadIdx.x; e < meta->n_levels * GRID_HIT_COUNT_STRIDE; e += FP_THREADS) lists.zero_counts[e] = 0;
+		}
+		__syncthreads();
+	}
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
@@ -57,18 +78,22 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 	for (int d = 0; d < D; ++d) primes[d] = meta->primes[d];
 	const uint32_t n_words = n / 64;
 	constexpr int C = 1 << D;
+	constexpr int R_ROWS = C / 2;
+	constexpr uint32_t HIT_SHIFT = grid_hit_mask_shift(D);
 
 	for (uint32_t it = slot; it < n_items; it += blocks_per_xcd) {
 		const uint32_t w = items[it];
 		const uint32_t level = w >> 24;
 		const uint32_t base = (w & 0xffffffu) * FP_ITEM_SAMPLES + wave * FP_WAVE_SAMPLES; // first sample of this wave
-		if (base >= n) continue;
+		if constexpr (!LISTS) { if (base >= n) continue; } // (LISTS: the waves of a workgroup meet at barriers; a wave past the end recomputes the last sample and emits nothing)
 		const GridLevel lv = meta->levels[level];
 		const half_t* __restrict__ lgrid = grid + (size_t)lv.offset * F;
 		half_t* __restrict__ lout = out + (size_t)level * n * F;
 		const uint32_t n_chunks = lv.scatter_n_chunks;
-		const bool want_bits = bits != nullptr && n_chunks > 1 && n_chunks <= FP_MAX_CHUNKS;
+		const bool want_bits = !LISTS && bits != nullptr && n_chunks > 1 && n_chunks <= FP_MAX_CHUNKS;
 		const bool lds_or = want_bits && n_chunks > 8;
+		const bool want_lists = LISTS && n_chunks > 1 && n_chunks <= FP_MAX_CHUNKS; // workgroup-uniform: depends on the level only
+		uint32_t cr[FP_SPT][R_ROWS]; // per (sample, element): corner mask << 24 | chunk << 16 | rank inside (item, chunk); ~0: no element
 		const bool nearest = interpolation == (uint32_t)InterpolationType::Nearest;
 
 		if (lds_or) {
@@ -111,6 +136,7 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 			for (int d = 0; d < D; ++d) cell[d] = pos_fract(xin[d], lv.scale, interpolation, &pos[k][d], &pd);
 			touched[k] = 0;
 			sel[k] = 0;
+			uint32_t ch_a[R], ch_b[R]; // LISTS: the chunks of row r's two corners
 #pragma unroll
 			for (int r = 0; r < R; ++r) {
 				if (r > 0 && nearest) { P[k][r] = P[k][0]; E[k][r] = E[k][0]; continue; }
@@ -134,6 +160,76 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 				if (want_bits) {
 					note_chunk(k, idx0);
 					if (!nearest) note_chunk(k, idx1);
+				}
+				if constexpr (LISTS) {
+					if (want_lists) {
+						ch_a[r] = scatter_chunk(lv, idx0);
+						ch_b[r] = nearest ? ch_a[r] : scatter_chunk(lv, idx1);
+					}
+				}
+			}
+			if constexpr (LISTS) {
+				// One element per (sample, chunk) holding corners of the sample: row r's corner A opens an element unless an earlier row's
+				// chunk is the same (dense levels: both rows of a cell usually lie in one chunk -- one element, one record gather in the
+				// scatter); the B corners join the element of their chunk, or -- a row that straddles two chunks, one in ~8000 -- go to
+				// that chunk's list directly.
+#pragma unroll
+				for (int r = 0; r < R_ROWS; ++r) cr[k][r] = 0xffffffffu;
+				if (want_lists && base + k * 64 + lane < n) {
+					uint32_t pmask[R_ROWS];
+					bool used[R_ROWS];
+#pragma unroll
+					for (int r = 0; r < R_ROWS; ++r) {
+						used[r] = !(nearest && r > 0);
+						pmask[r] = 1u << (2 * r);
+#pragma unroll
+						for (int j = 0; j < r; ++j) {
+							if (used[r] && used[j] && ch_a[j] == ch_a[r]) { pmask[j] |= 1u << (2 * r); used[r] = false; }
+						}
+					}
+					if (!nearest) {
+#pragma unroll
+						for (int r = 0; r < R_ROWS; ++r) {
+							bool placed = false;
+#pragma unroll
+							for (int j = 0; j < R_ROWS; ++j) {
+								if (!placed && used[j] && ch_a[j] == ch_b[r]) { pmask[j] |= 2u << (2 * r); placed = true; }
+							}
+							if (!placed) { // the row straddles two chunks: corner B goes to the level's straggler list
+								const uint32_t at = atomicAdd(&lists.counts[level * GRID_HIT_COUNT_STRIDE], 1u);
+								if (at < lists.straggler_capacity) {
+									typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+									*(u2*)&lists.stragglers[((size_t)level * lists.straggler_capacity + at) * 2] = u2{i | (2u << (2 * r)) << HIT_SHIFT, ch_b[r]};
+								}
+							}
+						}
+					}
+#pragma unroll
+					for (int r = 0; r < R_ROWS; ++r) {
+						if (used[r]) {
+							const uint32_t rank = __hip_atomic_fetch_add((lds_u32*)&l_cnt[ch_a[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							cr[k][r] = pmask[r] << 24 | ch_a[r] << 16 | rank;
+						}
+					}
+				}
+			}
+		}
+		if constexpr (LISTS) {
+			if (want_lists) {
+				__syncthreads(); // every element of the item has its rank
+				if (wave == 0) {
+					const uint32_t cnt = l_cnt[lane];
+					l_cnt[lane] = 0;
+					uint32_t incl = cnt;
+#pragma unroll
+					for (int o = 1; o < 64; o <<= 1) {
+						const uint32_t up = __shfl_up(incl, o);
+						if (lane >= (uint32_t)o) incl += up;
+					}
+					l_off[lane] = incl - cnt;
+					uint32_t* heads = lists.heads + ((size_t)level * lists.n_items + (w & 0xffffffu)) * GRID_HIT_HEADS;
+					heads[lane] = incl - cnt;
+					if (lane == 63) { heads[64] = incl; *l_total = incl; }
 				}
 			}
 		}
@@ -182,6 +278,23 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 			}
 		}
 
+		// ---- phase 3 (LISTS): the item's elements, staged in chunk order, leave as one run into the item's region of the level's pool
+		if constexpr (LISTS) {
+			if (want_lists) {
+				__syncthreads(); // the chunks' offsets are there
+#pragma unroll
+				for (int k = 0; k < FP_SPT; ++k)
+#pragma unroll
+					for (int r = 0; r < R_ROWS; ++r) {
+						const uint32_t v = cr[k][r];
+						if (v != 0xffffffffu) l_stage[l_off[(v >> 16) & 0xffu] + (v & 0xffffu)] = (base + k * 64 + lane) | (v >> 24) << HIT_SHIFT;
+					}
+				__syncthreads();
+				const uint32_t total = *l_total;
+				uint32_t* dst = lists.elems + ((size_t)level * lists.n_items + (w & 0xffffffu)) * lists.item_capacity;
+				for (uint32_t p = tid; p < total; p += FP_THREADS) dst[p] = l_stage[p];
+			}
+		}
 		// ---- phase 3: bit planes.  Lane c ends up with the FP_SPT consecutive words of chunk c (and of chunk c + 64): dense runs per lane.
 		if (want_bits) {
 #pragma unroll
@@ -221,11 +334,16 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 
 template <int D, int F, int SPT>
 void launch_planes(hipStream_t s, const GridMeta* dm, const uint32_t* work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n, MatView x, const void* grid, void* out, uint64_t* bits,
-                   const MlpPrepJob* prep_job) {
+                   const MlpPrepJob* prep_job, const GridHitLists* hit_lists) {
 	MlpPrepJob prep{};
 	if (prep_job) prep = *prep_job;
-	hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
-	                   (unsigned long long*)bits, prep);
+	if (hit_lists) {
+		hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT, true>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
+		                   nullptr, prep, *hit_lists);
+	} else {
+		hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT, false>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
+		                   (unsigned long long*)bits, prep, GridHitLists{});
+	}
 	HIP_CHECK_THROW(hipGetLastError());
 }
 
@@ -236,6 +354,8 @@ uint32_t max_scatter_chunks(const GridMeta& meta) {
 }
 
 } // namespace
+
+uint32_t grid_hit_item_samples(const GridMeta& meta) { return FP_THREADS * grid_planes_spt(meta); }
 
 // samples per thread of the kernel shape used for this grid (see k_grid_fwd_planes)
 uint32_t grid_planes_spt(const GridMeta& meta) {
@@ -297,14 +417,17 @@ void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& w
 }
 
 void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
-                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits, const MlpPrepJob* prep_job) {
+                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits, const MlpPrepJob* prep_job, const GridHitLists* hit_lists) {
 	CHECK_THROW(grid_planes_supported(meta, n));
+	CHECK_THROW(!hit_lists || (hit_lists->elems && hit_lists->heads && hit_lists->stragglers && hit_lists->counts && n <= grid_hit_max_samples(meta) &&
+	                           hit_lists->item_samples == grid_hit_item_samples(meta) && hit_lists->n_items == div_round_up(n, hit_lists->item_samples) &&
+	                           hit_lists->item_capacity >= (hit_lists->item_samples << (meta.n_pos_dims - 1))));
 	const uint32_t F = meta.n_features_per_level;
 #define TCNN_PLANES_F(D, SPT) \
 	switch (F) { \
-		case 2: return launch_planes<D, 2, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job); \
-		case 4: return launch_planes<D, 4, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job); \
-		default: return launch_planes<D, 8, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job); \
+		case 2: return launch_planes<D, 2, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job, hit_lists); \
+		case 4: return launch_planes<D, 4, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job, hit_lists); \
+		default: return launch_planes<D, 8, SPT>(stream, dev_meta, dev_work, max_items, blocks_per_xcd, n, x, grid, out_planes, chunk_bits, prep_job, hit_lists); \
 	}
 #define TCNN_PLANES(D) \
 	if (grid_planes_spt(meta) == 8) { TCNN_PLANES_F(D, 8) } else if (grid_planes_spt(meta) == 4) { TCNN_PLANES_F(D, 4) } else { TCNN_PLANES_F(D, 2) }

@@ -600,8 +600,23 @@ bool grid_scatter_records_supported(const GridMeta& meta) {
 	return (D == 2 && (F == 2 || F == 4)) || (D == 3 && F == 2);
 }
 
+// Hit lists and the finer cut that goes with them pay where the grid has levels of MANY chunks: there the bit-plane form scans 32 KB per
+// task to find the 3 % of samples that hit, and the lists' price in the forward kernel (~0.5 us per level) is small against its gathers.
+// A grid whose levels all fit a few chunks (config_hash.json: T = 2^15, at most 4 chunks per level) is served better by the bit planes'
+// ballot form -- its tasks stream the samples in order and test them, no gathers at all (measured on it: lists 0.149 ms per step, bit planes 0.135).
+bool grid_scatter_prefers_lists(const GridMeta& meta) {
+	if (!grid_scatter_records_supported(meta) || meta.hash_type == (uint32_t)HashType::Rng || meta.n_pos_dims > 3) return false;
+	const uint32_t capacity = SCATTER_ACC_BYTES / (meta.n_features_per_level * 8);
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		const uint32_t k = div_round_up(meta.levels[l].size, capacity);
+		if (k > 8 && k <= SCATTER_MAX_CHUNKS) return true;
+	}
+	return false;
+}
+
 void grid_scatter_setup_levels(GridMeta& meta) {
 	const uint32_t capacity = SCATTER_ACC_BYTES / (meta.n_features_per_level * 8); // entries one workgroup can own (64-bit accumulators)
+	const bool prefers_lists = grid_scatter_prefers_lists(meta);
 	auto cut = [](GridLevel& lv, uint32_t entries_per_chunk) {
 		lv.scatter_n_chunks = div_round_up(lv.size, entries_per_chunk);
 		lv.scatter_per_chunk = next_multiple(div_round_up(lv.size, lv.scatter_n_chunks), 8u);
@@ -623,6 +638,17 @@ void grid_scatter_setup_levels(GridMeta& meta) {
 		const uint32_t bin_capacity = grid_bin_acc_bytes() / (meta.n_features_per_level * 8); // the binned kernels have their own chunk size
 		lv.scatter_binned = (lv.scatter_n_chunks > bin_above && div_round_up(lv.size, bin_capacity) <= grid_bin_max_chunks() && grid_bin_supported(meta)) ? 1u : 0u;
 		if (lv.scatter_binned) cut(lv, bin_capacity);
+		// Round 4: a level that fits fewer chunks than the filter can describe is cut finer anyway -- into up to 64 chunks of at least 256
+		// entries -- where the scatter gathers one record per hit (the forms with records).  Every chunk then has ONE owner whatever the
+		// level's size: a level of 16 384 entries used to be 2 chunks shared by ~35 workgroups each (split over the samples), every one
+		// of them flushing 16 384 64-bit global atomics into the scratch table (~10 us per task, measured) for the finalize pass to round;
+		// as 64 chunks of 256 entries it is 64 tasks like those of the hashed levels, no scratch, no atomics.  Levels below 8192 entries
+		// stay one chunk: their tasks stream the samples in order (no gathers) and their flush is small.  TCNN_AMD_SCATTER_FINE_CUT=0: as before.
+		static const bool fine_cut = [] { const char* e = getenv("TCNN_AMD_SCATTER_FINE_CUT"); return !(e && e[0] == '0'); }();
+		if (fine_cut && prefers_lists && !lv.scatter_binned && lv.size >= 8192 && lv.scatter_n_chunks < SCATTER_MAX_CHUNKS) {
+			const uint32_t per_chunk = std::min(capacity, std::max(256u, next_multiple(div_round_up(lv.size, SCATTER_MAX_CHUNKS), 8u)));
+			cut(lv, per_chunk);
+		}
 	}
 }
 
@@ -869,12 +895,15 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
 		case 4: dispatch_scatter<4>(stream, meta.n_features_per_level, dev_meta, dev_tasks, n_tasks, n, x, dL_dy, dy_stride_sample, dy_stride_level, grad, bits, sc, accumulate, dy_records, adam); break;
 		default: throw std::runtime_error{"GridEncoding: number of input dims must be 2 or 3."};
 	}
-	if (n_ranges > 0) {
-		const uint32_t n_reduce_blocks = reduce_job ? div_round_up(reduce_job->n_elems, (uint32_t)SLAB_REDUCE_ELEMS) : 0;
-		hipLaunchKernelGGL(k_grid_scatter_finalize, dim3(n_reduce_blocks + n_ranges * FINALIZE_BLOCKS_PER_RANGE), dim3(FINALIZE_THREADS), 0, stream, dev_ranges, sc, (half_t*)grad,
-		                   accumulate ? 1 : 0, n_reduce_blocks, reduce_job ? *reduce_job : MlpReduceJob{});
-		if (reduce_job) reduce_job->taken = true;
-	}
+	grid_scatter_finalize(stream, dev_ranges, n_ranges, scratch, grad, accumulate, reduce_job);
+}
+
+void grid_scatter_finalize(hipStream_t stream, const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, void* grad, bool accumulate, const MlpReduceJob* reduce_job) {
+	if (n_ranges == 0) return;
+	const uint32_t n_reduce_blocks = reduce_job ? div_round_up(reduce_job->n_elems, (uint32_t)SLAB_REDUCE_ELEMS) : 0;
+	hipLaunchKernelGGL(k_grid_scatter_finalize, dim3(n_reduce_blocks + n_ranges * FINALIZE_BLOCKS_PER_RANGE), dim3(FINALIZE_THREADS), 0, stream, dev_ranges, (unsigned long long*)scratch, (half_t*)grad,
+	                   accumulate ? 1 : 0, n_reduce_blocks, reduce_job ? *reduce_job : MlpReduceJob{});
+	if (reduce_job) reduce_job->taken = true;
 }
 
 } // namespace tcnn_amd

@@ -216,6 +216,10 @@ struct EncodingContext {
 	ArenaBuf to_reduce; // Composite encoding with a Sum / Product reduction: the nested outputs [nested][n][width]
 	ArenaBuf dy_dx;       // grid only: float [n][L*F][D]
 	ArenaBuf chunk_mask;  // grid only: uint64 [L][32][n/64] bit planes, which samples touch which scatter chunk (filter for the LDS scatter)
+	ArenaBuf hit_elems;   // grid only, instead of chunk_mask: the hit lists of this batch (GridHitLists::elems); counters and validity below
+	GridHitLists hit_lists;
+	uint64_t hit_generation = 0; // the encoding's list counters are reused by later forward passes: lists are valid while this is the latest one on its stream
+	const void* hit_stream = nullptr;
 	uint32_t n = 0;
 	mutable bool dy_records = false; // the level planes handed to backward() hold 16-byte scatter records {coordinates, gradients} (mlp_train_fused); set by the caller of backward()
 	// Set by the caller of backward() for a step whose optimizer update may ride on the gradient kernel (AdamInFlush, arrays
@@ -265,6 +269,7 @@ public:
 	// true: backward() (with level planes allowed) prefers 16-byte records {coordinates, gradients} per (level, sample)
 	virtual bool scatter_records_usable(MatView x) const { return false; }
 	virtual uint32_t scatter_record_planes() const { return 0; } // 16-byte records per sample when scatter_records_usable()
+	virtual uint64_t scatter_wide_fallbacks() { return 0; }      // grid only: tasks of the list-fed scatter that had to take the 64-bit passes
 	// > 0: forward_planes() can write the encoded batch as level planes [padded / F][n][F] (no input gradients in that form)
 	virtual uint32_t forward_plane_features(uint32_t n) { return 0; }
 	// prep_job (optional): a side job the forward kernel carries along -- the fragment images of the network behind the encoding
@@ -457,12 +462,35 @@ public:
 		EncodingContext ctx;
 		CHECK_THROW(forward_plane_features(n) > 0);
 		const bool want_filter = prepare_param_gradients && lds_scatter_usable();
-		if (want_filter) {
+		const bool want_lists = want_filter && hit_lists_usable(n);
+		if (want_lists) {
+			// Hit lists (k_grid_scatter_lists.hip): the storage is this pass's own; the stragglers' counts live in one of the stream's two
+			// counter sets -- this launch counts in one and zeroes the other for the next forward pass, so no memset sits between the steps.
+			HitCounters& hc = hit_counters(stream);
+			GridHitLists& hl = ctx.hit_lists;
+			hl.item_samples = grid_hit_item_samples(m_meta);
+			hl.n_items = div_round_up(n, hl.item_samples);
+			hl.item_capacity = hl.item_samples << (m_meta.n_pos_dims - 1);
+			hl.straggler_capacity = n << (m_meta.n_pos_dims - 1);
+			const size_t L = m_meta.n_levels;
+			const size_t elems_bytes = L * hl.n_items * hl.item_capacity * sizeof(uint32_t), heads_bytes = next_multiple_sz(L * hl.n_items * GRID_HIT_HEADS * sizeof(uint32_t), 256);
+			ctx.hit_elems = ArenaBuf{stream, elems_bytes + heads_bytes + L * hl.straggler_capacity * 2 * sizeof(uint32_t)};
+			hl.elems = ctx.hit_elems.as<uint32_t>();
+			hl.heads = (uint32_t*)((char*)ctx.hit_elems.data() + elems_bytes);
+			hl.stragglers = (uint32_t*)((char*)ctx.hit_elems.data() + elems_bytes + heads_bytes);
+			hl.counts = hc.sets[hc.next].as<uint32_t>();
+			hl.zero_counts = hc.sets[hc.next ^ 1].as<uint32_t>();
+			hc.next ^= 1;
+			ctx.hit_generation = ++hc.generation;
+			ctx.hit_stream = (const void*)stream;
+			ctx.n = n;
+		} else if (want_filter) {
 			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_scatter_max_chunks() * (n / 64) * sizeof(uint64_t)};
 			ctx.n = n;
 		}
 		PlanesPlan& plan = planes_plan(n);
-		grid_forward_planes(stream, m_meta, dev_meta(), plan.dev_work.as<uint32_t>(), plan.max_items, plan.blocks_per_xcd, n, x, params, out_planes, ctx.chunk_mask.as<uint64_t>(), prep_job);
+		grid_forward_planes(stream, m_meta, dev_meta(), plan.dev_work.as<uint32_t>(), plan.max_items, plan.blocks_per_xcd, n, x, params, out_planes, ctx.chunk_mask.as<uint64_t>(), prep_job,
+		                    want_lists ? &ctx.hit_lists : nullptr);
 		return ctx;
 	}
 
@@ -480,6 +508,24 @@ public:
 				cast_float_to_half(stream, n_params(), tmp.as<float>(), grads);
 			} else if (lds_scatter_usable() && n % 64 == 0) {
 				// MI355X path: LDS owner-computes scatter with exact integer accumulation; writes every element (k_grid_scatter.hip)
+				// hit lists of this very batch, their counters not yet handed to a later forward pass of this stream
+				const bool lists = ctx.hit_elems && ctx.n == n && ctx.hit_stream == (const void*)stream && hit_counters(stream).generation == ctx.hit_generation &&
+				                   !(ctx.adam && mode == GradientMode::Overwrite);
+				if (lists) { // k_grid_scatter_lists.hip: a static plan, nothing to tune
+					ListsPlan& lp = lists_plan(n, stream, dy_planes && ctx.dy_records);
+					const uint32_t F = m_meta.n_features_per_level;
+					const uint32_t dy_stride_sample = dy_planes ? F : padded_output_width(), dy_stride_level = dy_planes ? n * F : F;
+					ctx.adam_done.clear();
+					grid_backward_lists(stream, m_meta, dev_meta(), lp.dev_tasks.as<GridScatterTask>(), lp.n_tasks,
+					                    lp.dev_ranges.as<GridScatterRange>(), lp.n_ranges, lp.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, ctx.hit_lists,
+					                    mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, ctx.reduce_job, hit_counters(stream).fallbacks.as<uint32_t>());
+					if (dL_dx) {
+						CHECK_THROW(ctx.dy_dx);
+						CHECK_THROW(!dy_planes);
+						grid_backward_input(stream, m_meta, m_fp32, n, dL_dy, padded_output_width(), ctx.dy_dx.as<float>(), *dL_dx);
+					}
+					return;
+				}
 				ScatterPlan& plan = scatter_plan(n, stream);
 				const uint32_t F = m_meta.n_features_per_level;
 				const uint64_t* mask = (ctx.chunk_mask && ctx.n == n) ? ctx.chunk_mask.as<uint64_t>() : nullptr;
@@ -621,6 +667,73 @@ public:
 		return *(m_scatter_plans[key] = std::move(plan));
 	}
 
+	// the list-fed kernel's tasks (grid_scatter_lists_plan), per (batch size, stream, record form): like ScatterPlan it owns device state a
+	// launch leaves behind for the next one on the same stream (the zeroed scratch table)
+	struct ListsPlan {
+		DeviceBuf dev_tasks, dev_ranges, scratch;
+		uint32_t n_tasks = 0, n_ranges = 0;
+	};
+	ListsPlan& lists_plan(uint32_t n, hipStream_t stream, bool records) {
+		const auto key = std::make_pair(n | (records ? 0x80000000u : 0u), (const void*)stream);
+		auto it = m_lists_plans.find(key);
+		if (it != m_lists_plans.end()) return *it->second;
+		auto plan = std::make_unique<ListsPlan>();
+		std::vector<GridScatterTask> tasks;
+		std::vector<GridScatterRange> ranges;
+		size_t scratch_elems = 0;
+		const bool paired = records && m_meta.n_pos_dims == 2 && m_meta.n_features_per_level == 2;
+		grid_scatter_lists_plan(m_meta, n, paired, tasks, ranges, scratch_elems);
+		plan->n_tasks = (uint32_t)tasks.size();
+		plan->n_ranges = (uint32_t)ranges.size();
+		auto upload = [](DeviceBuf& b, const void* src, size_t bytes) {
+			b.resize(bytes);
+			if (bytes) HIP_CHECK_THROW(hipMemcpy(b.data(), src, bytes, hipMemcpyHostToDevice));
+		};
+		upload(plan->dev_tasks, tasks.data(), tasks.size() * sizeof(GridScatterTask));
+		upload(plan->dev_ranges, ranges.data(), ranges.size() * sizeof(GridScatterRange));
+		plan->scratch.resize(scratch_elems * sizeof(uint64_t));
+		plan->scratch.memset(0); // the finalize pass leaves it zeroed again after every step
+		return *(m_lists_plans[key] = std::move(plan));
+	}
+
+	// Hit lists: TCNN_AMD_SCATTER_LISTS=0 keeps the bit planes (A/B runs, tests; read per step so that one process can cover both)
+	bool hit_lists_usable(uint32_t n) const {
+		const char* e = getenv("TCNN_AMD_SCATTER_LISTS"); // 0: never; 1: wherever the kernel can take the grid (tests); unset: where it pays (grid_scatter_prefers_lists)
+		if (e && e[0] == '0') return false;
+		if (const char* a = getenv("TCNN_AMD_ADAM_IN_FLUSH")) { if (a[0] == '1') return false; } // the optimizer step inside the flush is k_grid_scatter's
+		if (m_any_binned || n > grid_hit_max_samples(m_meta) || m_meta.n_pos_dims > 3 || m_meta.hash_type == (uint32_t)HashType::Rng) return false; // (Rng: its hash is a loop)
+		return (e && e[0] == '1') || grid_scatter_prefers_lists(m_meta);
+	}
+	static size_t next_multiple_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+	struct HitCounters {
+		DeviceBuf sets[2], fallbacks; // two sets of list tails [n_levels][GRID_HIT_COUNT_STRIDE]; how many tasks took the 64-bit passes
+		int next = 0;
+		uint64_t generation = 0;
+	};
+	HitCounters& hit_counters(hipStream_t stream) {
+		auto it = m_hit_counters.find((const void*)stream);
+		if (it != m_hit_counters.end()) return *it->second;
+		auto hc = std::make_unique<HitCounters>();
+		for (auto& set : hc->sets) {
+			set.resize((size_t)m_meta.n_levels * GRID_HIT_COUNT_STRIDE * sizeof(uint32_t));
+			set.memset(0);
+		}
+		hc->fallbacks.resize(sizeof(uint32_t));
+		hc->fallbacks.memset(0);
+		return *(m_hit_counters[(const void*)stream] = std::move(hc));
+	}
+public:
+	// tasks of the list-fed scatter that found their packed 32-bit sums unprovable and ran the 64-bit passes, since this encoding was built (all streams)
+	uint64_t scatter_wide_fallbacks() override {
+		uint64_t total = 0;
+		for (auto& kv : m_hit_counters) {
+			uint32_t v = 0;
+			HIP_CHECK_THROW(hipMemcpy(&v, kv.second->fallbacks.data(), sizeof(v), hipMemcpyDeviceToHost));
+			total += v;
+		}
+		return total;
+	}
+
 	Json hyperparams() const override { // grid.h:1098-1115
 		static const char* types[] = {"Hash", "Dense", "Tiled"};
 		static const char* interps[] = {"Nearest", "Linear", "Smoothstep"};
@@ -642,6 +755,8 @@ private:
 	GridMeta m_meta;
 	DeviceBuf m_dev_meta;
 	std::map<std::pair<uint32_t, const void*>, std::unique_ptr<ScatterPlan>> m_scatter_plans;
+	std::map<const void*, std::unique_ptr<HitCounters>> m_hit_counters;
+	std::map<std::pair<uint32_t, const void*>, std::unique_ptr<ListsPlan>> m_lists_plans;
 	std::map<uint32_t, std::unique_ptr<PlanesPlan>> m_planes_plans;
 	bool m_scatter_levels_ok = true;
 	bool m_any_binned = false;
@@ -1620,6 +1735,7 @@ public:
 	bool live_image_kept() const { return m_live_image_kept; }           // the last fused step's optimizer launch left the live image current
 	void invalidate_live_image() { m_network->invalidate_live_image(); } // the parameters change(d) some other way
 	size_t image_preps() const { return m_image_preps; }                 // k_mlp_prep launches of fused steps so far (a test's view of the above)
+	uint64_t scatter_wide_fallbacks() { return m_encoding->scatter_wide_fallbacks(); }
 	// the register-resident fused kernel (k_train_regs.hip) writes dL_doutput / L as compact [n][dims] matrices (TrainContext::compact)
 	bool fused_compact_context_supported(uint32_t n) const {
 		const bool ok = use_fused_step() && mlp_train_regs_supported(m_network->desc(), n) && m_network->padded_output_width() == 16;
@@ -2972,6 +3088,7 @@ public:
 	void* params() { expose_params(); return m_params.data(); }
 	const void* params_unexposed() const { return m_params.data(); } // for comparisons only
 	size_t image_preps() const { return m_model->image_preps(); }
+	uint64_t scatter_wide_fallbacks() { return m_model->scatter_wide_fallbacks(); }
 	void* param_gradients() const { return m_grads.data(); }
 
 private:

@@ -89,8 +89,33 @@ uint32_t grid_planes_spt(const GridMeta& meta);        // samples per thread of 
 void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd);
 // prep_job (optional, mlp_side_jobs.h; passed to the kernel by value): the kernel also builds the MLP's fragment images
 struct MlpPrepJob;
+// ---- hit lists (round 4): the scatter's sample filter as a STREAM instead of bit planes to be scanned.  For every level cut into
+// 2 .. GRID_FILTER_MAX_CHUNKS chunks the forward kernel writes, per work item (grid_hit_item_samples() consecutive samples of one level), the
+// item's elements SORTED BY CHUNK into the item's own region of the level's pool, plus 65 offsets: where each chunk's run starts inside
+// the region ([64]: how many elements the item has).  An element is 32 bits: the sample in the low bits, above them one bit per corner
+// of the cell, 2^D of them -- corner 2 r + b is corner b (0: cell_0, 1: cell_0 + 1) of cell row r (bit d - 1 of r set: cell_d + 1,
+// d = 1 .. D - 1) -- set where that corner's entry lies in the run's chunk.  A chunk's owner walks the items' runs of its chunk: no scan
+// of a bit plane, no compaction queue, nothing to test per sample.  No counters, no atomics: a region's place is the item's number
+// (the first form appended to one list per chunk through a global atomic on its tail per item and chunk -- 64 lanes, one
+// instruction -- and those 5632 same-address atomics alone cost the forward kernel 15 of its 72 us).  The one exception: a row whose
+// two corners fall into different chunks (one in ~8000) sends its second corner to the level's straggler list {element, chunk}, which
+// every owner of the level scans.
+inline constexpr uint32_t grid_hit_mask_shift(uint32_t n_pos_dims) { return 32u - (1u << n_pos_dims); } // 28 (2-D), 24 (3-D)
+constexpr uint32_t GRID_HIT_COUNT_STRIDE = 64;   // uint32 per level between the straggler counts (one memory channel each)
+constexpr uint32_t GRID_HIT_HEADS = 65;          // offsets per item: GRID_FILTER_MAX_CHUNKS + 1
+struct GridHitLists {
+	uint32_t* elems = nullptr;       // [n_levels][n_items][item_capacity]
+	uint32_t* heads = nullptr;       // [n_levels][n_items][GRID_HIT_HEADS]
+	uint32_t* stragglers = nullptr;  // [n_levels][straggler_capacity][2]: {element, chunk}
+	uint32_t* counts = nullptr;      // [n_levels][GRID_HIT_COUNT_STRIDE]: stragglers per level; all zero when the forward kernel starts
+	uint32_t* zero_counts = nullptr; // the counter set of the NEXT forward launch on this stream: zeroed by this one
+	uint32_t n_items = 0, item_samples = 0, item_capacity = 0, straggler_capacity = 0;
+};
+uint32_t grid_hit_item_samples(const GridMeta& meta); // samples per work item of the forward kernel shape used for this grid (k_grid_planes.hip)
+inline uint32_t grid_hit_max_samples(const GridMeta& meta) { return 1u << grid_hit_mask_shift(meta.n_pos_dims); }
+// hit_lists (optional, instead of chunk_bits): see above
 void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
-                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits, const MlpPrepJob* prep_job = nullptr);
+                         MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits, const MlpPrepJob* prep_job = nullptr, const GridHitLists* hit_lists = nullptr);
 // reference-shaped gradient scatter with global float atomics (fp32 grids, F == 1, tables too large for the LDS scheme).
 // grad: T[n_params] accumulated in place (caller zeroes it).  For F == 1 && !fp32 the caller passes an fp32 scratch as `grad`.
 void grid_backward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, bool fp32_grad, uint32_t n, MatView x, const void* dL_dy, bool dy_fp32, uint32_t dy_stride, void* grad);
@@ -111,6 +136,7 @@ typedef std::vector<std::pair<size_t, size_t>> ParamRanges; // sorted, disjoint 
 constexpr uint32_t GRID_FILTER_MAX_CHUNKS = 64;     // chunks per level the sample filter can describe (bit planes per level)
 uint32_t grid_scatter_max_chunks();                 // = GRID_FILTER_MAX_CHUNKS
 void grid_scatter_setup_levels(GridMeta& meta);     // fills GridLevel::scatter_* (how each level's table is cut into chunks)
+bool grid_scatter_prefers_lists(const GridMeta& meta); // the grid has levels of many chunks: hit lists (k_grid_scatter_lists.hip) instead of bit planes
 // Plans the task list for a batch of n samples (half gradients, F >= 2).
 // measured_level_us (optional): per-level workgroup time of a first launch (grid_scatter_level_costs) -> tuned task sizes
 void grid_scatter_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems,
@@ -129,6 +155,18 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
                        uint64_t* task_times = nullptr, // task_times (optional): device uint64[n_tasks][8], per-task timestamps for the plan tuner
                        const AdamInFlush* adam = nullptr, // adam (optional, record form only): arrays indexed like grad; see grid_scatter_adam_ranges
                        const MlpReduceJob* reduce_job = nullptr); // (optional) carried by the finalize launch when there is one; ->taken says so
+// ---- the same scatter fed by hit lists (k_grid_scatter_lists.hip): two workgroups per CU with 64 KiB of accumulators each -- both features
+// of an entry in ONE 64-bit LDS add as 2 x int32 while a per-task bound proves that no half can overflow, 64-bit accumulators in two
+// passes otherwise -- tasks of its own plan (GridScatterTask::pad = split s | n_splits << 16: which share of a chunk's list), same scratch, same results.
+uint32_t grid_scatter_lists_lds_bytes();
+// the kernel's tasks in launch order (one workgroup each; block b runs on XCD b % 8: k_grid_scatter_lists.hip)
+void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, bool paired_records, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems);
+void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
+                         const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
+                         const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const GridHitLists& lists, bool accumulate, bool dy_records,
+                         const MlpReduceJob* reduce_job, uint32_t* fallback_count = nullptr);
+// the finalize pass of the shared chunks (+ the MLP's slab reduction), shared by both scatter kernels
+void grid_scatter_finalize(hipStream_t stream, const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, void* grad, bool accumulate, const MlpReduceJob* reduce_job);
 // the parameter ranges (relative to grad) a launch of `tasks` with `adam` updates itself; empty = this plan cannot carry the optimizer step
 ParamRanges grid_scatter_adam_ranges(const GridMeta& meta, const std::vector<GridScatterTask>& tasks, bool dy_records);
 // dy_records: dL_dy is float4 [grid_scatter_record_planes()][n] scatter records {coordinates, gradient halves} (mlp_device.h

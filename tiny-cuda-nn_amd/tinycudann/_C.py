@@ -10,6 +10,8 @@ import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "libtcnn_amd.so")
+if os.environ.get("TCNN_AMD_LIB"):  # development: the laboratory build (build.py --dev, -DTCNN_AMD_DEV) in place of the product
+    LIB_PATH = os.path.abspath(os.environ["TCNN_AMD_LIB"])
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -108,6 +110,7 @@ _SIGNATURES = {
     "tcnn_trainer_optimizer_step_count": (_u32, [_vp]),
     "tcnn_trainer_params_updated_in_flush": (C.c_size_t, [_vp]),
     "tcnn_trainer_image_preps": (C.c_size_t, [_vp]),
+    "tcnn_trainer_scatter_wide_fallbacks": (C.c_size_t, [_vp]),
     "tcnn_trainer_profile_next_step": (_int, [_vp]),
     "tcnn_trainer_profile_collect": (_int, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_u32)]),
     "tcnn_trainer_serialize": (_int, [_vp, _int, _pp, C.POINTER(_sz)]),

@@ -102,6 +102,10 @@ class Trainer:
         """launches of the weight-rearranging kernel by this trainer's training steps so far (tcnn_amd.h: tcnn_trainer_image_preps)"""
         return int(_C.lib.tcnn_trainer_image_preps(self._h))
 
+    def scatter_wide_fallbacks(self):
+        """tasks of the grid gradient kernel that could not prove their packed 32-bit sums and ran the 64-bit passes (tcnn_amd.h)"""
+        return int(_C.lib.tcnn_trainer_scatter_wide_fallbacks(self._h))
+
     def profile_collect(self, stream=None):
         """-> ({piece: mean milliseconds per profiled step}, number of profiled steps)"""
         ms = (C.c_float * 4)()
