@@ -93,8 +93,10 @@ def c4_measure(steps, warmup, world, setup=None):
 
     tr, x = setup if setup is not None else c4_setup()
 
+    timing = {}  # the last step's events (tinycudann/parallel.py): kernel time and un-hidden exchange time apart
+
     def step():
-        return sharded_inference(lambda rows: tr.inference_half(rows), x, C4_OUT, out_dtype=torch.half, chunks=C4_CHUNKS if world > 1 else 1)
+        return sharded_inference(lambda rows: tr.inference_half(rows), x, C4_OUT, out_dtype=torch.half, chunks=C4_CHUNKS if world > 1 else 1, timing=timing)
 
     def barrier():
         torch.cuda.synchronize()
@@ -118,8 +120,17 @@ def c4_measure(steps, warmup, world, setup=None):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     b, e = shard_rows(C4_ROWS, world, 0)
-    kernel_ms = e0.elapsed_time(e1) / max(steps, 1)  # this rank's stream: its shard's kernels + the all-gather
-    return {"elapsed": elapsed, "rows_per_gpu": e - b, "stream_ms_per_step": kernel_ms, "checksum": float(y.double().sum().item())}
+    stream_ms = e0.elapsed_time(e1) / max(steps, 1)  # this rank's stream: its shard's kernels + the all-gather
+    res = {"elapsed": elapsed, "rows_per_gpu": e - b, "stream_ms_per_step": stream_ms, "checksum": float(y.double().sum().item())}
+    # the last timed step taken apart (this rank): the infer_fn calls, and what was left of the gathers when the kernels were done
+    if timing.get("kernel_events"):
+        res["kernel_ms"] = sum(k0.elapsed_time(k1) for k0, k1 in timing["kernel_events"])
+        g = timing.get("gather_wait_events")
+        res["gather_wait_ms"] = g[0].elapsed_time(g[1]) if g else 0.0
+    else:  # one rank: no exchange, the stream time is the kernels'
+        res["kernel_ms"], res["gather_wait_ms"] = stream_ms, 0.0
+    res["bytes_in"] = timing.get("bytes_in", 0)
+    return res
 
 
 def ranks_device(torch, local_rank, backend):
@@ -155,7 +166,8 @@ def run_c4(args):
             "value": C4_ROWS * args.steps / m["elapsed"], "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": m["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "c4: Identity + 128x4 FullyFusedMLP inference, 32 -> 16", "global_batch": C4_ROWS, "rows_per_gpu": m["rows_per_gpu"],
-                       "parallelism": f"rows x{world} + all_gather", "output_checksum": m["checksum"]},
+                       "parallelism": f"rows x{world} + all_gather", "output_checksum": m["checksum"],
+                       "kernel_ms": m["kernel_ms"], "gather_wait_ms": m["gather_wait_ms"], "bytes_in": m["bytes_in"]},
             "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<128>", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": None, "note": "stream time of rank 0 per step (MLP kernel + weight preparation + all-gather) over its shard's FLOPs"},
         }), flush=True)
@@ -166,7 +178,7 @@ def run_c4(args):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ENCODE_KERNEL = {"c3a": "k_grid_fwd_planes", "c3b": "k_grid_fwd_planes", "c5": "k_grid_fwd_planes"}
-SCATTER_KERNEL = {"c3a": "k_grid_scatter (+ finalize)", "c3b": "k_grid_scatter (+ finalize)", "c5": "k_bin_* + k_grid_scatter"}
+SCATTER_KERNEL = {"c3a": "k_grid_scatter_lists (+ finalize)", "c3b": "k_grid_scatter (+ finalize)", "c5": "k_bin_* + k_grid_scatter"}
 
 
 def hbm_piece(kernel, algorithmic_bytes, ms):
@@ -202,7 +214,7 @@ def cpu_baseline(name, budget_s=15.0):
         "unit": "samples/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{steps} training_step(s) of the CPU oracle at batch {sample_batch} (full Adam over all {tr.model.n_params} parameters each step)",
+        "sample": f"{steps} training_step(s) of the CPU oracle at batch {sample_batch} of the workload's {batch} (full Adam over all {tr.model.n_params} parameters each step)",
     }
 
 
@@ -303,7 +315,11 @@ def other_configs(tcnn, torch):
             ms = m["elapsed"] / steps * 1e3
             mlp_ms = m["pieces"]["mlp_kernel"]
             tf = FLOP_PER_SAMPLE[name] * batch / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
-            out[name] = {"metric": METRIC[name], "ms_per_step": ms, "value": batch * steps / m["elapsed"], "unit": "samples/s", "batch": batch, "steps": steps,
+            frac21 = None
+            if name == "c2":  # at 64k samples this launch is overhead-bound (2 trips per wave): say so by showing the kernel at 2^21 beside it
+                m21 = measure_training(tcnn, torch, name, 1 << 21, 16, 4)
+                frac21 = FLOP_PER_SAMPLE[name] * (1 << 21) / (m21["pieces"]["mlp_kernel"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if m21["pieces"]["mlp_kernel"] > 0 else None
+            out[name] = {"metric": METRIC[name], "ms_per_step": ms, "value": batch * steps / m["elapsed"], "unit": "samples/s", "batch": batch, "steps": steps, "mlp_frac_at_2p21": frac21,
                          "roofline": {"bound": "mfma", "kernel": MLP_KERNEL[name], "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "avg_launch_ms": mlp_ms,
                                       "traffic": pmc_traffic(MLP_KERNEL[name], name)[0], "traffic_source": pmc_traffic(MLP_KERNEL[name], name)[1]},
                          "pieces_ms": {k: m["pieces"][k] for k in ("encode", "mlp_kernel", "encoding_backward", "optimizer")}}
@@ -409,6 +425,8 @@ def main():
             m = c4_measure(n_sh, 5, world, setup)
             sharded = {"metric": "inference throughput (rows/s) FullyFusedMLP 128x4, batch=1M, rows sharded + all_gather of half outputs", "value": C4_ROWS * n_sh / m["elapsed"],
                        "unit": "rows/s", "ms_per_step": m["elapsed"] / n_sh * 1e3, "rows_per_gpu": m["rows_per_gpu"], "scaling": "strong",
+                       "kernel_ms": m["kernel_ms"], "gather_wait_ms": m["gather_wait_ms"], "bytes_in": m["bytes_in"],
+                       "note": "kernel_ms / gather_wait_ms: rank 0's last step -- device time of its inference calls, and of the wait for the gathers they did not hide",
                        "output_checksum": m["checksum"]}
         else:
             sharded = {"error": err or "another rank could not set the sharded inference up"}
@@ -421,6 +439,19 @@ def main():
         achieved = flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         kernel = MLP_KERNEL[args.workload]
         traffic, traffic_src = pmc_traffic(kernel, args.workload if not args.batch else "")
+        mfma_floor_ms = flops / (MFMA_PEAK_TFLOPS * 1e12) * 1e3
+        hbm_floor_ms = traffic / (HBM_PEAK_GBS * 1e9) * 1e3 if traffic else None
+        bound = "hbm" if (hbm_floor_ms or 0.0) > mfma_floor_ms else "mfma"
+        # the same kernel at batch 2^21: the ~6 us a launch costs whatever its size (fill, final reduction, write-back) are 1/8 of what they are at 2^18
+        frac_2p21 = None
+        if world == 1 and args.workload == "c3a" and not args.batch and not args.no_other_configs:
+            try:
+                m21 = measure_training(tcnn, torch, args.workload, 1 << 21, 16, 4)
+                ms21 = m21["pieces"]["mlp_kernel"]
+                frac_2p21 = FLOP_PER_SAMPLE[args.workload] * (1 << 21) / (ms21 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if ms21 > 0 else None
+            except Exception:
+                frac_2p21 = None
+            torch.cuda.empty_cache()
         adam_bytes = ADAM_BYTES_PER_PARAM * n_params
         adam_gbs = adam_bytes / (pieces["optimizer"] * 1e-3) / 1e9 if pieces["optimizer"] > 0 else 0.0
         # compulsory HBM bytes of a step: Adam's ADAM_BYTES_PER_PARAM per parameter, the half gradient table written and the half table read once
@@ -447,7 +478,11 @@ def main():
                        "parallelism": f"independent replicas x{world}, no gradient exchange (training does not shard in the reference)" if world > 1 else "single GPU",
                        "batches": f"{POOL} pre-generated batches visited in turn", "loss_first_last": [loss0, loss1],
                        "scatter_tasks_summed_in_64_bits": scatter_wide_tasks},
-            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+            # `frac` is the metric's own number (% of the fp16 MFMA peak).  What actually bounds the kernel is said beside it: its floor at the
+            # MFMA peak and its floor at the HBM peak for the bytes the counters saw -- at 124 FLOP per byte it sits under the HBM roof.
+            "roofline": {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "mfma_floor_ms": mfma_floor_ms, "hbm_floor_ms": hbm_floor_ms, "frac_of_bound": (max(mfma_floor_ms, hbm_floor_ms or 0.0) / mlp_ms) if mlp_ms > 0 else None,
+                         "frac_at_2p21": frac_2p21,
                          "traffic": traffic, "traffic_source": traffic_src, "flop_per_launch": flops, "avg_launch_ms": mlp_ms, "profiled_steps": n_profiled,
                          "share_of_step": mlp_ms / step_ms if step_ms > 0 else None,
                          "pieces": {"encode_ms": pieces["encode"], "mlp_kernel_ms": mlp_ms, "encoding_backward_ms": pieces["encoding_backward"],

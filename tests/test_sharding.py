@@ -64,7 +64,8 @@ def _worker(rank, world, port, n, results, chunks=1, half=False):
             y = _row_fn(rows)
             return y.half() if half else y  # Trainer.inference_half returns halves
 
-        out = par.sharded_inference(infer, x, 3, chunks=chunks)
+        timing = {}
+        out = par.sharded_inference(infer, x, 3, chunks=chunks, timing=timing)
         want = _row_fn(x)
         if half:
             want = want.half()
@@ -72,6 +73,8 @@ def _worker(rank, world, port, n, results, chunks=1, half=False):
         chunked = chunks > 1 and n % (chunks * world * 256) == 0
         want_calls = [n // chunks // world] * chunks if chunked else ([e - b] if e > b else [])
         ok = bool(torch.equal(out, want)) and out.dtype == want.dtype and calls == want_calls
+        if chunked:  # the decomposition a scaling run reports (bench.py c4_sharded_inference): bytes this rank receives; device events only with CUDA tensors
+            ok = ok and timing.get("bytes_in") == (world - 1) * n // world * 3 * out.element_size() and "kernel_events" not in timing
         results[rank] = ok
     finally:
         dist.destroy_process_group()

@@ -13,6 +13,16 @@ using namespace tcnn_amd;
 
 namespace {
 thread_local std::string g_last_error;
+tcnn_amd::Switches g_switches;
+
+bool env_is(const char* name, char c) {
+	const char* e = getenv(name);
+	return e && e[0] == c;
+}
+int env_01(const char* name) { // -1: unset or neither 0 nor 1
+	const char* e = getenv(name);
+	return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
+}
 
 template <typename F>
 int guarded(F&& f) {
@@ -55,6 +65,31 @@ struct tcnn_trainer_s {
 struct tcnn_train_ctx_s {
 	std::unique_ptr<TrainContext> ctx;
 };
+
+namespace tcnn_amd {
+const Switches& switches() { return g_switches; }
+void switches_reload() {
+	Switches w;
+	w.grid_planes = !env_is("TCNN_AMD_GRID_PLANES", '0');
+	{ const char* e = getenv("TCNN_AMD_GRID_SCATTER"); w.grid_scatter_lds = !(e && std::string{e} == "atomic"); }
+	w.scatter_records = !env_is("TCNN_AMD_SCATTER_RECORDS", '0');
+	w.scatter_tune = !env_is("TCNN_AMD_SCATTER_TUNE", '0');
+	w.scatter_lists = env_01("TCNN_AMD_SCATTER_LISTS");
+	w.scatter_wide = env_is("TCNN_AMD_SCATTER_WIDE", '1');
+	w.fused_step = !env_is("TCNN_AMD_FUSED_STEP", '0');
+	w.side_jobs = !env_is("TCNN_AMD_SIDE_JOBS", '0');
+	w.live_image = !env_is("TCNN_AMD_LIVE_IMAGE", '0');
+	w.adam_steps32 = env_is("TCNN_AMD_ADAM_STEPS32", '1');
+	w.adam_in_flush = env_is("TCNN_AMD_ADAM_IN_FLUSH", '1');
+	w.adam_in_reduce = !env_is("TCNN_AMD_ADAM_IN_REDUCE", '0');
+	w.mlp_r32 = !env_is("TCNN_AMD_MLP_R32", '0');
+	w.mlp_r32a = env_01("TCNN_AMD_MLP_R32A");
+	w.mlp_regs = !env_is("TCNN_AMD_MLP_REGS", '0');
+	w.mlp_fast = !env_is("TCNN_AMD_MLP_FAST", '0');
+	if (const char* e = getenv("TCNN_AMD_MLP_PRIO")) w.mlp_prio = (uint32_t)atoi(e);
+	g_switches = w;
+}
+} // namespace tcnn_amd
 
 extern "C" {
 
@@ -113,6 +148,7 @@ void tcnn_set_log_callback(void (*callback)(int, const char*, void*), void* user
 }
 
 int tcnn_create_network_with_input_encoding(uint32_t n_input_dims, uint32_t n_output_dims, const char* encoding_json, const char* network_json, tcnn_module_t* out) {
+	switches_reload(); // the A/B switches are read once per model (tcnn_common.h: Switches)
 	return guarded([&] {
 		CHECK_THROW(out != nullptr);
 		auto m = std::make_unique<tcnn_module_s>();
@@ -127,6 +163,7 @@ int tcnn_create_network(uint32_t n_input_dims, uint32_t n_output_dims, const cha
 }
 
 int tcnn_create_encoding(uint32_t n_input_dims, const char* encoding_json, int precision, tcnn_module_t* out) {
+	switches_reload(); // the A/B switches are read once per model (tcnn_common.h: Switches)
 	return guarded([&] {
 		CHECK_THROW(out != nullptr);
 		auto m = std::make_unique<tcnn_module_s>();
@@ -206,6 +243,7 @@ const char* tcnn_module_name(tcnn_module_t m) {
 
 // ---------------------------------------------------------------------------------------------------------- trainer
 int tcnn_create_from_config_seeded(uint32_t n_input_dims, uint32_t n_output_dims, const char* config_json, uint32_t seed, tcnn_trainer_t* out) {
+	switches_reload(); // the A/B switches are read once per model (tcnn_common.h: Switches)
 	return guarded([&] {
 		CHECK_THROW(out != nullptr);
 		auto t = std::make_unique<tcnn_trainer_s>();

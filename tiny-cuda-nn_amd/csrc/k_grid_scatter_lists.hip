@@ -33,7 +33,10 @@ namespace {
 constexpr uint32_t SL_ACC_BYTES = 64 * 1024;
 constexpr uint32_t SL_THREADS = 512;
 constexpr uint32_t SL_WAVES = SL_THREADS / 64;
-constexpr uint32_t SL_LDS_BYTES = SL_ACC_BYTES + 256; // + the waves' bound sums and the verdict
+constexpr uint32_t SL_WINDOW = 1536;                  // elements of a wave's 64 runs looked up through one fill of its owner table
+constexpr uint32_t SL_WAVE_LDS = SL_WINDOW + 256;     // per wave: owner table (one byte per element: the lane whose run holds it), the runs' positions
+constexpr uint32_t SL_LDS_BYTES = SL_ACC_BYTES + 256 + SL_WAVES * SL_WAVE_LDS; // accumulators, the waves' bound sums and the verdict, the waves' tables
+static_assert(2 * SL_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 #ifndef TCNN_SL_SB
 #define TCNN_SL_SB 2
 #endif
@@ -177,7 +180,7 @@ struct ScatterRuns {
 // [begin, end) of a level that is one chunk.
 template <int D, int F, bool REC, bool PACKED>
 __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, const uint32_t e0, const uint32_t n_sub, const bool listed, const ScatterRuns& runs, const bool with_stragglers,
-                                const uint32_t begin, const uint32_t end, const uint32_t wave, const uint32_t lane) {
+                                const uint32_t begin, const uint32_t end, const uint32_t wave, const uint32_t lane, char* wave_lds, const uint32_t first_h0, const uint32_t first_h1) {
 	typedef typename ScatterCtx<D, F, REC>::vecF vecF;
 	float bound = 0;
 	const bool nearest = c.interpolation == (uint32_t)InterpolationType::Nearest;
@@ -213,8 +216,10 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 		return bound;
 	}
 	// Listed.  A wave takes 64 items at a time, one per lane: the lane reads where its item's run of this chunk starts and ends, a scan
-	// over the lanes numbers the runs' elements 0 .. T - 1, and element e is found by a 6-step search over the lanes' running totals
-	// (ds_bpermute) -- ~16 elements per run, so a wave's loads of 64 consecutive e touch four or five runs.
+	// over the lanes numbers the runs' elements 0 .. T - 1, and every lane writes its own number into a wave-private byte table at its
+	// elements' positions (~16 each) -- element e is then TWO LDS reads away: table[e] names the lane, positions[lane] where its run
+	// lies.  (First form: a 6-step search over the lanes' running totals with ds_bpermute per element -- 7 cross-lane reads and ~20 vector
+	// instructions per 64 elements, and the kernel is bound by its vector instructions: 28 us per task against 21 with plain lists.)
 	//
 	// Then a software pipeline over batches of 64 SL_SB elements, NS = SL_LEAD + 2 register sets that rotate STATICALLY (the loop is
 	// unrolled NS times; a set is never copied -- a move of a register whose load is still in flight is a wait for it): per step the
@@ -233,8 +238,12 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 	const uint32_t n_groups = (end - begin + 63) / 64;
 	for (uint32_t g = wave; g < n_groups; g += SL_WAVES) { // wave-uniform
 		const uint32_t item0 = begin + g * 64, item = item0 + lane;
-		const uint32_t* hd = runs.heads + (size_t)min(item, end - 1) * GRID_HIT_HEADS;
-		const uint32_t h0 = hd[0], h1 = hd[1];
+		uint32_t h0 = first_h0, h1 = first_h1; // the wave's first group: requested when the task began, under the zeroing of the accumulators
+		if (g != wave) {
+			const uint32_t* hd = runs.heads + (size_t)min(item, end - 1) * GRID_HIT_HEADS;
+			h0 = hd[0];
+			h1 = hd[1];
+		}
 		const uint32_t cnt = item < end ? h1 - h0 : 0u;
 		uint32_t incl = cnt;
 #pragma unroll
@@ -243,7 +252,12 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 			if (lane >= (uint32_t)o) incl += up;
 		}
 		const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-		const uint32_t pos0 = (item * runs.item_capacity + h0) - (incl - cnt); // element e of this lane's run sits at pos0 + e
+		uint8_t* owner = (uint8_t*)wave_lds;                 // [SL_WINDOW]
+		uint32_t* run_pos = (uint32_t*)(wave_lds + SL_WINDOW); // [64]: element e of lane l's run sits at run_pos[l] + e in the level's pool
+		run_pos[lane] = (item * runs.item_capacity + h0) - (incl - cnt);
+		for (uint32_t w0 = 0; w0 < total; w0 += SL_WINDOW) { // (one window unless the runs are far longer than the ~16 elements of a uniform batch)
+		const uint32_t w1 = min(total, w0 + SL_WINDOW);
+		for (uint32_t j = max(incl - cnt, w0); j < min(incl, w1); ++j) owner[j - w0] = (uint8_t)lane;
 		uint32_t el[NS][SL_SB];
 		u32x4 rec[NS][SL_SB];    // REC: the record
 		float xs[NS][SL_SB][D];  // else: coordinates and gradient by loads of their own (an element without corners reads sample 0's)
@@ -252,14 +266,9 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 #pragma unroll
 			for (int s = 0; s < SL_SB; ++s) {
 				const uint32_t e = b0 + s * 64 + lane;
-				uint32_t it = 0; // the number of lanes whose running total is <= e: the lane of the run that holds element e
-#pragma unroll
-				for (uint32_t step = 32; step > 0; step >>= 1) {
-					const uint32_t v = __shfl(incl, (int)(it + step - 1));
-					it += v <= e ? step : 0u;
-				}
-				const uint32_t at = __shfl(pos0, (int)(it & 63u)) + e;
-				el[set][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_pool, e < total ? at * 4u : 0xfffffffcu, 0, 0);
+				const bool have = e < w1;
+				const uint32_t at = run_pos[owner[have ? e - w0 : 0u]] + e;
+				el[set][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_pool, have ? at * 4u : 0xfffffffcu, 0, 0);
 			}
 		};
 		auto gather = [&](const int set) {
@@ -293,29 +302,30 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 			}
 		};
 #pragma unroll
-		for (int b = 0; b <= SL_LEAD; ++b) load_elems(b, b * BATCH);
+		for (int b = 0; b <= SL_LEAD; ++b) load_elems(b, w0 + b * BATCH);
 #pragma unroll
 		for (int b = 0; b < SL_LEAD; ++b) gather(b);
-		const uint32_t quarter = max(total / 4u, 1u);
-		for (uint32_t b0 = 0; b0 < total; b0 += NS * BATCH) {
+		const uint32_t quarter = max((w1 - w0) / 4u, 1u);
+		for (uint32_t b0 = w0; b0 < w1; b0 += NS * BATCH) {
 			// The two workgroups of a CU share its address path, and the arbiter serves the older wave first: left alone the older workgroup
 			// runs as if it had the CU to itself (a task in 14 us) and the younger one takes the rest (30 us).  Priority by progress
 			// instead: whoever is further from the end of its run goes first.
 			{
-				const uint32_t done = b0 / quarter; // wave-uniform
+				const uint32_t done = (b0 - w0) / quarter; // wave-uniform
 				if (done == 0) __builtin_amdgcn_s_setprio(3);
 				else if (done == 1) __builtin_amdgcn_s_setprio(2);
 				else if (done == 2) __builtin_amdgcn_s_setprio(1);
 				else __builtin_amdgcn_s_setprio(0);
 			}
 #pragma unroll
-			for (int u = 0; u < NS; ++u) { // batch j = b0 / BATCH + u lives in set u (j is a multiple of NS at u = 0)
+			for (int u = 0; u < NS; ++u) { // batch j = (b0 - w0) / BATCH + u lives in set u (j is a multiple of NS at u = 0)
 				load_elems((u + SL_LEAD + 1) % NS, b0 + (u + SL_LEAD + 1) * BATCH);
 				gather((u + SL_LEAD) % NS);
 				accumulate(u);
 			}
 		}
 		__builtin_amdgcn_s_setprio(0);
+		} // window
 	}
 	// the level's stragglers (second corners of rows that straddle two chunks: one row in ~8000): every task of the level looks through all of them
 	if (with_stragglers) {
@@ -415,6 +425,12 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 		with_stragglers = s == 0;
 	}
 
+	uint32_t first_h0 = 0, first_h1 = 0; // where this lane's item (of the wave's first 64) keeps its run of the chunk
+	if (listed && begin < end) {
+		const uint32_t* hd = runs.heads + (size_t)min(begin + wave * 64 + lane, end - 1) * GRID_HIT_HEADS;
+		first_h0 = hd[0];
+		first_h1 = hd[1];
+	}
 	typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 	auto zero_acc = [&](const uint32_t bytes) {
 		u4* a4 = (u4*)smem;
@@ -442,7 +458,7 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 		}
 		__syncthreads();
 		if (dbg_times && tid == 0) dbg_times[1] = __builtin_amdgcn_s_memrealtime();
-		float bound = sl_pass<D, F, REC, true>(c, acc, task.entry_begin, task.n_entries, listed, runs, with_stragglers, begin, end, wave, lane);
+		float bound = sl_pass<D, F, REC, true>(c, acc, task.entry_begin, task.n_entries, listed, runs, with_stragglers, begin, end, wave, lane, smem + SL_ACC_BYTES + 256 + wave * SL_WAVE_LDS, first_h0, first_h1);
 		// workgroup verdict: (sum over everything added) + (largest initial value) bounds every entry's sum
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
@@ -475,10 +491,17 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 				if (v1 != 0) atomicAdd(sc + 2 * i + 1, (unsigned long long)v1);
 			}
 		} else {
+			// both sums fit 32 bits (that is what the bound proved): below 2^24 in magnitude (|value| < 1, nearly always) the integer is
+			// exact as a float, the scaling is exact, and the hardware's float -> half conversion is the ONE rounding (RNE); else the general path
 			typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+			auto round32 = [](const int v) -> half_t {
+				if (__builtin_expect((uint32_t)(v + (1 << 24)) < (1u << 25), 1)) return (half_t)((float)v * 5.9604644775390625e-08f);
+				return fixed_to_half((long long)v);
+			};
 			for (uint32_t i = tid; i < n_vals / 2; i += SL_THREADS) {
 				const unsigned long long s = a[i];
-				((h2*)g)[i] = h2{fixed_to_half_fast(lo_of(s)), fixed_to_half_fast(hi_of(s))};
+				const int lo = (int)(uint32_t)s, hi = (int)(uint32_t)((s - (unsigned long long)(long long)lo) >> 32);
+				((h2*)g)[i] = h2{round32(lo), round32(hi)};
 			}
 		}
 	} else {
@@ -499,7 +522,7 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 				zero_acc(sub_vals * 8);
 			}
 			__syncthreads();
-			(void)sl_pass<D, F, REC, false>(c, acc, task.entry_begin + sub_lo, n_sub, listed, runs, with_stragglers, begin, end, wave, lane);
+			(void)sl_pass<D, F, REC, false>(c, acc, task.entry_begin + sub_lo, n_sub, listed, runs, with_stragglers, begin, end, wave, lane, smem + SL_ACC_BYTES + 256 + wave * SL_WAVE_LDS, first_h0, first_h1);
 			__syncthreads();
 			if (task.flush_atomic) {
 				unsigned long long* sc = scratch + (size_t)task.scratch_begin + (size_t)sub_lo * F;
@@ -686,7 +709,6 @@ void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMet
 	CHECK_THROW(n <= grid_hit_max_samples(meta) && meta.hash_type != (uint32_t)HashType::Rng);
 	// every chunk must fit the 64 KiB of packed accumulators (the plan's chunks are cut for 128 KiB of 64-bit ones: the same entry count)
 	for (uint32_t l = 0; l < meta.n_levels; ++l) CHECK_THROW(meta.levels[l].scatter_binned || meta.levels[l].scatter_per_chunk * meta.n_features_per_level * 4 <= SL_ACC_BYTES);
-	const char* wide_env = getenv("TCNN_AMD_SCATTER_WIDE"); // tests: every task through the 64-bit passes (read per call so that one process can cover both)
 	ScatterListsArgs a{};
 	a.meta = dev_meta;
 	a.tasks = dev_tasks;
@@ -699,7 +721,7 @@ void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMet
 	a.lists = lists;
 	a.scratch = (unsigned long long*)scratch;
 	a.accumulate_mode = accumulate ? 1 : 0;
-	a.force_wide = (wide_env && wide_env[0] == '1') ? 1 : 0;
+	a.force_wide = switches().scatter_wide ? 1 : 0; // tests: every task through the 64-bit passes
 	a.dbg_times = nullptr;
 	a.fallback_count = fallback_count;
 	switch (meta.n_pos_dims) {

@@ -851,9 +851,13 @@ void mlp_train_fused(hipStream_t stream, const MlpDesc& d, const void* image, ui
 		a.ob_dims = oneblob->n_dims;
 		while ((1u << a.ob_log2) < oneblob->n_bins) ++a.ob_log2;
 	}
+#ifdef TCNN_AMD_DEV // laboratory build (build.py --dev): in-kernel clocks of the 5th launch
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
 	static int timing_left = 5;
 	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&a.dbg, 64));
+#else
+	int timing_left = 0; (void)timing_left;
+#endif
 	dispatch_train(stream, d, a, cfg, mlp_train_fused_grid(d, n));
 	if (a.dbg) {
 		unsigned long long h[8];

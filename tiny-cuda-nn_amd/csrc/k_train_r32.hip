@@ -481,11 +481,8 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 
 } // namespace
 
-// TCNN_AMD_MLP_R32=0 keeps k_train_regs.hip's kernel (A/B runs; read per call so that tests can cover both forms in one process)
-static bool r32_enabled() {
-	const char* e = getenv("TCNN_AMD_MLP_R32");
-	return !(e && e[0] == '0');
-}
+// TCNN_AMD_MLP_R32=0 keeps k_train_regs.hip's kernel (A/B runs; Switches, read once per model)
+static bool r32_enabled() { return switches().mlp_r32; }
 
 // the one shape this kernel is instantiated for, with the formats of the grid encoding's training step: input as level planes of 2
 // features, <= 4 outputs, ReLU, L2 / RelativeL2, `out` and 2-D scatter records written, no data_pdf
@@ -503,14 +500,18 @@ bool mlp_train_r32_applies(const MlpDesc& d, uint32_t n, uint32_t x_plane_featur
 // 131 072 samples (MLP kernel at 2^14 / 2^16 / 2^17 samples: 7.9 / 12.0 / 16.0 us against 10.1 / 12.6 / 16.7); at 2^18 the two are equal
 // (24.7 us) and k_mlp_train_r32 stays.  TCNN_AMD_MLP_R32A=1 / 0 forces one (A/B runs, tests).
 static bool r32a_chosen(uint32_t n) {
-	const char* e = getenv("TCNN_AMD_MLP_R32A");
-	if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+	const int forced = switches().mlp_r32a;
+	if (forced >= 0) return forced == 1;
 	return n <= 131072u;
 }
 // workgroups = weight-gradient slabs of the kernel mlp_train_r32 launches for this batch
 uint32_t mlp_train_r32_grid(uint32_t n) {
 	if (r32a_chosen(n)) {
-		static const uint32_t cap = getenv("TCNN_AMD_MLP_GRID") ? (uint32_t)std::max(1, atoi(getenv("TCNN_AMD_MLP_GRID"))) : 512u; // development knob
+		uint32_t cap = 512u;
+#ifdef TCNN_AMD_DEV
+		static const uint32_t dev_cap = getenv("TCNN_AMD_MLP_GRID") ? (uint32_t)std::max(1, atoi(getenv("TCNN_AMD_MLP_GRID"))) : 512u; // laboratory knob
+		cap = dev_cap;
+#endif
 		return std::max(1u, std::min(cap, div_round_up(n / 32, (uint32_t)R32A_NW))); // two workgroups of four waves per CU
 	}
 	return std::max(1u, std::min(256u, div_round_up(n / 32, (uint32_t)R32_NW)));
@@ -534,22 +535,28 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 	a.n_params = n_params;
 	for (int l = 0; l < 3; ++l) a.w_off[l] = d.layers[l].w_off;
 	a.loss_scale = loss_scale;
+	auto go = [&](auto kernel) {
+		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R32_LDS_BYTES));
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(R32_NW * 64), R32_LDS_BYTES, stream, a);
+		HIP_CHECK_THROW(hipGetLastError());
+	};
+	a.prio_mode = switches().mlp_prio;
+	CHECK_THROW(grid == mlp_train_r32_grid(n));
+#ifndef TCNN_AMD_DEV
+	if (r32a_chosen(n)) return mlp_train_r32a_launch(stream, a, grid, loss == LossType::L2 ? 1 : 2);
+	if (loss == LossType::L2) go(k_mlp_train_r32<1>);
+	else go(k_mlp_train_r32<2>);
+#else
+	// ---- laboratory build (build.py --dev): in-kernel clocks (TCNN_AMD_MLP_TIMING), timing-only kernel variants (TCNN_AMD_MLP_DIAG), start
+	// delays (TCNN_AMD_MLP_STAGGER), workgroup placement (TCNN_AMD_MLP_WHERE).  None of this is in the product library.
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
 	static int timing_left = 5;
 	if (timing && timing_left > 0) {
 		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * 1024));
 		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * 1024));
 	}
-	auto go = [&](auto kernel) {
-		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R32_LDS_BYTES));
-		hipLaunchKernelGGL(kernel, dim3(grid), dim3(R32_NW * 64), R32_LDS_BYTES, stream, a);
-		HIP_CHECK_THROW(hipGetLastError());
-	};
-	a.prio_mode = 1;
-	if (const char* e = getenv("TCNN_AMD_MLP_PRIO")) a.prio_mode = (uint32_t)atoi(e);
 	if (const char* e = getenv("TCNN_AMD_MLP_STAGGER")) a.stagger = (uint32_t)atoi(e);
 	static const int diag = getenv("TCNN_AMD_MLP_DIAG") ? atoi(getenv("TCNN_AMD_MLP_DIAG")) : 0;
-	CHECK_THROW(grid == mlp_train_r32_grid(n));
 	if (r32a_chosen(n)) {
 		mlp_train_r32a_launch(stream, a, grid, loss == LossType::L2 ? 1 : 2);
 		if (a.dbg) {
@@ -653,6 +660,7 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 		}
 		(void)hipFree(a.dbg);
 	}
+#endif
 }
 
 } // namespace tcnn_amd

@@ -795,10 +795,7 @@ __global__ void __launch_bounds__(OB_NW * 64, 1) k_mlp_train_r32ob_acc(const ObA
 } // namespace
 
 // TCNN_AMD_MLP_R32=0 keeps k_train.hip's kernel
-static bool r32ob_enabled() {
-	const char* e = getenv("TCNN_AMD_MLP_R32");
-	return !(e && e[0] == '0');
-}
+static bool r32ob_enabled() { return switches().mlp_r32; }
 
 bool mlp_train_r32ob_shape(const MlpDesc& d, uint32_t n, uint32_t n_bins, uint32_t n_dims) {
 	if (!r32ob_enabled() || d.width != 64 || d.in_width != 128 || d.out_width != 16 || d.n_hidden != 2 || d.n_frags_r32 == 0) return false;
@@ -830,12 +827,16 @@ void mlp_train_r32ob(hipStream_t stream, const MlpDesc& d, const void* image, ui
 	for (int l = 0; l < 3; ++l) a.w_off[l] = d.layers[l].w_off;
 	a.loss_scale = loss_scale;
 	const uint32_t grid = mlp_train_r32ob_grid(n);
+#ifdef TCNN_AMD_DEV // laboratory build (build.py --dev): in-kernel clocks of the 5th launch
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
 	static int timing_left = 5;
 	if (timing && timing_left > 0) {
 		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * 48));
 		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * 48));
 	}
+#else
+	int timing_left = 0; (void)timing_left;
+#endif
 	auto go = [&](auto kernel, int lds_bytes) {
 		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(OB_NW * 64), lds_bytes, stream, a);
@@ -846,7 +847,9 @@ void mlp_train_r32ob(hipStream_t stream, const MlpDesc& d, const void* image, ui
 	// (the reference's benchmark protocol at 2^21 samples: 6.8e9 against 5.95e9 samples/s).  TCNN_AMD_MLP_R32OB_FORM=shared|acc forces one.
 	const uint32_t trips = div_round_up(n / 32, grid * OB_NW);
 	bool shared = trips <= 4;
+#ifdef TCNN_AMD_DEV
 	if (const char* e = getenv("TCNN_AMD_MLP_R32OB_FORM")) shared = e[0] == 's';
+#endif
 	if (shared) {
 		if (loss == LossType::L2) go(k_mlp_train_r32ob<1>, OB_LDS_BYTES);
 		else go(k_mlp_train_r32ob<2>, OB_LDS_BYTES);

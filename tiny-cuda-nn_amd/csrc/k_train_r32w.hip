@@ -376,10 +376,7 @@ __global__ void __launch_bounds__(W_NW * 64, 1) k_mlp_train_r32w(const WArgs a) 
 
 } // namespace
 
-static bool r32w_enabled() {
-	const char* e = getenv("TCNN_AMD_MLP_R32");
-	return !(e && e[0] == '0');
-}
+static bool r32w_enabled() { return switches().mlp_r32; }
 
 bool mlp_train_r32w_shape(const MlpDesc& d, uint32_t n) {
 	if (!r32w_enabled() || d.width != 128 || d.in_width != 64 || d.out_width != 16 || d.n_hidden != 2 || d.n_frags_r32 != (uint32_t)W_NFRAGS) return false;
@@ -410,12 +407,16 @@ void mlp_train_r32w(hipStream_t stream, const MlpDesc& d, const void* image, uin
 	a.n_params = n_params;
 	for (int l = 0; l < 3; ++l) a.w_off[l] = d.layers[l].w_off;
 	a.loss_scale = loss_scale;
+#ifdef TCNN_AMD_DEV // laboratory build (build.py --dev): in-kernel clocks of the 5th launch
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
 	static int timing_left = 5;
 	if (timing && timing_left > 0) {
 		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * 32));
 		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * 32));
 	}
+#else
+	int timing_left = 0; (void)timing_left;
+#endif
 	auto go = [&](auto kernel) {
 		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES));
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(W_NW * 64), W_LDS_BYTES, stream, a);

@@ -583,12 +583,13 @@ template <int IN_T, int NH> void launch_regs(hipStream_t stream, const MlpDesc& 
 	const bool relu = d.activation == (uint32_t)Activation::ReLU;
 	constexpr int RELU = (int)Activation::ReLU, NONE = (int)Activation::None;
 	// the compile-time formats of k_mlp_train_regs<FAST> (TCNN_AMD_MLP_FAST=0: the general form, for A/B runs and tests)
-	const char* fast_env = getenv("TCNN_AMD_MLP_FAST");
-	const bool fast = !(fast_env && fast_env[0] == '0') && loss != 0 && relu && a.x_plane_f == 2 && a.dims <= 4 && a.data_pdf == nullptr && a.out != nullptr && a.dL_dx != nullptr &&
+	const bool fast = switches().mlp_fast && loss != 0 && relu && a.x_plane_f == 2 && a.dims <= 4 && a.data_pdf == nullptr && a.out != nullptr && a.dL_dx != nullptr &&
 	                  a.rec_x != nullptr && a.rec_dims == 2 && a.dx_plane_f == 2;
 	if constexpr (IN_T == 2 && NH == 2) {
+#ifdef TCNN_AMD_DEV
 		static const bool phases = getenv("TCNN_AMD_MLP_TIMING") && getenv("TCNN_AMD_MLP_TIMING")[0] == '2';
 		if (phases && a.dbg && fast && loss == 2) return go(k_mlp_train_regs<IN_T, NH, RELU, 2, true, true>);
+#endif
 	}
 	if (fast) return loss == 1 ? go(k_mlp_train_regs<IN_T, NH, RELU, 1, true>) : go(k_mlp_train_regs<IN_T, NH, RELU, 2, true>);
 #define TCNN_REGS_CASE(L_) \
@@ -611,11 +612,8 @@ __global__ void __launch_bounds__(256) k_expand_context(const uint32_t n, const 
 
 } // namespace
 
-// TCNN_AMD_MLP_REGS=0 keeps k_train.hip's kernels (A/B runs; read per call so that tests can cover both forms in one process)
-static bool regs_enabled() {
-	const char* e = getenv("TCNN_AMD_MLP_REGS");
-	return !(e && e[0] == '0');
-}
+// TCNN_AMD_MLP_REGS=0 keeps k_train.hip's kernels (A/B runs; Switches, read once per model)
+static bool regs_enabled() { return switches().mlp_regs; }
 
 bool mlp_train_regs_supported(const MlpDesc& d, uint32_t n) {
 	if (!regs_enabled() || n == 0 || n % 16 != 0 || n > (1u << 22)) return false; // 32-bit byte offsets into [n][...] matrices
@@ -625,7 +623,9 @@ bool mlp_train_regs_supported(const MlpDesc& d, uint32_t n) {
 uint32_t mlp_train_regs_grid(const MlpDesc& d, uint32_t n) {
 	(void)d;
 	uint32_t cap = 256;
-	if (const char* e = getenv("TCNN_AMD_MLP_GRID")) cap = std::max(1, atoi(e)); // development knob (how the trip time depends on the number of busy CUs: it does not)
+#ifdef TCNN_AMD_DEV
+	if (const char* e = getenv("TCNN_AMD_MLP_GRID")) cap = std::max(1, atoi(e)); // laboratory knob (how the trip time depends on the number of busy CUs: it does not)
+#endif
 	return std::max(1u, std::min(cap, div_round_up(n / 16, (uint32_t)REGS_NW)));
 }
 
@@ -642,15 +642,19 @@ void mlp_train_regs(hipStream_t stream, const MlpDesc& d, const void* image, uin
 	}
 	RegsArgs a{(const half_t*)x, target, data_pdf, (const half_t*)external_dL_dy, (half_t*)out, (half_t*)compact_dL_dout, compact_L, (half_t*)dL_dx, slabs, (const h8*)image,
 	           dx_record_x, n, dims, dx_record_dims, x_plane_features, dx_plane_features, n_params, loss_scale, 1u, nullptr};
-	if (const char* e = getenv("TCNN_AMD_MLP_PRIO")) a.prio_mode = (uint32_t)atoi(e);
+	a.prio_mode = switches().mlp_prio;
 	const int loss_id = external_dL_dy ? 0 : (loss == LossType::L2 ? 1 : 2);
 	const uint32_t grid = mlp_train_regs_grid(d, n);
+#ifdef TCNN_AMD_DEV // laboratory build (build.py --dev): in-kernel clocks of the 5th launch
 	static const bool timing = getenv("TCNN_AMD_MLP_TIMING") != nullptr;
 	static int timing_left = 5;
 	if (timing && timing_left > 0) {
 		HIP_CHECK_THROW(hipMalloc(&a.dbg, (size_t)grid * (32 + 8 * REGS_NW + 64)));
 		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * (32 + 8 * REGS_NW + 64)));
 	}
+#else
+	int timing_left = 0; (void)timing_left;
+#endif
 	if (regs_layout_matches<2, 2>(d)) launch_regs<2, 2>(stream, d, a, grid, loss_id);
 	else if (regs_layout_matches<1, 2>(d)) launch_regs<1, 2>(stream, d, a, grid, loss_id);
 	else if (regs_layout_matches<2, 1>(d)) launch_regs<2, 1>(stream, d, a, grid, loss_id);

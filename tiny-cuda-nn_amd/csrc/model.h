@@ -431,13 +431,7 @@ public:
 	}
 
 	// TCNN_AMD_GRID_PLANES=0 keeps the AoS forward kernel inside the fused training step (A/B runs)
-	static bool use_planes() {
-		static const bool v = [] {
-			const char* e = getenv("TCNN_AMD_GRID_PLANES");
-			return !(e && std::string{e} == "0");
-		}();
-		return v;
-	}
+	static bool use_planes() { return switches().grid_planes; }
 	uint32_t forward_plane_features(uint32_t n) override {
 		return (!m_fp32 && use_planes() && m_n_to_pad == 0 && grid_planes_supported(m_meta, n)) ? m_meta.n_features_per_level : 0;
 	}
@@ -607,9 +601,7 @@ public:
 	// The MLP kernel writes {coordinates, gradient} records and the scatter does one gather per hit instead of two: measured on
 	// C3a the scatter gains 12 us and the MLP kernel loses 6 us (4x the dX bytes).  TCNN_AMD_SCATTER_RECORDS=0 turns it off.
 	bool scatter_records_usable(MatView x) const override {
-		const char* e = getenv("TCNN_AMD_SCATTER_RECORDS"); // read per step so that tests can cover both forms in one process
-		const bool enabled = !(e && e[0] == '0');
-		return enabled && lds_scatter_usable() && !m_any_binned && grid_scatter_records_supported(m_meta) && x.stride_dim == 1 && x.stride_sample == m_meta.n_pos_dims;
+		return switches().scatter_records && lds_scatter_usable() && !m_any_binned && grid_scatter_records_supported(m_meta) && x.stride_dim == 1 && x.stride_sample == m_meta.n_pos_dims;
 	}
 
 	uint32_t scatter_record_planes() const override { return grid_scatter_record_planes(m_meta); }
@@ -618,13 +610,7 @@ public:
 	bool lds_scatter_usable() const { return !m_fp32 && m_meta.n_features_per_level >= 2 && use_lds_scatter() && m_scatter_levels_ok; }
 
 	// TCNN_AMD_GRID_SCATTER=atomic selects the reference-shaped global-atomic kernel (kept for A/B runs and as the fp32 / F==1 path)
-	static bool use_lds_scatter() {
-		static const bool v = [] {
-			const char* e = getenv("TCNN_AMD_GRID_SCATTER");
-			return !(e && std::string{e} == "atomic");
-		}();
-		return v;
-	}
+	static bool use_lds_scatter() { return switches().grid_scatter_lds; }
 
 	struct ScatterPlan {
 		DeviceBuf dev_tasks, dev_ranges, scratch;
@@ -635,10 +621,7 @@ public:
 		ParamRanges adam_ranges; // what a launch of this plan in record form updates itself when it is handed an AdamInFlush
 	};
 	// TCNN_AMD_SCATTER_TUNE=0 keeps the untuned task list (A/B runs)
-	static bool scatter_tuning_enabled() { // read per call so that tests can cover both forms in one process
-		const char* e = getenv("TCNN_AMD_SCATTER_TUNE");
-		return !(e && e[0] == '0');
-	}
+	static bool scatter_tuning_enabled() { return switches().scatter_tune; }
 	// (re)builds the device-side plan; the caller guarantees that no launch using the old one is still running
 	void build_scatter_plan(ScatterPlan& plan, uint32_t n, const std::vector<float>* measured_level_us) {
 		std::vector<GridScatterRange> ranges;
@@ -698,11 +681,10 @@ public:
 
 	// Hit lists: TCNN_AMD_SCATTER_LISTS=0 keeps the bit planes (A/B runs, tests; read per step so that one process can cover both)
 	bool hit_lists_usable(uint32_t n) const {
-		const char* e = getenv("TCNN_AMD_SCATTER_LISTS"); // 0: never; 1: wherever the kernel can take the grid (tests); unset: where it pays (grid_scatter_prefers_lists)
-		if (e && e[0] == '0') return false;
-		if (const char* a = getenv("TCNN_AMD_ADAM_IN_FLUSH")) { if (a[0] == '1') return false; } // the optimizer step inside the flush is k_grid_scatter's
+		const int want = switches().scatter_lists; // 0: never; 1: wherever the kernel can take the grid (tests); -1: where it pays (grid_scatter_prefers_lists)
+		if (want == 0 || switches().adam_in_flush) return false; // (the optimizer step inside the flush is k_grid_scatter's)
 		if (m_any_binned || n > grid_hit_max_samples(m_meta) || m_meta.n_pos_dims > 3 || m_meta.hash_type == (uint32_t)HashType::Rng) return false; // (Rng: its hash is a loop)
-		return (e && e[0] == '1') || grid_scatter_prefers_lists(m_meta);
+		return want == 1 || grid_scatter_prefers_lists(m_meta);
 	}
 	static size_t next_multiple_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 	struct HitCounters {
@@ -1711,27 +1693,15 @@ public:
 	}
 
 	// TCNN_AMD_FUSED_STEP=0 selects the reference-shaped kernel sequence (forward / loss / backward / wgrad) for A/B runs
-	static bool use_fused_step() {
-		static const bool v = [] {
-			const char* e = getenv("TCNN_AMD_FUSED_STEP");
-			return !(e && std::string{e} == "0");
-		}();
-		return v;
-	}
+	static bool use_fused_step() { return switches().fused_step; }
 	// TCNN_AMD_SIDE_JOBS=0: k_mlp_prep stays a launch of its own (A/B runs; read per step so that tests cover both)
-	static bool side_jobs_enabled() {
-		const char* e = getenv("TCNN_AMD_SIDE_JOBS");
-		return !(e && e[0] == '0');
-	}
+	static bool side_jobs_enabled() { return switches().side_jobs; }
 	bool fused_step_supported(uint32_t n) const { return use_fused_step() && mlp_train_fused_supported(m_network->desc(), n); }
 	// the fused step of a model without encoding parameters hands its weight gradients to the optimizer inside the slab reduction
 	bool optimizer_rides_on_reduce() const { return m_encoding->n_params() == 0; }
 	// TCNN_AMD_LIVE_IMAGE=0: every step builds its fragment images with k_mlp_prep again instead of keeping one current (Network::live_image;
 	// bit-identical, one ~4.5 us launch more per step of a model without encoding parameters)
-	static bool live_image_enabled() {
-		const char* e = getenv("TCNN_AMD_LIVE_IMAGE");
-		return !(e && e[0] == '0');
-	}
+	static bool live_image_enabled() { return switches().live_image; }
 	bool live_image_kept() const { return m_live_image_kept; }           // the last fused step's optimizer launch left the live image current
 	void invalidate_live_image() { m_network->invalidate_live_image(); } // the parameters change(d) some other way
 	size_t image_preps() const { return m_image_preps; }                 // k_mlp_prep launches of fused steps so far (a test's view of the above)
@@ -2118,10 +2088,7 @@ public:
 	// by the HBM-bound kernel -- and widened in place of one step's time before one could overflow; snapshots carry uint32 either
 	// way.  TCNN_AMD_ADAM_STEPS32=1: uint32 from the start (A/B runs, tests).
 	static constexpr uint32_t NARROW_STEP_LIMIT = 65535;
-	static bool narrow_steps_enabled() {
-		const char* e = getenv("TCNN_AMD_ADAM_STEPS32");
-		return !(e && e[0] == '1');
-	}
+	static bool narrow_steps_enabled() { return !switches().adam_steps32; }
 	size_t step_bytes() const { return m_steps16 ? sizeof(uint16_t) : sizeof(uint32_t); }
 	void ensure_step_width(hipStream_t stream) { // call with m_current_step = the step about to be applied
 		if (!m_steps16 || m_current_step < NARROW_STEP_LIMIT) return;
@@ -2910,16 +2877,10 @@ public:
 	size_t params_updated_in_flush() const { return m_params_updated_in_flush; }
 	// TCNN_AMD_ADAM_IN_FLUSH=1: the optimizer's update is applied by the gradient kernels where they can carry it.  Off by default:
 	// bit-identical and measured equal in time on C3a (0.229 / 0.230 vs 0.230 / 0.225 ms per step; DESIGN.md "Adam in the scatter").
-	static bool adam_in_flush_enabled() { // read per step so that tests can cover both forms in one process
-		const char* e = getenv("TCNN_AMD_ADAM_IN_FLUSH");
-		return e && e[0] == '1';
-	}
+	static bool adam_in_flush_enabled() { return switches().adam_in_flush; }
 	// TCNN_AMD_ADAM_IN_REDUCE=0: models without encoding parameters (BASELINE config 2) run the optimizer as a launch of its own again
 	// instead of behind the weight gradients' slab reduction (k_wgrad_reduce_adam; bit-identical, one ~4 us launch less per step)
-	static bool adam_in_reduce_enabled() {
-		const char* e = getenv("TCNN_AMD_ADAM_IN_REDUCE");
-		return !(e && e[0] == '0');
-	}
+	static bool adam_in_reduce_enabled() { return switches().adam_in_reduce; }
 
 	void optimizer_step(hipStream_t stream, float loss_scale) { // trainer.h:155-157
 		m_model->invalidate_live_image();

@@ -35,6 +35,31 @@ constexpr uint32_t MAX_MLP_LAYERS = 16;
 	do { hipError_t _e = (x); if (_e != hipSuccess) throw std::runtime_error{std::string{__FILE__ ":" TCNN_STR(__LINE__) " " #x " failed: "} + hipGetErrorString(_e)}; } while (0)
 
 inline uint32_t div_round_up(uint32_t v, uint32_t d) { return (v + d - 1) / d; }
+
+// The A/B switches of the training step and of inference (DESIGN.md "Switches"): every one defaults to the fast path, none changes a result
+// beyond what is stated there.  They are read from the environment ONCE PER MODEL -- when create_from_config / a module constructor runs
+// (switches_reload, capi.cpp) -- not per step: a process that wants another setting sets the variable and creates a new model.
+struct Switches {
+	bool grid_planes = true;      // TCNN_AMD_GRID_PLANES=0: the AoS forward kernel inside the fused training step
+	bool grid_scatter_lds = true; // TCNN_AMD_GRID_SCATTER=atomic: the reference-shaped global-atomic gradient kernel
+	bool scatter_records = true;  // TCNN_AMD_SCATTER_RECORDS=0: gradient planes instead of {coordinates, gradient} records
+	bool scatter_tune = true;     // TCNN_AMD_SCATTER_TUNE=0: the untuned task list of k_grid_scatter
+	int scatter_lists = -1;       // TCNN_AMD_SCATTER_LISTS=0 / 1: never / wherever possible (unset: where it pays, grid_scatter_prefers_lists)
+	bool scatter_wide = false;    // TCNN_AMD_SCATTER_WIDE=1: every task of k_grid_scatter_lists through its 64-bit passes (tests)
+	bool fused_step = true;       // TCNN_AMD_FUSED_STEP=0: forward / loss / backward / wgrad kernels instead of the fused step
+	bool side_jobs = true;        // TCNN_AMD_SIDE_JOBS=0: k_mlp_prep and the slab reduction as launches of their own
+	bool live_image = true;       // TCNN_AMD_LIVE_IMAGE=0: k_mlp_prep every step
+	bool adam_steps32 = false;    // TCNN_AMD_ADAM_STEPS32=1: uint32 update counts from the start
+	bool adam_in_flush = false;   // TCNN_AMD_ADAM_IN_FLUSH=1: Adam applied by the scatter's chunk owners
+	bool adam_in_reduce = true;   // TCNN_AMD_ADAM_IN_REDUCE=0: k_adam as a launch of its own for models without encoding parameters
+	bool mlp_r32 = true;          // TCNN_AMD_MLP_R32=0: k_mlp_train_regs / k_mlp_train instead of the 32x32x16 kernels
+	int mlp_r32a = -1;            // TCNN_AMD_MLP_R32A=0 / 1: k_mlp_train_r32 / k_mlp_train_r32a whatever the batch size
+	bool mlp_regs = true;         // TCNN_AMD_MLP_REGS=0: the LDS-image kernels of k_train.hip
+	bool mlp_fast = true;         // TCNN_AMD_MLP_FAST=0: k_mlp_train_regs with run-time formats
+	uint32_t mlp_prio = 1;        // TCNN_AMD_MLP_PRIO: wave priorities of the MLP kernels (0 none, 1 alternating per trip, 2, 3)
+};
+const Switches& switches();
+void switches_reload();
 inline uint32_t next_multiple(uint32_t v, uint32_t d) { return div_round_up(v, d) * d; }
 
 // ------------------------------------------------------------------------------------------------------------------

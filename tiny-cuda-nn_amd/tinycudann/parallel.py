@@ -36,7 +36,7 @@ def _agreed_dtype(local_dtype, group, device):
     return _DTYPE_CODES[int(code.item()) - 1]
 
 
-def sharded_inference(infer_fn, x, n_out, group=None, out_dtype=None, chunks=1):
+def sharded_inference(infer_fn, x, n_out, group=None, out_dtype=None, chunks=1, timing=None):
     """Every rank holds the full input `x` [n, n_in] (or at least its own rows); rank r evaluates rows shard_rows(...) with
     `infer_fn(x_rows) -> [rows, n_out]` and all ranks end up with the full [n, n_out] output, in the dtype infer_fn returns
     (half for Trainer.inference_half: SURVEY 8e's 4 MB per GPU for BASELINE config 4) unless out_dtype says otherwise.
@@ -48,7 +48,12 @@ def sharded_inference(infer_fn, x, n_out, group=None, out_dtype=None, chunks=1):
 
     chunks > 1 (and n a multiple of chunks x world_size x 256): the batch is cut into `chunks` consecutive row ranges, each of them
     sharded over the ranks; the gather of range i runs (asynchronously, on the collective's stream) while the ranks evaluate range
-    i + 1 -- at 8 GPUs config 4's exchange (7 x 4 MB inbound per GPU) is longer than its kernel, so only overlap hides either."""
+    i + 1 -- at 8 GPUs config 4's exchange (7 x 4 MB inbound per GPU) is longer than its kernel, so only overlap hides either.
+
+    timing (optional, CUDA tensors only): a dict that receives, for this call on this rank, device events bracketing the kernels
+    (`kernel_events`: one (start, end) pair per infer_fn call, recorded on the current stream) and the wait for the gathers
+    (`gather_wait_events`: around the w.wait() loop, i.e. what of the exchange the kernels did NOT hide) plus `bytes_in`, the bytes
+    this rank receives -- so that a scaling run can tell kernel time from exchange time.  Read them after a synchronisation."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = x.shape[0]
@@ -56,16 +61,33 @@ def sharded_inference(infer_fn, x, n_out, group=None, out_dtype=None, chunks=1):
         rows = n // chunks       # rows of a range
         mine = rows // world     # ... of which this rank evaluates `mine`
         out, works = None, []
+        timed = timing is not None and x.is_cuda
+        if timed:
+            timing["kernel_events"], timing["gather_wait_events"] = [], None
         for i in range(chunks):
             b = i * rows + rank * mine
+            if timed:
+                k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                k0.record()
             local = infer_fn(x[b : b + mine])
+            if timed:
+                k1.record()
+                timing["kernel_events"].append((k0, k1))
             if out_dtype is not None:
                 local = local.to(out_dtype)
             if out is None:
                 out = torch.empty((n, n_out), dtype=local.dtype, device=x.device)
             works.append((dist.all_gather_into_tensor(out[i * rows : (i + 1) * rows], local.contiguous(), group=group, async_op=True), local))
+        if timed:
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
         for w, _keep in works:  # `local` stays referenced until its gather has completed
             w.wait()
+        if timed:
+            g1.record()
+            timing["gather_wait_events"] = (g0, g1)
+        if timing is not None:
+            timing["bytes_in"] = (world - 1) * chunks * mine * n_out * out.element_size()
         return out
     begin, end = shard_rows(n, world, rank)
     shards = [shard_rows(n, world, r) for r in range(world)]
