@@ -361,7 +361,11 @@ uint32_t grid_hit_item_samples(const GridMeta& meta) { return FP_THREADS * grid_
 uint32_t grid_planes_spt(const GridMeta& meta) {
 	// 4 samples per thread (16 gathers in flight, half the registers, twice the waves per CU) measured against 8 on C3a, four runs
 	// each: 56.1-56.9 us against 58.7-59.2.  TCNN_AMD_FWD_SPT=8 keeps the old shape (A/B runs).
-	static const uint32_t forced = getenv("TCNN_AMD_FWD_SPT") ? (uint32_t)atoi(getenv("TCNN_AMD_FWD_SPT")) : 0u;
+	uint32_t forced = 0;
+#ifdef TCNN_AMD_DEV
+	static const uint32_t dev_forced = getenv("TCNN_AMD_FWD_SPT") ? (uint32_t)atoi(getenv("TCNN_AMD_FWD_SPT")) : 0u; // laboratory knob
+	forced = dev_forced;
+#endif
 	if (max_scatter_chunks(meta) > (uint32_t)FP_MAX_CHUNKS) return 2u;
 	return forced == 8 ? 8u : 4u;
 }
@@ -379,7 +383,9 @@ void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& w
 	const uint32_t items_per_level = div_round_up(n, FP_THREADS * grid_planes_spt(meta));
 	// relative cost of one item: tables beyond a few hundred KB miss the per-CU cache on nearly every corner pair
 	float coarse_cost = 0.6f;
-	if (const char* e = getenv("TCNN_AMD_FWD_COARSE_COST")) coarse_cost = (float)atof(e);
+#ifdef TCNN_AMD_DEV
+	if (const char* e = getenv("TCNN_AMD_FWD_COARSE_COST")) coarse_cost = (float)atof(e); // laboratory knob
+#endif
 	std::vector<float> cost(meta.n_levels);
 	double total = 0;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
@@ -389,20 +395,46 @@ void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& w
 	}
 	// profiling aid: TCNN_AMD_FWD_LEVELS="lo,hi" restricts the work list to levels lo..hi (results are then incomplete!)
 	uint32_t dbg_lo = 0, dbg_hi = meta.n_levels;
-	if (const char* e = getenv("TCNN_AMD_FWD_LEVELS")) {
-		sscanf(e, "%u,%u", &dbg_lo, &dbg_hi);
-		total = 0;
-		for (uint32_t l = dbg_lo; l <= dbg_hi && l < meta.n_levels; ++l) total += (double)cost[l] * items_per_level;
-	}
+#ifdef TCNN_AMD_DEV
+	if (const char* e = getenv("TCNN_AMD_FWD_LEVELS")) sscanf(e, "%u,%u", &dbg_lo, &dbg_hi);
+#endif
+	(void)total;
+	// A level whose table does not fit an XCD's L2 anyway (> 4 MB: config 5's 32 MB tables) is NOT given to one XCD: with per-XCD level runs
+	// eight such tables are in flight at once -- 256 MB, the whole Infinity Cache, beside the plane stores -- nothing stays resident and
+	// every 16-byte pair costs a DRAM burst (3.07 GB read for 537 MB of gathers, measured).  Its items are dealt out to all XCDs in turn
+	// instead, behind the levels that do fit: all XCDs then work on the same one or two big tables at a time, which stay in the Infinity Cache.
+	size_t wide_bytes = (size_t)4 << 20;
+#ifdef TCNN_AMD_DEV
+	if (const char* e = getenv("TCNN_AMD_FWD_WIDE_MB")) wide_bytes = (size_t)std::max(atoi(e), 0) << 20; // 0: never (A/B runs)
+#endif
+	auto is_wide = [&](uint32_t l) { return wide_bytes > 0 && (size_t)meta.levels[l].size * meta.n_features_per_level * 2 > wide_bytes; };
+	double narrow_total = 0;
+	for (uint32_t l = 0; l < meta.n_levels; ++l) if (l >= dbg_lo && l <= dbg_hi && !is_wide(l)) narrow_total += (double)cost[l] * items_per_level;
 	std::vector<std::vector<uint32_t>> runs(8);
 	double acc = 0;
 	for (uint32_t l = 0; l < meta.n_levels; ++l) {
-		if (l < dbg_lo || l > dbg_hi) continue;
+		if (l < dbg_lo || l > dbg_hi || is_wide(l)) continue;
 		for (uint32_t i = 0; i < items_per_level; ++i) {
-			const uint32_t bin = std::min<uint32_t>((uint32_t)((acc + 0.5 * cost[l]) * 8.0 / total), 7u);
+			const uint32_t bin = std::min<uint32_t>((uint32_t)((acc + 0.5 * cost[l]) * 8.0 / narrow_total), 7u);
 			runs[bin].push_back(l << 24 | i);
 			acc += cost[l];
 		}
+	}
+	{ // even the runs out before the wide levels follow (they start together)
+		size_t longest = 0;
+		for (auto& r : runs) longest = std::max(longest, r.size());
+		uint32_t next = 0;
+		for (uint32_t l = 0; l < meta.n_levels; ++l) {
+			if (l < dbg_lo || l > dbg_hi || !is_wide(l)) continue;
+			for (uint32_t i = 0; i < items_per_level; ++i) {
+				// fill the shortest run first until all are level, then round robin
+				size_t best = next % 8;
+				for (size_t b = 0; b < 8; ++b) if (runs[b].size() < runs[best].size()) best = b;
+				runs[best].push_back(l << 24 | i);
+				++next;
+			}
+		}
+		(void)longest;
 	}
 	max_items = 0;
 	for (auto& r : runs) max_items = std::max<uint32_t>(max_items, (uint32_t)r.size());
@@ -413,7 +445,9 @@ void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& w
 	}
 	// 8 workgroups (16 waves) per CU on each XCD's 32 CUs, fewer when there is less work
 	blocks_per_xcd = std::max(1u, std::min(256u, max_items));
-	if (const char* e = getenv("TCNN_AMD_FWD_BLOCKS_PER_XCD")) blocks_per_xcd = std::max(1, atoi(e));
+#ifdef TCNN_AMD_DEV
+	if (const char* e = getenv("TCNN_AMD_FWD_BLOCKS_PER_XCD")) blocks_per_xcd = std::max(1, atoi(e)); // laboratory knob
+#endif
 }
 
 void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,

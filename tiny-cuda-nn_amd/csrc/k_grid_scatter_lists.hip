@@ -383,7 +383,10 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 	if (task.n_entries == 0) return;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	if (dbg_times && tid == 0) dbg_times[0] = __builtin_amdgcn_s_memrealtime();
+	if (dbg_times && tid == 0) {
+		dbg_times[0] = __builtin_amdgcn_s_memrealtime();
+		dbg_times[4] = __builtin_readcyclecounter(); // shader clocks beside the 100 MHz clock: the task's clock rate (laboratory builds print it)
+	}
 
 	ScatterCtx<D, F, REC> c;
 	c.lv = meta->levels[task.level];
@@ -539,7 +542,10 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 	}
 	if (dbg_times) {
 		__syncthreads();
-		if (tid == 0) dbg_times[3] = __builtin_amdgcn_s_memrealtime();
+		if (tid == 0) {
+			dbg_times[3] = __builtin_amdgcn_s_memrealtime();
+			dbg_times[5] = __builtin_readcyclecounter();
+		}
 	}
 }
 
@@ -587,6 +593,7 @@ void launch_lists(hipStream_t s, ScatterListsArgs a, uint32_t n_tasks) {
 				fprintf(stderr, "task %3u level %2u entries %6u samples %6u atomic %u: start %7.1f zero %6.1f accumulate %6.1f flush %6.1f us | split %u of %u\n", i, ht[i].level, ht[i].n_entries,
 				        ht[i].sample_end - ht[i].sample_begin, ht[i].flush_atomic, (h[i * 8] - t0) * 0.01, (h[i * 8 + 1] - h[i * 8]) * 0.01, (h[i * 8 + 2] - h[i * 8 + 1]) * 0.01,
 				        (h[i * 8 + 3] - h[i * 8 + 2]) * 0.01, ht[i].pad & 0xffffu, ht[i].pad >> 16);
+				if (i % 37 == 0 && h[i * 8 + 3] > h[i * 8]) fprintf(stderr, "  clock of task %u: %.0f MHz\n", i, (double)(h[i * 8 + 5] - h[i * 8 + 4]) / ((h[i * 8 + 3] - h[i * 8]) * 0.01));
 			}
 		}
 		(void)hipFree(dbg);

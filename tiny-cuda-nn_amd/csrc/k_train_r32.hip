@@ -412,10 +412,10 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 			const u32x4 lo = __builtin_bit_cast(u32x4, pack8(dx, 0)), hi = __builtin_bit_cast(u32x4, pack8(dx, 1));
 			const uint32_t x0 = __builtin_bit_cast(uint32_t, in.xs.x), x1 = __builtin_bit_cast(uint32_t, in.xs.y);
 			const uint32_t rb = blk * 512, pair2 = a.n * 32; // pair2: two level pairs further
-			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, lo[0], lo[1]}, rs_rec, rec_off + rb, 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, lo[2], lo[3]}, rs_rec, rec_off + (rb + pair2), 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[0], hi[1]}, rs_rec, rec_off + (rb + 2 * pair2), 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[2], hi[3]}, rs_rec, rec_off + (rb + 3 * pair2), 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, lo[0], lo[1]}, rs_rec, rec_off + rb, 0, R32_REC_AUX);
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, lo[2], lo[3]}, rs_rec, rec_off + (rb + pair2), 0, R32_REC_AUX);
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[0], hi[1]}, rs_rec, rec_off + (rb + 2 * pair2), 0, R32_REC_AUX);
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[2], hi[3]}, rs_rec, rec_off + (rb + 3 * pair2), 0, R32_REC_AUX);
 		}
 		R32_SB(); R32_STAMP(14);
 	}

@@ -6,6 +6,15 @@
 
 namespace tcnn_amd {
 
+// Cache policy of the scatter-record stores (the aux operand of the raw buffer stores: 0 default, 2 nontemporal).  Round 2 measured that
+// streamed records cost the scatter 10 us: its tasks then ran on whatever XCD and found the records in the writer's L2.  Since round 4 a
+// record plane is gathered by ONE XCD, which pulls it into its own L2 whatever the writers' L2s hold -- and every dirty line left in
+// those at the kernel's end is written back on the kernel's time.
+#ifndef TCNN_R32_REC_AUX
+#define TCNN_R32_REC_AUX 0
+#endif
+constexpr int R32_REC_AUX = TCNN_R32_REC_AUX;
+
 struct R32Args {
 	const half_t* x;        // level planes half2 [16][n]
 	const float* target;    // [n][dims]
