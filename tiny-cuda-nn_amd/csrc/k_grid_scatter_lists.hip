@@ -501,11 +501,21 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 				if (__builtin_expect((uint32_t)(v + (1 << 24)) < (1u << 25), 1)) return (half_t)((float)v * 5.9604644775390625e-08f);
 				return fixed_to_half((long long)v);
 			};
-			for (uint32_t i = tid; i < n_vals / 2; i += SL_THREADS) {
-				const unsigned long long s = a[i];
+			auto pair_of = [&](const unsigned long long s) -> uint32_t {
 				const int lo = (int)(uint32_t)s, hi = (int)(uint32_t)((s - (unsigned long long)(long long)lo) >> 32);
-				((h2*)g)[i] = h2{round32(lo), round32(hi)};
+				return __builtin_bit_cast(uint32_t, (h2{round32(lo), round32(hi)}));
+			};
+			// four accumulators = eight halves = one 16-byte store per lane where the chunk allows (its first value 16-byte aligned in the table: a
+			// quarter of the store instructions, which queue behind the other workgroup's gathers in the CU's address path)
+			const uint32_t n_pairs = n_vals / 2;
+			const bool quads = ((uintptr_t)g & 15u) == 0;
+			const uint32_t n_quads = quads ? n_pairs / 4 : 0;
+			for (uint32_t q = tid; q < n_quads; q += SL_THREADS) {
+				typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+				const u64x2 s01 = *(const u64x2*)(a + 4 * q), s23 = *(const u64x2*)(a + 4 * q + 2);
+				((u4*)g)[q] = u4{pair_of(s01.x), pair_of(s01.y), pair_of(s23.x), pair_of(s23.y)};
 			}
+			for (uint32_t i = 4 * n_quads + tid; i < n_pairs; i += SL_THREADS) ((uint32_t*)g)[i] = pair_of(a[i]);
 		}
 	} else {
 		// ------------------------------------------------------------------------------------------------ wide passes: 64-bit accumulators, half of the entries at a time
