@@ -20,6 +20,7 @@
 // Arithmetic per contribution is the reference's: (half) weight * dL_dy in fp16 (grid.h:254), weights as fp32 products in dimension
 // order; the sum is exact (integers), rounded to fp16 once -- bit-identical to k_grid_scatter and to the oracle's orc_grid_backward_exact.
 #include "grid_fixed.h"
+#include "adam_device.h"
 #include "mlp_side_jobs.h"
 
 #include <algorithm>
@@ -50,6 +51,7 @@ constexpr int SL_LEAD = TCNN_SL_LEAD;                 // batches gathered ahead 
 constexpr float SL_PACKED_BOUND = 120.0f;
 
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) float lds_f32; // (explicit: a generic pointer to LDS selected against a global one does not compile on gfx950)
 
 template <int D, int F, bool REC>
 struct ScatterCtx {
@@ -362,10 +364,99 @@ struct ScatterListsArgs {
 	int accumulate_mode, force_wide;
 	unsigned long long* dbg_times;
 	uint32_t* fallback_count;
+	AdamInFlush adam; // w_fp != nullptr: the single owner of a chunk applies the optimizer's update to it as it flushes (sl_flush_adam)
 };
+
+// The single owner of a chunk has the chunk's FINAL gradient in LDS when it flushes: adam.h:48-119 runs on it at once -- the same adam_one
+// on the same half gradient as k_adam afterwards, so the same bits (tests: test_adam_in_the_scatter_flush_is_bit_identical) -- and the 28 bytes
+// of optimizer state per parameter stream from and to HBM while the CU's other workgroup gathers from its L2: the two kernels' bounds are
+// different resources.  (Round 2 built this into k_grid_scatter, one 16-wave workgroup per CU, and measured it equal to the two launches: a
+// lone workgroup's accumulators sit idle while it streams.  Two workgroups per CU are what makes it pay.)
+// grad_quad(q) -> the four half gradients of parameters 4 q .. 4 q + 3 of the chunk; p0: the chunk's first parameter; window: LDS floats.
+template <typename GradQuad>
+__device__ inline void sl_flush_adam(const AdamInFlush& adam, const size_t p0, const uint32_t n_quads, half_t* __restrict__ g, lds_f32* window, const uint32_t window_floats, const uint32_t tid, GradQuad&& grad_quad) {
+	typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+	float* __restrict__ wf_p = adam.w_fp + p0;
+	float* __restrict__ m1_p = adam.m1 + p0;
+	float* __restrict__ m2_p = adam.m2 + p0;
+	uint32_t* __restrict__ st_p = (uint32_t*)adam.steps + p0; // uint16 counts (adam.steps16): addressed through st16_p
+	uint16_t* __restrict__ st16_p = (uint16_t*)adam.steps + p0;
+	half_t* __restrict__ wh_p = (half_t*)adam.w_half + p0;
+	// the most recent steps of the debiasing table -- all that parameters touched in the last few thousand steps ask for -- in LDS
+	const uint32_t common = adam.args.common_step;
+	const uint32_t window_base = common + 1 > window_floats ? common + 1 - window_floats : 0; // window[i] = table[window_base + i], up to table[common]
+	for (uint32_t i = tid; i < window_floats; i += SL_THREADS) if (window_base + i <= common) window[i] = adam.debias_table[window_base + i];
+	__syncthreads();
+	const float debias = window[common - window_base];
+	const auto debias_of = [&](const uint32_t t) { return t >= window_base ? window[t - window_base] : adam.debias_table[t]; };
+	constexpr int Q = 4; // quads per thread in flight
+	for (uint32_t q0 = tid; q0 < n_quads; q0 += Q * SL_THREADS) {
+		h4 gq[Q], old[Q];
+		bool live[Q], has_old[Q];
+		float4 wf[Q], a1[Q], a2[Q];
+		uint4 st[Q];
+#pragma unroll
+		for (int k = 0; k < Q; ++k) {
+			const uint32_t q = q0 + k * SL_THREADS;
+			live[k] = q < n_quads;
+			has_old[k] = false;
+			if (live[k]) {
+				gq[k] = grad_quad(q);
+				*(h4*)(g + 4 * (size_t)q) = gq[k];
+				const bool z0 = gq[k][0] == (half_t)0.0f, z1 = gq[k][1] == (half_t)0.0f, z2 = gq[k][2] == (half_t)0.0f, z3 = gq[k][3] == (half_t)0.0f;
+				live[k] = !(z0 && z1 && z2 && z3); // adam.h:76-79: a grid parameter with a zero gradient is left alone -- nothing else of it is read
+				has_old[k] = live[k] && (z0 || z1 || z2 || z3);
+			}
+			if (live[k]) {
+				wf[k] = *(const float4*)(wf_p + 4 * (size_t)q);
+				a1[k] = *(const float4*)(m1_p + 4 * (size_t)q);
+				a2[k] = *(const float4*)(m2_p + 4 * (size_t)q);
+				if (adam.steps16) {
+					typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+					const u16x4 sv = *(const u16x4*)(st16_p + 4 * (size_t)q);
+					st[k] = uint4{sv[0], sv[1], sv[2], sv[3]};
+				} else {
+					st[k] = *(const uint4*)(st_p + 4 * (size_t)q);
+				}
+				if (has_old[k]) old[k] = *(const h4*)(wh_p + 4 * (size_t)q);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < Q; ++k) {
+			if (!live[k]) continue;
+			const size_t i4 = 4 * (size_t)(q0 + k * SL_THREADS);
+			half_t wh[4];
+			bool up[4];
+			adam_one(adam.args, debias_of, debias, false, gq[k][0], wf[k].x, wh[0], a1[k].x, a2[k].x, st[k].x, up[0]);
+			adam_one(adam.args, debias_of, debias, false, gq[k][1], wf[k].y, wh[1], a1[k].y, a2[k].y, st[k].y, up[1]);
+			adam_one(adam.args, debias_of, debias, false, gq[k][2], wf[k].z, wh[2], a1[k].z, a2[k].z, st[k].z, up[2]);
+			adam_one(adam.args, debias_of, debias, false, gq[k][3], wf[k].w, wh[3], a1[k].w, a2[k].w, st[k].w, up[3]);
+			*(float4*)(wf_p + i4) = wf[k];
+			*(float4*)(m1_p + i4) = a1[k];
+			*(float4*)(m2_p + i4) = a2[k];
+			if (adam.steps16) {
+				typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+				*(u16x4*)(st16_p + i4) = u16x4{(uint16_t)st[k].x, (uint16_t)st[k].y, (uint16_t)st[k].z, (uint16_t)st[k].w};
+			} else {
+				*(uint4*)(st_p + i4) = st[k];
+			}
+			// parameters that were not updated keep their half value, whatever it is: quads with a zero gradient somewhere brought their old
+			// halves along, so that the quad is stored whole
+			if (up[0] && up[1] && up[2] && up[3]) {
+				*(h4*)(wh_p + i4) = h4{wh[0], wh[1], wh[2], wh[3]};
+			} else if (has_old[k]) {
+				*(h4*)(wh_p + i4) = h4{up[0] ? wh[0] : old[k][0], up[1] ? wh[1] : old[k][1], up[2] ? wh[2] : old[k][2], up[3] ? wh[3] : old[k][3]};
+			} else { // a non-zero half gradient that became zero when the loss scale was divided out
+#pragma unroll
+				for (int e = 0; e < 4; ++e) if (up[e]) wh_p[i4 + e] = wh[e];
+			}
+		}
+	}
+}
 
 template <int D, int F, bool REC>
 __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t task_index, char* smem) {
+	const ScatterListsArgs& a_ = a; // (a local `a` below shadows the argument block)
 	const GridMeta* __restrict__ meta = a.meta;
 	const uint32_t n = a.n;
 	const MatView x = a.x;
@@ -505,6 +596,15 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 				const int lo = (int)(uint32_t)s, hi = (int)(uint32_t)((s - (unsigned long long)(long long)lo) >> 32);
 				return __builtin_bit_cast(uint32_t, (h2{round32(lo), round32(hi)}));
 			};
+			if (a_.adam.w_fp) { // sole owner, optimizer step included (the host checked that the chunk is a whole number of aligned quads of parameters)
+				typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+				sl_flush_adam(a_.adam, ((size_t)c.lv.offset + task.entry_begin) * F, n_vals / 4, g, (lds_f32*)(smem + SL_ACC_BYTES + 256), SL_WAVES * SL_WAVE_LDS / 4, tid, [&](const uint32_t q) {
+					const unsigned long long s0 = a[2 * q], s1 = a[2 * q + 1];
+					const int l0 = (int)(uint32_t)s0, h0 = (int)(uint32_t)((s0 - (unsigned long long)(long long)l0) >> 32);
+					const int l1 = (int)(uint32_t)s1, h1 = (int)(uint32_t)((s1 - (unsigned long long)(long long)l1) >> 32);
+					return h4{round32(l0), round32(h0), round32(l1), round32(h1)};
+				});
+			} else {
 			// four accumulators = eight halves = one 16-byte store per lane where the chunk allows (its first value 16-byte aligned in the table: a
 			// quarter of the store instructions, which queue behind the other workgroup's gathers in the CU's address path)
 			const uint32_t n_pairs = n_vals / 2;
@@ -516,6 +616,7 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 				((u4*)g)[q] = u4{pair_of(s01.x), pair_of(s01.y), pair_of(s23.x), pair_of(s23.y)};
 			}
 			for (uint32_t i = 4 * n_quads + tid; i < n_pairs; i += SL_THREADS) ((uint32_t*)g)[i] = pair_of(a[i]);
+			}
 		}
 	} else {
 		// ------------------------------------------------------------------------------------------------ wide passes: 64-bit accumulators, half of the entries at a time
@@ -543,6 +644,13 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 					const long long v = acc64[i];
 					if (v != 0) atomicAdd(sc + i, (unsigned long long)v);
 				}
+			} else if (a_.adam.w_fp) {
+				typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+				// (the tables behind the accumulators are dead between the pass and the next part's: the barrier inside comes after every wave's pass)
+				__syncthreads();
+				sl_flush_adam(a_.adam, ((size_t)c.lv.offset + task.entry_begin + sub_lo) * F, sub_vals / 4, gs, (lds_f32*)(smem + SL_ACC_BYTES + 256), SL_WAVES * SL_WAVE_LDS / 4, tid, [&](const uint32_t q) {
+					return h4{fixed_to_half_fast(acc64[4 * q]), fixed_to_half_fast(acc64[4 * q + 1]), fixed_to_half_fast(acc64[4 * q + 2]), fixed_to_half_fast(acc64[4 * q + 3])};
+				});
 			} else {
 				typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 				for (uint32_t i = tid; i < sub_vals / 2; i += SL_THREADS) ((h2*)gs)[i] = h2{fixed_to_half_fast(acc64[2 * i]), fixed_to_half_fast(acc64[2 * i + 1])};
@@ -664,7 +772,11 @@ void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, bool paired_recor
 		const bool listed = n_chunks > 1;
 		// elements (listed: one gather each, ~2 corners) or samples (streamed, all corners) per chunk, and how many tasks share them
 		const double per_chunk_work = listed ? (double)n * rows / n_chunks : (double)n;
-		const uint32_t splits = listed ? (uint32_t)std::min(std::max(per_chunk_work / 16384.0 + 0.5, 1.0), 32.0) : std::min(std::max(n / 8192u, 1u), 64u);
+		// A chunk shared by several tasks is flushed through 64-bit global atomics, one per value and task (~27 G/s chip-wide: 16 384 values
+		// are ~10 us per task, and at 2^20 samples two tasks per fine chunk were 31 M atomics -- 0.53 ms against 0.26 for single owners whose
+		// tasks simply take longer).  So only small chunks are ever shared.
+		const bool cheap_flush = per_chunk * F <= 2048;
+		const uint32_t splits = listed ? (cheap_flush ? (uint32_t)std::min(std::max(per_chunk_work / 16384.0 + 0.5, 1.0), 32.0) : 1u) : std::min(std::max(n / 8192u, 1u), 64u);
 		const uint32_t samples_per_split = next_multiple(div_round_up(n, splits), 64u);
 		for (uint32_t c = 0; c < n_chunks; ++c) {
 			const uint32_t begin = c * per_chunk;
@@ -719,7 +831,7 @@ void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, bool paired_recor
 void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                          const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
                          const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const GridHitLists& lists, bool accumulate, bool dy_records,
-                         const MlpReduceJob* reduce_job, uint32_t* fallback_count) {
+                         const MlpReduceJob* reduce_job, uint32_t* fallback_count, const AdamInFlush* adam) {
 	if (n_tasks == 0) return;
 	CHECK_THROW(lists.elems != nullptr && lists.heads != nullptr && lists.stragglers != nullptr && lists.counts != nullptr && lists.n_items > 0);
 	CHECK_THROW(!dy_records || grid_scatter_records_supported(meta));
@@ -741,6 +853,7 @@ void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMet
 	a.force_wide = switches().scatter_wide ? 1 : 0; // tests: every task through the 64-bit passes
 	a.dbg_times = nullptr;
 	a.fallback_count = fallback_count;
+	if (adam) a.adam = *adam;
 	switch (meta.n_pos_dims) {
 		case 2: dispatch_lists<2>(stream, meta.n_features_per_level, dy_records, a, n_tasks); break;
 		case 3: dispatch_lists<3>(stream, meta.n_features_per_level, dy_records, a, n_tasks); break;

@@ -503,16 +503,22 @@ public:
 			} else if (lds_scatter_usable() && n % 64 == 0) {
 				// MI355X path: LDS owner-computes scatter with exact integer accumulation; writes every element (k_grid_scatter.hip)
 				// hit lists of this very batch, their counters not yet handed to a later forward pass of this stream
-				const bool lists = ctx.hit_elems && ctx.n == n && ctx.hit_stream == (const void*)stream && hit_counters(stream).generation == ctx.hit_generation &&
-				                   !(ctx.adam && mode == GradientMode::Overwrite);
+				const bool lists = ctx.hit_elems && ctx.n == n && ctx.hit_stream == (const void*)stream && hit_counters(stream).generation == ctx.hit_generation;
 				if (lists) { // k_grid_scatter_lists.hip: a static plan, nothing to tune
 					ListsPlan& lp = lists_plan(n, stream, dy_planes && ctx.dy_records);
 					const uint32_t F = m_meta.n_features_per_level;
 					const uint32_t dy_stride_sample = dy_planes ? F : padded_output_width(), dy_stride_level = dy_planes ? n * F : F;
+					// the optimizer's update may ride on the flush of every chunk with a single owner (AdamInFlush; what is listed in adam_done is no
+					// longer the optimizer's to do)
+					const AdamInFlush* adam = nullptr;
 					ctx.adam_done.clear();
+					if (ctx.adam && mode == GradientMode::Overwrite) {
+						ctx.adam_done = lp.adam_ranges;
+						if (!ctx.adam_done.empty()) adam = ctx.adam;
+					}
 					grid_backward_lists(stream, m_meta, dev_meta(), lp.dev_tasks.as<GridScatterTask>(), lp.n_tasks,
 					                    lp.dev_ranges.as<GridScatterRange>(), lp.n_ranges, lp.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, ctx.hit_lists,
-					                    mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, ctx.reduce_job, hit_counters(stream).fallbacks.as<uint32_t>());
+					                    mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, ctx.reduce_job, hit_counters(stream).fallbacks.as<uint32_t>(), adam);
 					if (dL_dx) {
 						CHECK_THROW(ctx.dy_dx);
 						CHECK_THROW(!dy_planes);
@@ -655,6 +661,7 @@ public:
 	struct ListsPlan {
 		DeviceBuf dev_tasks, dev_ranges, scratch;
 		uint32_t n_tasks = 0, n_ranges = 0;
+		ParamRanges adam_ranges; // what a launch of this plan updates itself when it is handed an AdamInFlush: the chunks with a single owner
 	};
 	ListsPlan& lists_plan(uint32_t n, hipStream_t stream, bool records) {
 		const auto key = std::make_pair(n | (records ? 0x80000000u : 0u), (const void*)stream);
@@ -668,6 +675,7 @@ public:
 		grid_scatter_lists_plan(m_meta, n, paired, tasks, ranges, scratch_elems);
 		plan->n_tasks = (uint32_t)tasks.size();
 		plan->n_ranges = (uint32_t)ranges.size();
+		plan->adam_ranges = grid_scatter_adam_ranges(m_meta, tasks, true);
 		auto upload = [](DeviceBuf& b, const void* src, size_t bytes) {
 			b.resize(bytes);
 			if (bytes) HIP_CHECK_THROW(hipMemcpy(b.data(), src, bytes, hipMemcpyHostToDevice));
@@ -682,9 +690,15 @@ public:
 	// Hit lists: TCNN_AMD_SCATTER_LISTS=0 keeps the bit planes (A/B runs, tests; read per step so that one process can cover both)
 	bool hit_lists_usable(uint32_t n) const {
 		const int want = switches().scatter_lists; // 0: never; 1: wherever the kernel can take the grid (tests); -1: where it pays (grid_scatter_prefers_lists)
-		if (want == 0 || switches().adam_in_flush) return false; // (the optimizer step inside the flush is k_grid_scatter's)
+		if (want == 0) return false;
 		if (m_any_binned || n > grid_hit_max_samples(m_meta) || m_meta.n_pos_dims > 3 || m_meta.hash_type == (uint32_t)HashType::Rng) return false; // (Rng: its hash is a loop)
-		return want == 1 || grid_scatter_prefers_lists(m_meta);
+		if (want == 1) return true;
+		// Where it pays: grids with levels of many chunks, and batches whose record planes (16 bytes per sample and level pair) an XCD's 4 MB L2
+		// can serve -- measured on C3a, step with lists / with bit planes in ms: 2^16 0.140 / 0.131 (960 tasks of a few hundred elements
+		// each are all start-up and flush), 2^17 0.164 / 0.165, 2^18 0.202 / 0.224, 2^19 0.329 / 0.340, 2^20 0.599 / 0.587, 2^21 1.247 / 1.112
+		// (planes of 16 - 32 MB: the owners' gathers run at the Infinity Cache's pace once their positions drift apart, while the
+		// bit-plane kernel's tasks, paced by their scans, stay in step and keep finding each other's lines in the L2).
+		return grid_scatter_prefers_lists(m_meta) && n >= (1u << 17) && n <= (1u << 19);
 	}
 	static size_t next_multiple_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 	struct HitCounters {

@@ -189,7 +189,8 @@ void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, bool paired_recor
 void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                          const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
                          const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const GridHitLists& lists, bool accumulate, bool dy_records,
-                         const MlpReduceJob* reduce_job, uint32_t* fallback_count = nullptr);
+                         const MlpReduceJob* reduce_job, uint32_t* fallback_count = nullptr,
+                         const AdamInFlush* adam = nullptr); // (optional) the single owners apply the optimizer step to their chunks: grid_scatter_adam_ranges(tasks) says which parameters
 // the finalize pass of the shared chunks (+ the MLP's slab reduction), shared by both scatter kernels
 void grid_scatter_finalize(hipStream_t stream, const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, void* grad, bool accumulate, const MlpReduceJob* reduce_job);
 // the parameter ranges (relative to grad) a launch of `tasks` with `adam` updates itself; empty = this plan cannot carry the optimizer step
