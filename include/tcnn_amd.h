@@ -195,6 +195,10 @@ size_t tcnn_trainer_image_preps(tcnn_trainer_t t);
  * that neither can overflow; a task whose bound fails runs again with 64-bit sums (same result, slower).  This counts those tasks since
  * the trainer was built; (size_t)-1 on error.  Synchronises with the device. */
 size_t tcnn_trainer_scatter_wide_fallbacks(tcnn_trainer_t t);
+/* Introspection (no counterpart in the reference): training steps of this trainer whose optimizer launch (adam_step, adam.h:150-188)
+ * also ran the last two reductions of the backward pass -- the rounding of the grid gradient's shared chunks and the sum of the network's
+ * weight-gradient slabs -- instead of a launch of their own in front of it (same results; TCNN_AMD_ADAM_PROLOGUE=0 separates them). */
+size_t tcnn_trainer_optimizer_prologue_steps(tcnn_trainer_t t);
 
 #ifdef __cplusplus
 }

@@ -944,6 +944,48 @@ def test_adam_in_the_scatter_flush_is_bit_identical(tcnn, oracle, cfg, n_in, n, 
     assert steps.max() == len(batches) and steps.min() < len(batches)  # some parameters missed updates: the skip is exercised
 
 
+@pytest.mark.parametrize("cfg,n_in,n,env", [(CONFIG_C3B, 2, 4096, {}), (CONFIG_C3A, 2, 16384, {}), (CONFIG_C3A, 2, 16384, {"TCNN_AMD_SCATTER_LISTS": "1"}),
+                                             (CONFIG_3D_F2, 3, 8192, {}), (CONFIG_C3A, 2, 16384, {"TCNN_AMD_ADAM_STEPS32": "1"})])
+def test_finalize_pass_inside_the_optimizer_launch_is_bit_identical(tcnn, oracle, cfg, n_in, n, env, monkeypatch):
+    """The last two reductions of the backward pass -- k_grid_scatter_finalize's rounding of the shared chunks' exact sums (grid.h:215-320's
+    gradient, summed exactly) and the fixed-order sum of the network's weight-gradient slabs -- run as the prologue of the optimizer's launch
+    (k_adam_prologue, the default) or as a launch of their own in front of k_adam (TCNN_AMD_ADAM_PROLOGUE=0): gradients, weights (fp32
+    master and half), both moments and the per-parameter step counts agree bit for bit over several steps, with both gradient kernels
+    (bit planes, hit lists), both widths of the step counts, across the scatter plan's re-cut after step 2 (a step that keeps its finalize
+    launch), and with a step without the optimizer in between (nothing is deferred then); the scratch table is left zero either way
+    (the next step's sums would be wrong otherwise)."""
+    import msgpack
+
+    batches = [oracle.synthetic_batch(n, n_in, 3, seed=70 + i) for i in range(6)]
+
+    def run(extra):
+        full = dict(env, **extra)
+        for k, v in full.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(n_in, 3, cfg, seed=1337)
+        for i, (x, t) in enumerate(batches):
+            if i == 3:
+                tr.training_step(_t(x), _t(t), run_optimizer=False)
+                g_mid = _bits(tr.param_gradients()).copy()
+                tr.optimizer_step()
+            else:
+                tr.training_step(_t(x), _t(t))
+        state = msgpack.unpackb(tr.serialize(True), raw=False)
+        for k in full:
+            monkeypatch.delenv(k)
+        return _bits(tr.params()), tr.params_full_precision().cpu().numpy().view(np.uint32), state["optimizer"], _bits(tr.param_gradients()), g_mid, tr.optimizer_prologue_steps()
+
+    half_a, fp_a, opt_a, g_a, gm_a, n_a = run({})
+    half_b, fp_b, opt_b, g_b, gm_b, n_b = run({"TCNN_AMD_ADAM_PROLOGUE": "0"})
+    # (all steps but the one without the optimizer and the one whose gradient launch is timed for the plan's tuner)
+    assert n_b == 0 and n_a >= len(batches) - 2, "which launch ran the finalize pass is not what this run asked for"
+    assert np.array_equal(g_a, g_b) and np.array_equal(gm_a, gm_b) and np.any(g_a != 0)
+    assert np.array_equal(fp_a, fp_b) and np.array_equal(half_a, half_b)
+    assert opt_a["current_step"] == opt_b["current_step"] == len(batches)
+    for key in ("first_moments_binary", "second_moments_binary", "param_steps_binary"):
+        assert opt_a[key] == opt_b[key], key
+
+
 @pytest.mark.parametrize("cfg,n", [(CONFIG_C2, 8192), (CONFIG_C1, 4096)])
 def test_adam_behind_the_slab_reduction_is_bit_identical(tcnn, oracle, cfg, n, monkeypatch):
     """Models without encoding parameters (BASELINE configs 2 and 1): the optimizer's update of the network's weights is applied by the

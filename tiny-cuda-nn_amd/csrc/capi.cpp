@@ -82,6 +82,7 @@ void switches_reload() {
 	w.adam_steps32 = env_is("TCNN_AMD_ADAM_STEPS32", '1');
 	w.adam_in_flush = env_is("TCNN_AMD_ADAM_IN_FLUSH", '1');
 	w.adam_in_reduce = !env_is("TCNN_AMD_ADAM_IN_REDUCE", '0');
+	w.adam_prologue = !env_is("TCNN_AMD_ADAM_PROLOGUE", '0');
 	w.mlp_r32 = !env_is("TCNN_AMD_MLP_R32", '0');
 	w.mlp_r32a = env_01("TCNN_AMD_MLP_R32A");
 	w.mlp_regs = !env_is("TCNN_AMD_MLP_REGS", '0');
@@ -341,6 +342,9 @@ int tcnn_trainer_inference_mixed_precision(tcnn_trainer_t t, tcnn_stream_t strea
 size_t tcnn_trainer_n_params(tcnn_trainer_t t) { return t->trainer->n_params(); }
 size_t tcnn_trainer_params_updated_in_flush(tcnn_trainer_t t) { return t->trainer->params_updated_in_flush(); }
 size_t tcnn_trainer_image_preps(tcnn_trainer_t t) { return t->trainer->image_preps(); }
+size_t tcnn_trainer_optimizer_prologue_steps(tcnn_trainer_t t) {
+	try { return (size_t)t->trainer->prologue_steps(); } catch (const std::exception& e) { g_last_error = e.what(); return (size_t)-1; }
+}
 size_t tcnn_trainer_scatter_wide_fallbacks(tcnn_trainer_t t) {
 	try { return (size_t)t->trainer->scatter_wide_fallbacks(); } catch (const std::exception& e) { g_last_error = e.what(); return (size_t)-1; }
 }

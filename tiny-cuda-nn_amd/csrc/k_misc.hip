@@ -11,6 +11,8 @@
 //   common_device.h:990-1014     trim_and_cast / cast / cast_from     -> k_trim_and_cast / k_cast_*
 #include "tcnn_common.h"
 #include "adam_device.h"
+#include "grid_fixed.h"
+#include "mlp_side_jobs.h"
 #include "oneblob_device.h"
 
 #include <hip/hip_fp16.h>
@@ -641,6 +643,161 @@ void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix
 	const AdamArgs a = make_adam_args(h, loss_scale, current_step);
 	if (steps16) adam_launch<uint16_t>(stream, a, n, n_matrix, w_fp, w_half, g_half, m1, m2, (uint16_t*)steps, debias_table);
 	else adam_launch<uint32_t>(stream, a, n, n_matrix, w_fp, w_half, g_half, m1, m2, (uint32_t*)steps, debias_table);
+}
+
+// ---- Adam with the backward pass's last two reductions in front (AdamPrologue, tcnn_common.h): workgroups [0, n_reduce_blocks) sum the MLP's
+// weight-gradient slabs (the order of mlp_reduce_block, mlp_side_jobs.h) and step those weights; the next PRO_BLOCKS_PER_RANGE per shared
+// range round the scatter's exact sums into the gradient (what k_grid_scatter_finalize does) and step those parameters; the others are
+// k_adam on everything else.  Whoever writes a gradient's final value applies adam_one to it at once.
+namespace {
+constexpr uint32_t PRO_THREADS = SLAB_REDUCE_ELEMS * SLAB_REDUCE_GROUPS; // 1024
+constexpr uint32_t PRO_BLOCKS_PER_RANGE = 64;
+
+template <typename STEP_T, typename DebiasOf>
+__device__ inline void adam_quad(const AdamArgs& a, DebiasOf&& from_table, const float debias, const bool quad_matrix, const size_t i4, const h4 gv,
+                                 float* __restrict__ w_fp, half_t* __restrict__ w, float* __restrict__ m1, float* __restrict__ m2, STEP_T* __restrict__ steps) {
+	// adam.h:76-79: a grid parameter with a zero gradient is left alone -- nothing else of it is read
+	if (!quad_matrix && gv[0] == (half_t)0.0f && gv[1] == (half_t)0.0f && gv[2] == (half_t)0.0f && gv[3] == (half_t)0.0f) return;
+	float4 wf = *(const float4*)(w_fp + i4), a1 = *(const float4*)(m1 + i4), a2 = *(const float4*)(m2 + i4);
+	uint4 st = adam_load_steps(steps + i4);
+	half_t wh[4];
+	bool up[4];
+	adam_one(a, from_table, debias, quad_matrix, gv[0], wf.x, wh[0], a1.x, a2.x, st.x, up[0]);
+	adam_one(a, from_table, debias, quad_matrix, gv[1], wf.y, wh[1], a1.y, a2.y, st.y, up[1]);
+	adam_one(a, from_table, debias, quad_matrix, gv[2], wf.z, wh[2], a1.z, a2.z, st.z, up[2]);
+	adam_one(a, from_table, debias, quad_matrix, gv[3], wf.w, wh[3], a1.w, a2.w, st.w, up[3]);
+	*(float4*)(w_fp + i4) = wf;
+	*(float4*)(m1 + i4) = a1;
+	*(float4*)(m2 + i4) = a2;
+	adam_store_steps(steps + i4, st);
+	if (up[0] && up[1] && up[2] && up[3]) {
+		*(h4*)(w + i4) = h4{wh[0], wh[1], wh[2], wh[3]};
+	} else { // skipped parameters keep their half value, whatever it is
+#pragma unroll
+		for (int e = 0; e < 4; ++e) if (up[e]) w[i4 + e] = wh[e];
+	}
+}
+
+struct PrologueArgs {
+	uint32_t n_reduce_blocks, reduce_elems, reduce_slabs;
+	int reduce_accumulate;
+	const float* slabs;
+	const GridScatterRange* ranges;
+	uint32_t n_ranges;
+	int accumulate;
+	unsigned long long* scratch;
+	size_t range_base; // parameter index of the gradient element the ranges' grad_begin counts from
+	size_t bulk_begin; // first parameter of the k_adam part (behind the MLP's weights when their slabs are summed here)
+};
+
+template <typename STEP_T>
+__global__ void __launch_bounds__(PRO_THREADS) k_adam_prologue(const AdamArgs a, const size_t n, const size_t n_matrix, float* __restrict__ w_fp, half_t* __restrict__ w, half_t* __restrict__ g,
+                                                               float* __restrict__ m1, float* __restrict__ m2, STEP_T* __restrict__ steps, const float* __restrict__ debias_table, const PrologueArgs p) {
+	__shared__ float part[SLAB_REDUCE_GROUPS * SLAB_REDUCE_ELEMS];
+	const float debias = debias_table[a.common_step];
+	const auto from_table = [&](const uint32_t t) { return debias_table[t]; };
+	const uint32_t tid = threadIdx.x;
+	if (blockIdx.x < p.n_reduce_blocks) {
+		// mlp_reduce_block's sum of element i over the slabs, term for term
+		const uint32_t e = tid & (SLAB_REDUCE_ELEMS - 1), grp = tid / SLAB_REDUCE_ELEMS;
+		const uint32_t i = blockIdx.x * SLAB_REDUCE_ELEMS + e;
+		float q[4] = {0, 0, 0, 0};
+		if (i < p.reduce_elems) {
+			uint32_t k = grp;
+			for (; k + 3 * SLAB_REDUCE_GROUPS < p.reduce_slabs; k += 4 * SLAB_REDUCE_GROUPS) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) q[u] += p.slabs[(size_t)(k + u * SLAB_REDUCE_GROUPS) * p.reduce_elems + i];
+			}
+			for (; k < p.reduce_slabs; k += SLAB_REDUCE_GROUPS) q[0] += p.slabs[(size_t)k * p.reduce_elems + i];
+		}
+		part[grp * SLAB_REDUCE_ELEMS + e] = (q[0] + q[1]) + (q[2] + q[3]);
+		__syncthreads();
+		if (grp == 0 && i < p.reduce_elems) {
+			float s = 0;
+#pragma unroll
+			for (int gi = 0; gi < SLAB_REDUCE_GROUPS; ++gi) s += part[gi * SLAB_REDUCE_ELEMS + e];
+			if (p.reduce_accumulate) s += (float)g[i];
+			const half_t gh = (half_t)s;
+			g[i] = gh;
+			bool up;
+			half_t wh;
+			uint32_t st1 = steps[i];
+			adam_one(a, from_table, debias, i < n_matrix, gh, w_fp[i], wh, m1[i], m2[i], st1, up);
+			steps[i] = (STEP_T)st1;
+			if (up) w[i] = wh;
+		}
+		return;
+	}
+	const uint32_t b = blockIdx.x - p.n_reduce_blocks;
+	if (b < p.n_ranges * PRO_BLOCKS_PER_RANGE) {
+		// k_grid_scatter_finalize's rounding of a shared range, four elements per thread; the scratch is left zero for the next step
+		const GridScatterRange r = p.ranges[b / PRO_BLOCKS_PER_RANGE];
+		typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+		u64x2* sc = (u64x2*)(p.scratch + r.scratch_begin);
+		const size_t g0 = p.range_base + r.grad_begin;
+		for (uint32_t quad = (b % PRO_BLOCKS_PER_RANGE) * PRO_THREADS + tid; quad < r.n_elems / 4; quad += PRO_BLOCKS_PER_RANGE * PRO_THREADS) {
+			const u64x2 lo = sc[2 * quad], hi = sc[2 * quad + 1];
+			sc[2 * quad] = u64x2{0, 0};
+			sc[2 * quad + 1] = u64x2{0, 0};
+			long long s[4] = {(long long)lo.x, (long long)lo.y, (long long)hi.x, (long long)hi.y};
+			const size_t i4 = g0 + 4 * (size_t)quad;
+			if (p.accumulate) {
+				const h4 old = *(const h4*)(g + i4);
+#pragma unroll
+				for (int e = 0; e < 4; ++e) s[e] += half_to_fixed(old[e]);
+			}
+			const h4 gv = h4{fixed_to_half(s[0]), fixed_to_half(s[1]), fixed_to_half(s[2]), fixed_to_half(s[3])};
+			*(h4*)(g + i4) = gv;
+			adam_quad(a, from_table, debias, i4 < n_matrix, i4, gv, w_fp, w, m1, m2, steps);
+		}
+		return;
+	}
+	const size_t i4 = p.bulk_begin + ((size_t)(b - p.n_ranges * PRO_BLOCKS_PER_RANGE) * PRO_THREADS + tid) * 4;
+	if (i4 >= n) return; // (n - bulk_begin is a multiple of 4: adam_step_with_prologue)
+	for (uint32_t r = 0; r < p.n_ranges; ++r) { // the shared ranges have been done above
+		const size_t rb = p.range_base + p.ranges[r].grad_begin;
+		if (i4 >= rb && i4 < rb + p.ranges[r].n_elems) return;
+	}
+	adam_quad(a, from_table, debias, i4 < n_matrix, i4, *(const h4*)(g + i4), w_fp, w, m1, m2, steps);
+}
+} // namespace
+
+bool adam_step_with_prologue(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
+                             float* w_fp, void* w_half, void* g_half, float* m1, float* m2, void* steps, bool steps16, const float* debias_table, const AdamPrologue& pro) {
+	const auto aligned = [](const void* ptr, size_t bytes) { return ((uintptr_t)ptr & (bytes - 1)) == 0; };
+	if (n == 0 || !(aligned(w_fp, 16) && aligned(m1, 16) && aligned(m2, 16) && aligned(steps, steps16 ? 8 : 16) && aligned(w_half, 8) && aligned(g_half, 8))) return false;
+	PrologueArgs p{};
+	p.bulk_begin = 0;
+	if (pro.has_reduce) {
+		// the MLP's weights are the first parameters and all of the matrix weights: quads must not straddle the end of either
+		if (pro.reduce_elems % 4 != 0 || pro.reduce_elems > n || n_matrix % 4 != 0) return false;
+		p.n_reduce_blocks = div_round_up(pro.reduce_elems, (uint32_t)SLAB_REDUCE_ELEMS);
+		p.reduce_elems = pro.reduce_elems;
+		p.reduce_slabs = pro.reduce_slabs;
+		p.reduce_accumulate = pro.reduce_accumulate;
+		p.slabs = pro.slabs;
+		p.bulk_begin = pro.reduce_elems;
+	} else if (n_matrix % 4 != 0) return false;
+	if ((n - p.bulk_begin) % 4 != 0) return false;
+	if (!pro.ranges.empty()) {
+		if ((const char*)pro.grad_base < (const char*)g_half || !aligned(pro.scratch, 16)) return false;
+		p.range_base = (size_t)((const half_t*)pro.grad_base - (const half_t*)g_half);
+		if (p.range_base % 4 != 0) return false;
+		for (const GridScatterRange& r : pro.ranges) {
+			if (r.grad_begin % 4 != 0 || r.n_elems % 4 != 0 || r.scratch_begin % 2 != 0 || p.range_base + r.grad_begin + r.n_elems > n || p.range_base + r.grad_begin < p.bulk_begin) return false;
+		}
+		p.ranges = pro.dev_ranges;
+		p.n_ranges = (uint32_t)pro.ranges.size();
+		p.scratch = (unsigned long long*)pro.scratch;
+		p.accumulate = pro.accumulate ? 1 : 0;
+	}
+	const AdamArgs a = make_adam_args(h, loss_scale, current_step);
+	const uint32_t bulk_blocks = div_round_up((uint32_t)((n - p.bulk_begin) / 4), PRO_THREADS);
+	const dim3 grid(p.n_reduce_blocks + p.n_ranges * PRO_BLOCKS_PER_RANGE + bulk_blocks);
+	if (steps16) hipLaunchKernelGGL(k_adam_prologue<uint16_t>, grid, dim3(PRO_THREADS), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (half_t*)g_half, m1, m2, (uint16_t*)steps, debias_table, p);
+	else hipLaunchKernelGGL(k_adam_prologue<uint32_t>, grid, dim3(PRO_THREADS), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (half_t*)g_half, m1, m2, (uint32_t*)steps, debias_table, p);
+	HIP_CHECK_THROW(hipGetLastError());
+	return true;
 }
 
 void adam_fill_debias_table(hipStream_t stream, float beta1, float beta2, uint32_t from, uint32_t to, float* table) {

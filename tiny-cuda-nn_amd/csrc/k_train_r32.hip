@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 				w[2 * k + 0] = __builtin_amdgcn_perm(odd, even, 0x05040100u); // (even.lo, odd.lo)
 				w[2 * k + 1] = __builtin_amdgcn_perm(odd, even, 0x07060302u); // (even.hi, odd.hi)
 			}
-			__builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, rs_out, o_off + blk * 1024, 0, 2);
+			__builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, rs_out, o_off + blk * 1024, 0, R32_OUT_AUX);
 		}
 		img_write(IMG_DY, w_chain, 0, dyf); // positions 4 h .. 4 h + 3 (plane h) and 8 + 4 h .. (plane 2 + h)
 		const h8 aY = tr_frag16(IMG_DY, 0);  // dY^T: 16 positions x 32 samples

@@ -229,6 +229,9 @@ struct EncodingContext {
 	mutable ParamRanges adam_done;
 	// likewise: a small job the backward pass may carry on one of its launches (MlpReduceJob::taken reports it)
 	mutable const MlpReduceJob* reduce_job = nullptr;
+	// likewise: the optimizer's launch offers to run the scatter's finalize pass (and the reduce job) as its prologue (AdamPrologue,
+	// tcnn_common.h).  A backward pass that takes the offer fills it in, sets ->pending and launches no finalize pass of its own.
+	mutable AdamPrologue* prologue = nullptr;
 	std::vector<EncodingContext> nested; // Composite: one context per nested encoding
 };
 
@@ -516,9 +519,11 @@ public:
 						ctx.adam_done = lp.adam_ranges;
 						if (!ctx.adam_done.empty()) adam = ctx.adam;
 					}
+					// the finalize pass (and the reduce job with it) may be left to the optimizer's launch: no ranges, no job -> no launch here
+					const bool defer = take_prologue(ctx, lp.dev_ranges.as<GridScatterRange>(), lp.host_ranges, lp.scratch.as<uint64_t>(), grads, mode);
 					grid_backward_lists(stream, m_meta, dev_meta(), lp.dev_tasks.as<GridScatterTask>(), lp.n_tasks,
-					                    lp.dev_ranges.as<GridScatterRange>(), lp.n_ranges, lp.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, ctx.hit_lists,
-					                    mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, ctx.reduce_job, hit_counters(stream).fallbacks.as<uint32_t>(), adam);
+					                    lp.dev_ranges.as<GridScatterRange>(), defer ? 0u : lp.n_ranges, lp.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, ctx.hit_lists,
+					                    mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, defer ? nullptr : ctx.reduce_job, hit_counters(stream).fallbacks.as<uint32_t>(), adam);
 					if (dL_dx) {
 						CHECK_THROW(ctx.dy_dx);
 						CHECK_THROW(!dy_planes);
@@ -544,9 +549,11 @@ public:
 					if (dy_planes && ctx.dy_records) ctx.adam_done = plan.adam_ranges;
 					if (!ctx.adam_done.empty()) adam = ctx.adam;
 				}
-				grid_backward_lds(stream, m_meta, dev_meta(), plan.dev_tasks.as<GridScatterTask>(), plan.n_tasks, plan.dev_ranges.as<GridScatterRange>(), plan.n_ranges,
+				// (not in the step whose launch is timed for the tuner: the plan, ranges and scratch included, is rebuilt right after it)
+				const bool defer = !tune && take_prologue(ctx, plan.dev_ranges.as<GridScatterRange>(), plan.host_ranges, plan.scratch.as<uint64_t>(), grads, mode);
+				grid_backward_lds(stream, m_meta, dev_meta(), plan.dev_tasks.as<GridScatterTask>(), plan.n_tasks, plan.dev_ranges.as<GridScatterRange>(), defer ? 0u : plan.n_ranges,
 				                  plan.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, mask,
-				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, tune ? times.as<uint64_t>() : nullptr, adam, ctx.reduce_job);
+				                  mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, tune ? times.as<uint64_t>() : nullptr, adam, defer ? nullptr : ctx.reduce_job);
 				if (m_any_binned) { // levels cut into more than 64 chunks (k_grid_bin.hip)
 					CHECK_THROW(!(dy_planes && ctx.dy_records));
 					ArenaBuf workspace{stream, grid_bin_workspace_bytes(m_meta, n)};
@@ -618,9 +625,33 @@ public:
 	// TCNN_AMD_GRID_SCATTER=atomic selects the reference-shaped global-atomic kernel (kept for A/B runs and as the fp32 / F==1 path)
 	static bool use_lds_scatter() { return switches().grid_scatter_lds; }
 
+	// The optimizer's launch has offered to run this backward pass's finalize pass (ctx.prologue): hand it the shared ranges, their scratch
+	// and the reduce job.  Only where the gradient kernel does not apply the optimizer step itself (AdamInFlush) and a finalize pass exists.
+	bool take_prologue(const EncodingContext& ctx, const GridScatterRange* dev_ranges, const std::vector<GridScatterRange>& ranges, uint64_t* scratch, void* grads, GradientMode mode) const {
+		AdamPrologue* p = ctx.prologue;
+		if (!p || !p->offered || p->pending || ctx.adam || (ranges.empty() && !ctx.reduce_job) || m_any_binned) return false;
+		p->dev_ranges = dev_ranges;
+		p->ranges = ranges;
+		p->scratch = scratch;
+		p->grad_base = grads;
+		p->accumulate = mode == GradientMode::Accumulate;
+		p->has_reduce = false;
+		if (ctx.reduce_job) {
+			p->has_reduce = true;
+			p->reduce_elems = ctx.reduce_job->n_elems;
+			p->reduce_slabs = ctx.reduce_job->n_slabs;
+			p->slabs = ctx.reduce_job->slabs;
+			p->reduce_accumulate = ctx.reduce_job->accumulate;
+			ctx.reduce_job->taken = true;
+		}
+		p->pending = true;
+		return true;
+	}
+
 	struct ScatterPlan {
 		DeviceBuf dev_tasks, dev_ranges, scratch;
 		std::vector<GridScatterTask> host_tasks;
+		std::vector<GridScatterRange> host_ranges;
 		uint32_t n_tasks = 0, n_ranges = 0;
 		uint32_t launches = 0;
 		bool tuned = false;
@@ -635,6 +666,7 @@ public:
 		grid_scatter_plan(m_meta, n, plan.host_tasks, ranges, scratch_elems, measured_level_us);
 		plan.n_tasks = (uint32_t)plan.host_tasks.size();
 		plan.n_ranges = (uint32_t)ranges.size();
+		plan.host_ranges = ranges;
 		plan.adam_ranges = grid_scatter_adam_ranges(m_meta, plan.host_tasks, true);
 		plan.dev_tasks.resize(plan.host_tasks.size() * sizeof(GridScatterTask));
 		if (!plan.host_tasks.empty()) HIP_CHECK_THROW(hipMemcpy(plan.dev_tasks.data(), plan.host_tasks.data(), plan.host_tasks.size() * sizeof(GridScatterTask), hipMemcpyHostToDevice));
@@ -660,6 +692,7 @@ public:
 	// launch leaves behind for the next one on the same stream (the zeroed scratch table)
 	struct ListsPlan {
 		DeviceBuf dev_tasks, dev_ranges, scratch;
+		std::vector<GridScatterRange> host_ranges;
 		uint32_t n_tasks = 0, n_ranges = 0;
 		ParamRanges adam_ranges; // what a launch of this plan updates itself when it is handed an AdamInFlush: the chunks with a single owner
 	};
@@ -675,6 +708,7 @@ public:
 		grid_scatter_lists_plan(m_meta, n, paired, tasks, ranges, scratch_elems);
 		plan->n_tasks = (uint32_t)tasks.size();
 		plan->n_ranges = (uint32_t)ranges.size();
+		plan->host_ranges = ranges;
 		plan->adam_ranges = grid_scatter_adam_ranges(m_meta, tasks, true);
 		auto upload = [](DeviceBuf& b, const void* src, size_t bytes) {
 			b.resize(bytes);
@@ -1741,7 +1775,8 @@ public:
 	// forward() -> loss_evaluate() -> backward(), activations never leave the CU.  out / dL_dout / L: [n][padded_out].
 	std::unique_ptr<ModelContext> fused_step(hipStream_t stream, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
 	                                         LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, MatViewMut* dL_dinput, const void* params,
-	                                         void* gradients, GradientMode mode, StepProfile* profile = nullptr, const AdamInFlush* adam = nullptr, ParamRanges* adam_done = nullptr) {
+	                                         void* gradients, GradientMode mode, StepProfile* profile = nullptr, const AdamInFlush* adam = nullptr, ParamRanges* adam_done = nullptr,
+	                                         AdamPrologue* prologue = nullptr) {
 		check_batch(n);
 		auto ctx = std::make_unique<Ctx>();
 		// Everything in order on the caller's stream.  Running the two small kernels around the MLP kernel (k_mlp_prep, k_wgrad_reduce,
@@ -1751,7 +1786,7 @@ public:
 		fused_encode(stream, *ctx, n, input, params, dL_dinput != nullptr, mode != GradientMode::Ignore, side_jobs_enabled());
 		if (profile) profile->mark(stream, StepProfile::Encode, true);
 		fused_mlp_and_scatter(stream, *ctx, n, input, target, data_pdf, external_dL_dy, loss, loss_scale, out, dL_dout, L, compact_context, dL_dinput, params, gradients, mode, profile,
-		                      adam, adam_done);
+		                      adam, adam_done, prologue);
 		return ctx;
 	}
 
@@ -1785,7 +1820,7 @@ public:
 	// the slab reduction and the encoding's backward pass.  target == nullptr requires external_dL_dy.
 	void fused_mlp_and_scatter(hipStream_t stream, const Ctx& ctx, uint32_t n, MatView input, const float* target, const float* data_pdf, const void* external_dL_dy,
 	                           LossType loss, float loss_scale, void* out, void* dL_dout, float* L, bool compact_context, MatViewMut* dL_dinput, const void* params, void* gradients,
-	                           GradientMode mode, StepProfile* profile = nullptr, const AdamInFlush* adam = nullptr, ParamRanges* adam_done = nullptr) {
+	                           GradientMode mode, StepProfile* profile = nullptr, const AdamInFlush* adam = nullptr, ParamRanges* adam_done = nullptr, AdamPrologue* prologue = nullptr) {
 		const _Float16* p = (const _Float16*)params;
 		_Float16* g = (_Float16*)gradients;
 		const uint32_t n_net = (uint32_t)m_network->n_params();
@@ -1874,7 +1909,9 @@ public:
 				enc_adam = adam->advanced(n_net);
 				ctx.encoding_ctx.adam = &enc_adam;
 			}
+			ctx.encoding_ctx.prologue = prologue;
 			m_encoding->backward(stream, ctx.encoding_ctx, n, input, dL_dnetwork_input.data(), dL_dinput, p + n_net, g ? g + n_net : nullptr, mode, plane_f > 0);
+			ctx.encoding_ctx.prologue = nullptr;
 			ctx.encoding_ctx.adam = nullptr;
 			if (ctx.encoding_ctx.reduce_job) {
 				ctx.encoding_ctx.reduce_job = nullptr;
@@ -1997,6 +2034,11 @@ public:
 	virtual void finish_split_step(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, const void* gradients, const ParamRanges& done) {
 		throw std::runtime_error{"Optimizer: finish_split_step without begin_split_step"};
 	}
+	// step() with the backward pass's finalize pass as the prologue of the same launch (AdamPrologue).  takes_prologue(): this optimizer
+	// can; step_with_prologue returns false when this prologue's shapes do not fit -- nothing has happened then, the caller runs the
+	// finalize pass and step() itself.
+	virtual bool takes_prologue() const { return false; }
+	virtual bool step_with_prologue(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, void* gradients, const AdamPrologue& prologue) { return false; }
 	virtual float learning_rate() const = 0;
 	virtual void set_learning_rate(float val) = 0;
 	virtual uint32_t step_count() const = 0;
@@ -2094,6 +2136,17 @@ public:
 		ensure_step_width(stream);
 		adam_step(stream, m_h, m_n_weights, m_n_matrix, loss_scale, m_current_step, weights_full_precision, weights, gradients,
 		          m_first_moments.as<float>(), m_second_moments.as<float>(), m_param_steps.data(), m_steps16, m_debias.as<float>());
+	}
+
+	bool takes_prologue() const override { return true; }
+	bool step_with_prologue(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, void* gradients, const AdamPrologue& prologue) override {
+		++m_current_step;
+		ensure_debias_table(stream);
+		ensure_step_width(stream);
+		if (adam_step_with_prologue(stream, m_h, m_n_weights, m_n_matrix, loss_scale, m_current_step, weights_full_precision, weights, gradients, m_first_moments.as<float>(),
+		                            m_second_moments.as<float>(), m_param_steps.data(), m_steps16, m_debias.as<float>(), prologue)) return true;
+		--m_current_step; // (the table and the width of the counts are as step() wants them; it counts the step itself)
+		return false;
 	}
 
 	// The per-parameter update counts (this fork's adam.h:66-99: a parameter whose gradient is zero in a step is skipped, so it has
@@ -2889,12 +2942,27 @@ public:
 	}
 
 	size_t params_updated_in_flush() const { return m_params_updated_in_flush; }
+	size_t m_prologue_steps = 0;
 	// TCNN_AMD_ADAM_IN_FLUSH=1: the optimizer's update is applied by the gradient kernels where they can carry it.  Off by default:
 	// bit-identical and measured equal in time on C3a (0.229 / 0.230 vs 0.230 / 0.225 ms per step; DESIGN.md "Adam in the scatter").
 	static bool adam_in_flush_enabled() { return switches().adam_in_flush; }
 	// TCNN_AMD_ADAM_IN_REDUCE=0: models without encoding parameters (BASELINE config 2) run the optimizer as a launch of its own again
 	// instead of behind the weight gradients' slab reduction (k_wgrad_reduce_adam; bit-identical, one ~4 us launch less per step)
 	static bool adam_in_reduce_enabled() { return switches().adam_in_reduce; }
+
+	// the finalize pass and the slab reduction an AdamPrologue holds, as the launches they were
+	void run_prologue_alone(hipStream_t stream, const AdamPrologue& p) {
+		MlpReduceJob job;
+		if (p.has_reduce) {
+			job.n_elems = p.reduce_elems;
+			job.n_slabs = p.reduce_slabs;
+			job.slabs = p.slabs;
+			job.grad = m_grads.data();
+			job.accumulate = p.reduce_accumulate;
+		}
+		if (!p.ranges.empty()) grid_scatter_finalize(stream, p.dev_ranges, (uint32_t)p.ranges.size(), p.scratch, p.grad_base, p.accumulate, p.has_reduce ? &job : nullptr);
+		else if (p.has_reduce) mlp_reduce_slabs(stream, p.reduce_elems, p.reduce_slabs, p.slabs, m_grads.data(), p.reduce_accumulate != 0);
+	}
 
 	void optimizer_step(hipStream_t stream, float loss_scale) { // trainer.h:155-157
 		m_model->invalidate_live_image();
@@ -2940,10 +3008,14 @@ public:
 			const bool split = run_optimizer && mode == GradientMode::Overwrite && (adam_in_flush_enabled() || (adam_in_reduce_enabled() && m_model->optimizer_rides_on_reduce())) &&
 			                   m_optimizer->begin_split_step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), adam);
 			if (m_params_exposed) m_model->invalidate_live_image(); // somebody holds a pointer to the parameters: no image outlives a step
+			// the optimizer's launch offers to finish the backward pass's gradients itself (AdamPrologue: the scatter's finalize pass and the
+			// MLP's slab reduction as the prologue of k_adam's launch -- one launch and one kernel boundary less per step)
+			AdamPrologue prologue;
+			prologue.offered = run_optimizer && !split && mode != GradientMode::Ignore && switches().adam_prologue && m_optimizer->takes_prologue();
 			ctx->model_ctx = m_model->fused_step(stream, n, input, target, data_pdf, external_dL_dy, m_loss, loss_scale, ctx->output.data(),
 			                                     ctx->compact ? ctx->compact_dL_doutput.data() : ctx->dL_doutput.data(),
 			                                     ctx->compact ? ctx->compact_L.as<float>() : ctx->L.as<float>(), ctx->compact, dL_dinput, m_params.data(), m_grads.data(), mode,
-			                                     &m_profile, split ? &adam : nullptr, split ? &adam_done : nullptr);
+			                                     &m_profile, split ? &adam : nullptr, split ? &adam_done : nullptr, prologue.offered ? &prologue : nullptr);
 			if (run_optimizer) {
 				m_profile.mark(stream, StepProfile::Optimizer, false);
 				m_params_updated_in_flush = 0;
@@ -2951,9 +3023,16 @@ public:
 				if (split) {
 					if (!m_model->live_image_kept()) m_model->invalidate_live_image(); // the update below (or the gradient kernels') changes network weights
 					m_optimizer->finish_split_step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data(), adam_done);
+				} else if (prologue.pending) {
+					m_model->invalidate_live_image();
+					if (m_optimizer->step_with_prologue(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data(), prologue)) ++m_prologue_steps;
+					else {
+						run_prologue_alone(stream, prologue); // shapes the fused launch does not take: the two launches of before
+						m_optimizer->step(stream, loss_scale, m_params_fp.as<float>(), m_params.data(), m_grads.data());
+					}
 				} else optimizer_step(stream, loss_scale);
 				m_profile.mark(stream, StepProfile::Optimizer, true);
-			}
+			} else if (prologue.pending) run_prologue_alone(stream, prologue); // (never: nothing is offered without an optimizer step)
 			m_profile.end_step();
 			return ctx;
 		} else {
@@ -3064,6 +3143,7 @@ public:
 	const void* params_unexposed() const { return m_params.data(); } // for comparisons only
 	size_t image_preps() const { return m_model->image_preps(); }
 	uint64_t scatter_wide_fallbacks() { return m_model->scatter_wide_fallbacks(); }
+	size_t prologue_steps() const { return m_prologue_steps; }
 	void* param_gradients() const { return m_grads.data(); }
 
 private:

@@ -14,6 +14,10 @@ namespace tcnn_amd {
 #define TCNN_R32_REC_AUX 0
 #endif
 constexpr int R32_REC_AUX = TCNN_R32_REC_AUX;
+#ifndef TCNN_R32_OUT_AUX
+#define TCNN_R32_OUT_AUX 2
+#endif
+constexpr int R32_OUT_AUX = TCNN_R32_OUT_AUX; // the [n][16] output rows (2: nontemporal)
 
 struct R32Args {
 	const half_t* x;        // level planes half2 [16][n]

@@ -52,6 +52,7 @@ struct Switches {
 	bool adam_steps32 = false;    // TCNN_AMD_ADAM_STEPS32=1: uint32 update counts from the start
 	bool adam_in_flush = false;   // TCNN_AMD_ADAM_IN_FLUSH=1: Adam applied by the scatter's chunk owners
 	bool adam_in_reduce = true;   // TCNN_AMD_ADAM_IN_REDUCE=0: k_adam as a launch of its own for models without encoding parameters
+	bool adam_prologue = true;    // TCNN_AMD_ADAM_PROLOGUE=0: the scatter's finalize pass (+ slab reduction) as a launch of its own in front of k_adam
 	bool mlp_r32 = true;          // TCNN_AMD_MLP_R32=0: k_mlp_train_regs / k_mlp_train instead of the 32x32x16 kernels
 	int mlp_r32a = -1;            // TCNN_AMD_MLP_R32A=0 / 1: k_mlp_train_r32 / k_mlp_train_r32a whatever the batch size
 	bool mlp_regs = true;         // TCNN_AMD_MLP_REGS=0: the LDS-image kernels of k_train.hip
@@ -411,6 +412,28 @@ struct AdamInFlush {
 		return r;
 	}
 };
+// What the backward pass of a fused step leaves for the optimizer's launch to finish (k_adam_prologue, k_misc.hip): the scatter's finalize
+// pass -- the shared chunks' exact sums in `scratch` are rounded into the gradient, the scratch left zero -- and the fixed-order sum of the
+// MLP's weight-gradient slabs.  Both are the last writes of the gradients the optimizer reads next: in ONE launch the workgroup that
+// finishes a gradient updates its parameters at once, every other workgroup does what k_adam does, and the step has one ~5 us launch
+// (k_grid_scatter_finalize) and one kernel boundary less.  Same rounding, same adam_one: gradients, weights, moments, counts bit-identical.
+struct AdamPrologue {
+	bool offered = false;                      // the trainer will run an optimizer that can take it (set by the trainer)
+	bool pending = false;                      // the backward pass left its finalize pass here instead of launching it
+	const GridScatterRange* dev_ranges = nullptr;
+	std::vector<GridScatterRange> ranges;      // host copy; grad_begin relative to grad_base
+	uint64_t* scratch = nullptr;
+	void* grad_base = nullptr;                 // half: the gradient array the ranges index (the encoding's part of the gradient vector)
+	bool accumulate = false;
+	bool has_reduce = false;
+	uint32_t reduce_elems = 0, reduce_slabs = 0; // the MLP's weights (the first reduce_elems parameters) and its slabs
+	const float* slabs = nullptr;
+	int reduce_accumulate = 0;
+};
+// adam_step with the prologue in the same launch.  false: the shapes do not allow it (alignment) -- nothing was launched, the caller
+// runs grid_scatter_finalize / mlp_reduce_slabs and adam_step itself.
+bool adam_step_with_prologue(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,
+                             float* w_fp, void* w_half, void* g_half, float* m1, float* m2, void* steps, bool steps16, const float* debias_table, const AdamPrologue& p);
 // steps: the per-parameter update counts, uint32 or -- steps16 -- uint16 (what the optimizer keeps while every count fits:
 // 4 of the 36 bytes per parameter the kernel moves are the counts' upper halves otherwise)
 void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix, float loss_scale, uint32_t current_step,

@@ -102,6 +102,10 @@ class Trainer:
         """launches of the weight-rearranging kernel by this trainer's training steps so far (tcnn_amd.h: tcnn_trainer_image_preps)"""
         return int(_C.lib.tcnn_trainer_image_preps(self._h))
 
+    def optimizer_prologue_steps(self):
+        """training steps whose optimizer launch also finished the backward pass's gradients (tcnn_amd.h: tcnn_trainer_optimizer_prologue_steps)"""
+        return int(_C.lib.tcnn_trainer_optimizer_prologue_steps(self._h))
+
     def scatter_wide_fallbacks(self):
         """tasks of the grid gradient kernel that could not prove their packed 32-bit sums and ran the 64-bit passes (tcnn_amd.h)"""
         return int(_C.lib.tcnn_trainer_scatter_wide_fallbacks(self._h))
