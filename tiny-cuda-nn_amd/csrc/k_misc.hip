@@ -690,8 +690,17 @@ struct PrologueArgs {
 	size_t bulk_begin; // first parameter of the k_adam part (behind the MLP's weights when their slabs are summed here)
 };
 
+// (98 scalar registers per wave admit ONE 16-wave workgroup per CU.  Limiting them to 80 -- amdgpu_num_sgpr, two workgroups per CU, the
+// 8 waves per SIMD k_adam keeps -- was measured on C3a, same device, three alternations: optimizer 61.0 - 62.5 us against 58.8 - 59.8.)
+#ifndef TCNN_PRO_BOUNDS
+#define TCNN_PRO_BOUNDS __launch_bounds__(PRO_THREADS)
+#endif
+#ifndef TCNN_PRO_Q
+#define TCNN_PRO_Q 1
+#endif
+constexpr int PRO_Q = TCNN_PRO_Q; // quads per thread of the k_adam part, one workgroup width apart
 template <typename STEP_T>
-__global__ void __launch_bounds__(PRO_THREADS) k_adam_prologue(const AdamArgs a, const size_t n, const size_t n_matrix, float* __restrict__ w_fp, half_t* __restrict__ w, half_t* __restrict__ g,
+__global__ void TCNN_PRO_BOUNDS k_adam_prologue(const AdamArgs a, const size_t n, const size_t n_matrix, float* __restrict__ w_fp, half_t* __restrict__ w, half_t* __restrict__ g,
                                                                float* __restrict__ m1, float* __restrict__ m2, STEP_T* __restrict__ steps, const float* __restrict__ debias_table, const PrologueArgs p) {
 	__shared__ float part[SLAB_REDUCE_GROUPS * SLAB_REDUCE_ELEMS];
 	const float debias = debias_table[a.common_step];
@@ -752,13 +761,23 @@ __global__ void __launch_bounds__(PRO_THREADS) k_adam_prologue(const AdamArgs a,
 		}
 		return;
 	}
-	const size_t i4 = p.bulk_begin + ((size_t)(b - p.n_ranges * PRO_BLOCKS_PER_RANGE) * PRO_THREADS + tid) * 4;
-	if (i4 >= n) return; // (n - bulk_begin is a multiple of 4: adam_step_with_prologue)
-	for (uint32_t r = 0; r < p.n_ranges; ++r) { // the shared ranges have been done above
-		const size_t rb = p.range_base + p.ranges[r].grad_begin;
-		if (i4 >= rb && i4 < rb + p.ranges[r].n_elems) return;
+	h4 gv[PRO_Q];
+	bool live[PRO_Q];
+#pragma unroll
+	for (int k = 0; k < PRO_Q; ++k) {
+		const size_t i4 = p.bulk_begin + (((size_t)(b - p.n_ranges * PRO_BLOCKS_PER_RANGE) * PRO_Q + k) * PRO_THREADS + tid) * 4;
+		live[k] = i4 < n; // (n - bulk_begin is a multiple of 4: adam_step_with_prologue)
+		for (uint32_t r = 0; r < p.n_ranges; ++r) { // the shared ranges have been done above
+			const size_t rb = p.range_base + p.ranges[r].grad_begin;
+			if (i4 >= rb && i4 < rb + p.ranges[r].n_elems) live[k] = false;
+		}
+		if (live[k]) gv[k] = *(const h4*)(g + i4);
 	}
-	adam_quad(a, from_table, debias, i4 < n_matrix, i4, *(const h4*)(g + i4), w_fp, w, m1, m2, steps);
+#pragma unroll
+	for (int k = 0; k < PRO_Q; ++k) {
+		const size_t i4 = p.bulk_begin + (((size_t)(b - p.n_ranges * PRO_BLOCKS_PER_RANGE) * PRO_Q + k) * PRO_THREADS + tid) * 4;
+		if (live[k]) adam_quad(a, from_table, debias, i4 < n_matrix, i4, gv[k], w_fp, w, m1, m2, steps);
+	}
 }
 } // namespace
 
@@ -792,7 +811,7 @@ bool adam_step_with_prologue(hipStream_t stream, const AdamHyper& h, size_t n, s
 		p.accumulate = pro.accumulate ? 1 : 0;
 	}
 	const AdamArgs a = make_adam_args(h, loss_scale, current_step);
-	const uint32_t bulk_blocks = div_round_up((uint32_t)((n - p.bulk_begin) / 4), PRO_THREADS);
+	const uint32_t bulk_blocks = div_round_up((uint32_t)((n - p.bulk_begin) / 4), PRO_THREADS * (uint32_t)PRO_Q);
 	const dim3 grid(p.n_reduce_blocks + p.n_ranges * PRO_BLOCKS_PER_RANGE + bulk_blocks);
 	if (steps16) hipLaunchKernelGGL(k_adam_prologue<uint16_t>, grid, dim3(PRO_THREADS), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (half_t*)g_half, m1, m2, (uint16_t*)steps, debias_table, p);
 	else hipLaunchKernelGGL(k_adam_prologue<uint32_t>, grid, dim3(PRO_THREADS), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (half_t*)g_half, m1, m2, (uint32_t*)steps, debias_table, p);
