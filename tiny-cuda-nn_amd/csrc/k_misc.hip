@@ -646,12 +646,14 @@ void adam_step(hipStream_t stream, const AdamHyper& h, size_t n, size_t n_matrix
 }
 
 // ---- Adam with the backward pass's last two reductions in front (AdamPrologue, tcnn_common.h): workgroups [0, n_reduce_blocks) sum the MLP's
-// weight-gradient slabs (the order of mlp_reduce_block, mlp_side_jobs.h) and step those weights; the next PRO_BLOCKS_PER_RANGE per shared
+// weight-gradient slabs (the order of mlp_reduce_block, mlp_side_jobs.h) and step those weights; the next pro_range_blocks() per shared
 // range round the scatter's exact sums into the gradient (what k_grid_scatter_finalize does) and step those parameters; the others are
 // k_adam on everything else.  Whoever writes a gradient's final value applies adam_one to it at once.
 namespace {
 constexpr uint32_t PRO_THREADS = SLAB_REDUCE_ELEMS * SLAB_REDUCE_GROUPS; // 1024
-constexpr uint32_t PRO_BLOCKS_PER_RANGE = 64;
+constexpr uint32_t PRO_MAX_BLOCKS_PER_RANGE = 64;
+// workgroups of a shared range: one per 1024 quads, at most 64 (k_grid_scatter_finalize's number)
+__host__ __device__ inline uint32_t pro_range_blocks(const uint32_t n_elems) { return min(PRO_MAX_BLOCKS_PER_RANGE, max(1u, (n_elems / 4 + PRO_THREADS - 1) / PRO_THREADS)); }
 
 template <typename STEP_T, typename DebiasOf>
 __device__ inline void adam_quad(const AdamArgs& a, DebiasOf&& from_table, const float debias, const bool quad_matrix, const size_t i4, const h4 gv,
@@ -683,7 +685,7 @@ struct PrologueArgs {
 	int reduce_accumulate;
 	const float* slabs;
 	const GridScatterRange* ranges;
-	uint32_t n_ranges;
+	uint32_t n_ranges, n_range_blocks; // (the sum of pro_range_blocks over the ranges)
 	int accumulate;
 	unsigned long long* scratch;
 	size_t range_base; // parameter index of the gradient element the ranges' grad_begin counts from
@@ -738,13 +740,16 @@ __global__ void TCNN_PRO_BOUNDS k_adam_prologue(const AdamArgs a, const size_t n
 		return;
 	}
 	const uint32_t b = blockIdx.x - p.n_reduce_blocks;
-	if (b < p.n_ranges * PRO_BLOCKS_PER_RANGE) {
+	if (b < p.n_range_blocks) {
 		// k_grid_scatter_finalize's rounding of a shared range, four elements per thread; the scratch is left zero for the next step
-		const GridScatterRange r = p.ranges[b / PRO_BLOCKS_PER_RANGE];
+		uint32_t ri = 0, first = 0; // which range this workgroup belongs to, and which of the range's workgroups it is
+		for (uint32_t nb = pro_range_blocks(p.ranges[0].n_elems); b >= first + nb; nb = pro_range_blocks(p.ranges[ri].n_elems)) { first += nb; ++ri; }
+		const GridScatterRange r = p.ranges[ri];
+		const uint32_t my = b - first, of = pro_range_blocks(r.n_elems);
 		typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 		u64x2* sc = (u64x2*)(p.scratch + r.scratch_begin);
 		const size_t g0 = p.range_base + r.grad_begin;
-		for (uint32_t quad = (b % PRO_BLOCKS_PER_RANGE) * PRO_THREADS + tid; quad < r.n_elems / 4; quad += PRO_BLOCKS_PER_RANGE * PRO_THREADS) {
+		for (uint32_t quad = my * PRO_THREADS + tid; quad < r.n_elems / 4; quad += of * PRO_THREADS) {
 			const u64x2 lo = sc[2 * quad], hi = sc[2 * quad + 1];
 			sc[2 * quad] = u64x2{0, 0};
 			sc[2 * quad + 1] = u64x2{0, 0};
@@ -765,7 +770,7 @@ __global__ void TCNN_PRO_BOUNDS k_adam_prologue(const AdamArgs a, const size_t n
 	bool live[PRO_Q];
 #pragma unroll
 	for (int k = 0; k < PRO_Q; ++k) {
-		const size_t i4 = p.bulk_begin + (((size_t)(b - p.n_ranges * PRO_BLOCKS_PER_RANGE) * PRO_Q + k) * PRO_THREADS + tid) * 4;
+		const size_t i4 = p.bulk_begin + (((size_t)(b - p.n_range_blocks) * PRO_Q + k) * PRO_THREADS + tid) * 4;
 		live[k] = i4 < n; // (n - bulk_begin is a multiple of 4: adam_step_with_prologue)
 		for (uint32_t r = 0; r < p.n_ranges; ++r) { // the shared ranges have been done above
 			const size_t rb = p.range_base + p.ranges[r].grad_begin;
@@ -775,7 +780,7 @@ __global__ void TCNN_PRO_BOUNDS k_adam_prologue(const AdamArgs a, const size_t n
 	}
 #pragma unroll
 	for (int k = 0; k < PRO_Q; ++k) {
-		const size_t i4 = p.bulk_begin + (((size_t)(b - p.n_ranges * PRO_BLOCKS_PER_RANGE) * PRO_Q + k) * PRO_THREADS + tid) * 4;
+		const size_t i4 = p.bulk_begin + (((size_t)(b - p.n_range_blocks) * PRO_Q + k) * PRO_THREADS + tid) * 4;
 		if (live[k]) adam_quad(a, from_table, debias, i4 < n_matrix, i4, gv[k], w_fp, w, m1, m2, steps);
 	}
 }
@@ -805,14 +810,23 @@ bool adam_step_with_prologue(hipStream_t stream, const AdamHyper& h, size_t n, s
 		for (const GridScatterRange& r : pro.ranges) {
 			if (r.grad_begin % 4 != 0 || r.n_elems % 4 != 0 || r.scratch_begin % 2 != 0 || p.range_base + r.grad_begin + r.n_elems > n || p.range_base + r.grad_begin < p.bulk_begin) return false;
 		}
+		// shared ranges that follow the k_adam part's first parameter without a gap (the coarse levels at the front of the table) are not its
+		// business: it starts behind them (its workgroups skip whatever other range they meet)
+		for (bool moved = true; moved;) {
+			moved = false;
+			for (const GridScatterRange& r : pro.ranges) {
+				if (r.n_elems && p.range_base + r.grad_begin == p.bulk_begin) { p.bulk_begin += r.n_elems; moved = true; }
+			}
+		}
 		p.ranges = pro.dev_ranges;
 		p.n_ranges = (uint32_t)pro.ranges.size();
+		for (const GridScatterRange& r : pro.ranges) p.n_range_blocks += pro_range_blocks(r.n_elems);
 		p.scratch = (unsigned long long*)pro.scratch;
 		p.accumulate = pro.accumulate ? 1 : 0;
 	}
 	const AdamArgs a = make_adam_args(h, loss_scale, current_step);
 	const uint32_t bulk_blocks = div_round_up((uint32_t)((n - p.bulk_begin) / 4), PRO_THREADS * (uint32_t)PRO_Q);
-	const dim3 grid(p.n_reduce_blocks + p.n_ranges * PRO_BLOCKS_PER_RANGE + bulk_blocks);
+	const dim3 grid(p.n_reduce_blocks + p.n_range_blocks + bulk_blocks);
 	if (steps16) hipLaunchKernelGGL(k_adam_prologue<uint16_t>, grid, dim3(PRO_THREADS), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (half_t*)g_half, m1, m2, (uint16_t*)steps, debias_table, p);
 	else hipLaunchKernelGGL(k_adam_prologue<uint32_t>, grid, dim3(PRO_THREADS), 0, stream, a, n, n_matrix, w_fp, (half_t*)w_half, (half_t*)g_half, m1, m2, (uint32_t*)steps, debias_table, p);
 	HIP_CHECK_THROW(hipGetLastError());
