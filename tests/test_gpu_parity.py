@@ -968,6 +968,8 @@ def test_finalize_pass_inside_the_optimizer_launch_is_bit_identical(tcnn, oracle
                 tr.training_step(_t(x), _t(t), run_optimizer=False)
                 g_mid = _bits(tr.param_gradients()).copy()
                 tr.optimizer_step()
+            elif i == 4:  # GradientMode::Accumulate: the prologue adds to the gradients of step 3 before it rounds
+                tr.training_step(_t(x), _t(t), gradient_mode=2)
             else:
                 tr.training_step(_t(x), _t(t))
         state = msgpack.unpackb(tr.serialize(True), raw=False)
