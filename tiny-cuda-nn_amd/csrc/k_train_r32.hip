@@ -50,7 +50,7 @@ template <typename V> __device__ inline void st32_stream(void* base, const uint3
 }
 
 // LOSS 1: L2, 2: RelativeL2
-// DIAG (timing-only builds, TCNN_AMD_MLP_DIAG; results are wrong): bit 0: weight fragments are not read from LDS, bit 1: the transposing
+// DIAG (timing-only builds, TCNN_AMD_MLP_DIAG; results are wrong; bit 5: no weight-gradient products): bit 0: weight fragments are not read from LDS, bit 1: the transposing
 // reads are not done, bit 2: the image writes are not done, bit 3: the loss is not evaluated; bit 4: ReLU' as min / sub / and;
 // bit 6: clocks per region of the trip (waves 0 and 4) into a.dbg (results are right with bits 4 and 6)
 //
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		R32_SB(); R32_STAMP(8);
 		// dWout (rows = positions, 16 hidden features per tile) beside the first tile of dH1 = (Wout^T dY) act'(H1) (common_device.h:241-297: from the forward OUTPUT)
 #pragma unroll
-		for (int tc = 0; tc < 4; ++tc) wout[tc] = mfma(aY, bH[tc], wout[tc]);
+		for (int tc = 0; tc < 4; ++tc) if constexpr ((DIAG & 32) == 0) wout[tc] = mfma(aY, bH[tc], wout[tc]);
 		const h8 d10 = relu_bwd8<(DIAG & 16) != 0>(pack8(g0, 0), h10), d11 = relu_bwd8<(DIAG & 16) != 0>(pack8(g0, 1), h11);
 		img_write(IMG_DH, w_chain, 0, d10);
 		img_write(IMG_DH, w_chain, 1, d11);
@@ -378,8 +378,10 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		for (int tr = 0; tr < 2; ++tr)
 #pragma unroll
 			for (int tc = 0; tc < 2; ++tc) {
+				if constexpr ((DIAG & 32) == 0) {
 				wacc[2 + 2 * tr + tc] = mfma32(tA[2 * tr + 0], tB[2 * tc + 0], wacc[2 + 2 * tr + tc]);
 				wacc[2 + 2 * tr + tc] = mfma32(tA[2 * tr + 1], tB[2 * tc + 1], wacc[2 + 2 * tr + tc]);
+				}
 			}
 		const h8 d00 = relu_bwd8<(DIAG & 16) != 0>(pack8(e0, 0), img_own(IMG_H0, 0)), d01 = relu_bwd8<(DIAG & 16) != 0>(pack8(e0, 1), img_own(IMG_H0, 1));
 		const h8 d02 = relu_bwd8<(DIAG & 16) != 0>(pack8(e1, 0), img_own(IMG_H0 + 2048, 0)), d03 = relu_bwd8<(DIAG & 16) != 0>(pack8(e1, 1), img_own(IMG_H0 + 2048, 1));
@@ -404,8 +406,10 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		R32_SB(); R32_STAMP(13);
 #pragma unroll
 		for (int tr = 0; tr < 2; ++tr) {
+			if constexpr ((DIAG & 32) == 0) {
 			wacc[tr] = mfma32(tA[2 * tr + 0], tB[0], wacc[tr]);
 			wacc[tr] = mfma32(tA[2 * tr + 1], tB[1], wacc[tr]);
+			}
 		}
 		// scatter records {x, y, gradients of levels 2 p, 2 p + 1}: registers 4 g .. 4 g + 3 are features 8 g + 4 h .. + 3, i.e. level pair p = 2 g + h
 		{
@@ -617,6 +621,7 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 	else if (diag == 15) go(k_mlp_train_r32<2, 15>);
 	else if (diag == 16) go(k_mlp_train_r32<2, 16>);
 	else if (diag == 64) go(k_mlp_train_r32<2, 64>);
+	else if (diag == 34) go(k_mlp_train_r32<2, 34>); // the chain wave of a role split: no weight-gradient products, no transposing reads
 	else if (loss == LossType::L2) go(k_mlp_train_r32<1>);
 	else go(k_mlp_train_r32<2>);
 	if (a.dbg) {
