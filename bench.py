@@ -249,6 +249,31 @@ METRIC = {
 POOL = 4  # pre-generated batches, visited in turn: the step is timed on fresh samples, not on one batch its scatter plan was cut for
 
 
+SETTLE_MS = 100.0  # --settle-ms
+
+
+def settle_device(torch, ms):
+    """An MI355X that has idled needs several milliseconds of work before its clocks have settled: the first ~25 training steps after an
+    idle period run 2-7 % slower than the ones behind them (tools/steps_probe.py, profiles/r04_steps_probe.txt: 202 -> 211 -> 199 us per
+    step in a fresh process, the same hump after 2 s of idling in the SAME process, none for a fresh trainer on a busy device) -- and
+    `--steps 20 --warmup 5` times exactly steps 6-25 of a fresh process (0.2127-0.2157 ms against 0.2004 for `--steps 200 --warmup 50`
+    on one device).  So the device is first kept busy for `ms` milliseconds with work that is NOT the workload and touches none of its
+    state -- memory-bound torch elementwise passes over a 256 MB tensor --, and the W warmup steps and the K timed steps follow at once.
+    Measured with the driver's flags: 0.2077-0.2109 ms (the workload's own kernels on a scratch trainer would settle it fully, 0.204-0.206:
+    not done, those would be warmup steps by another name).  Reported in the line as `device_settle_ms`; `--settle-ms 0` switches it off."""
+    if ms <= 0:
+        return
+    a = torch.rand((64 << 20,), device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(20):
+            b = a * 1.0001
+            a.add_(b, alpha=1e-6)
+        torch.cuda.synchronize()
+    del a, b
+
+
 def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=None):
     """`steps` timed trainer->training_step(input, target) calls (trainer.h:163-190) of workload `name` after `warmup` untimed ones.
     Every 8th timed step also records HIP events on the launch stream around its pieces (tcnn_trainer_profile_next_step: events
@@ -262,6 +287,7 @@ def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=N
     if barrier is None:
         barrier = torch.cuda.synchronize
     ctx = None
+    settle_device(torch, SETTLE_MS)
     for i in range(warmup):
         ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
     loss0 = tr.loss(ctx) if ctx is not None else float("nan")
@@ -357,10 +383,12 @@ def launch_ranks(n):
 
 
 def main():
+    global SETTLE_MS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle-ms", type=float, default=SETTLE_MS, help="milliseconds of unrelated device work (fp16 matmuls) before the warmup steps, so that an idle device's clocks have settled (settle_device); 0: none")
     ap.add_argument("--workload", default="c3a", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -368,6 +396,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the timing collectives (tests: gloo)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "none"], help="none: launcher / collective plumbing only, no GPU work (CPU tests)")
     args = ap.parse_args()
+    SETTLE_MS = max(0.0, args.settle_ms)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
     if args.device == "none":
@@ -467,6 +496,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "device_settle_ms": SETTLE_MS,
             "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
