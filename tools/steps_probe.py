@@ -31,3 +31,12 @@ for _ in range(200): b = a @ a
 torch.cuda.synchronize()
 tr3 = native.create_from_config(n_in, n_out, cfg).trainer
 timeline(tr3, tag="fresh trainer behind 200 matmuls:")
+
+# host side: how long one training_step call keeps the host (the first timed step's launch latency is all of this)
+import statistics
+torch.cuda.synchronize()
+hs = []
+for i in range(40):
+    t = time.perf_counter(); tr3.training_step(x, y); hs.append((time.perf_counter() - t) * 1e6)
+    if i % 10 == 9: torch.cuda.synchronize()
+print("host us per training_step call (Python -> ctypes -> 4 launches): median %.1f, first after a sync %.1f %.1f %.1f" % (statistics.median(hs), hs[0], hs[10], hs[20]))
