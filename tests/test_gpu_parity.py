@@ -877,6 +877,46 @@ def test_hit_list_scatter_is_exact(tcnn, oracle, monkeypatch, n_in, n, enc_cfg):
         assert np.array_equal(g2, g), env
 
 
+@pytest.mark.parametrize("shape", ["one_cell", "one_row", "chunk_edge", "mixed"])
+def test_hit_list_scatter_with_clustered_samples(tcnn, oracle, monkeypatch, shape):
+    """Collisions as the domain has them, at a batch size where the hit lists are the default (2^17 samples, BASELINE config 3a): every
+    sample in ONE cell of the finest level (all of a level's elements in one or two chunks: runs of 1024 elements per item, far beyond a
+    wave's window; sums far beyond what 32 bits are proven to hold -> the 64-bit passes), every sample on one row (y fixed), samples that
+    straddle the first chunk boundary of the dense levels (stragglers), and a mixture with uniform samples.  Gradients bit-identical to the
+    bit-plane kernel's (TCNN_AMD_SCATTER_LISTS=0), which sums in 64 bits and knows no lists; outputs identical too."""
+    n = 1 << 17
+    rng = np.random.default_rng(5)
+    x, t = oracle.synthetic_batch(n, 2, 3, seed=31)
+    if shape == "one_cell":
+        x[:] = np.float32([0.3141592, 0.2718281]) + rng.random((n, 2), dtype=np.float32) * np.float32(1e-6)
+    elif shape == "one_row":
+        x[:, 1] = np.float32(0.6180339)
+    elif shape == "chunk_edge":  # x around the places where dense levels' chunks meet: rows whose two corners lie in different chunks
+        x[:, 0] = (rng.integers(0, 64, n) / np.float32(64.0) + rng.uniform(-2e-3, 2e-3, n)).astype(np.float32).clip(0, 1)
+    else:
+        x[: n // 2] = np.float32([0.5, 0.5]) + rng.random((n // 2, 2), dtype=np.float32) * np.float32(1e-3)
+    n_net = oracle.Trainer(2, 3, CONFIG_C3A, seed=1337).model.network.n_params
+
+    def grads(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, CONFIG_C3A, seed=1337)
+        for _ in range(2):
+            ctx = tr.training_step(_t(x), _t(t), run_optimizer=False)
+        res = _bits(tr.param_gradients())[n_net:].copy(), _bits(ctx.output()).copy(), tr.scatter_wide_fallbacks()
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
+
+    g, out, fb = grads({})
+    g0, out0, fb0 = grads({"TCNN_AMD_SCATTER_LISTS": "0"})
+    assert fb0 == 0 and np.any(g != 0)
+    if shape == "one_cell":
+        assert fb > 0, "131 072 samples in one cell must overflow the proven range of the packed sums"
+    assert np.array_equal(out, out0)
+    assert np.array_equal(g, g0)
+
+
 def test_hit_list_scatter_falls_back_to_wide_sums(tcnn, oracle, monkeypatch):
     """Targets of 1e4 make dL/d(encoding) large enough that sum |product| of a task exceeds what 32-bit sums are proven to hold
     (128 in loss-scaled units): those tasks must notice, discard their packed sums and run the 64-bit passes -- same gradients as the
