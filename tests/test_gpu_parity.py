@@ -1019,6 +1019,11 @@ def test_finalize_pass_inside_the_optimizer_launch_is_bit_identical(tcnn, oracle
 
     half_a, fp_a, opt_a, g_a, gm_a, n_a = run({})
     half_b, fp_b, opt_b, g_b, gm_b, n_b = run({"TCNN_AMD_ADAM_PROLOGUE": "0"})
+    # a prologue the optimizer's launch does not take (here: refused on request) is run as the two launches of before by the trainer
+    half_c, fp_c, opt_c, g_c, gm_c, n_c = run({"TCNN_AMD_ADAM_PROLOGUE": "refuse"})
+    assert n_c == 0 and np.array_equal(g_c, g_b) and np.array_equal(gm_c, gm_b) and np.array_equal(fp_c, fp_b) and np.array_equal(half_c, half_b)
+    for key in ("first_moments_binary", "second_moments_binary", "param_steps_binary"):
+        assert opt_c[key] == opt_b[key], key
     # (all steps but the one without the optimizer and the one whose gradient launch is timed for the plan's tuner)
     assert n_b == 0 and n_a >= len(batches) - 2, "which launch ran the finalize pass is not what this run asked for"
     assert np.array_equal(g_a, g_b) and np.array_equal(gm_a, gm_b) and np.any(g_a != 0)

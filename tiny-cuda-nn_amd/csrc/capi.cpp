@@ -83,6 +83,7 @@ void switches_reload() {
 	w.adam_in_flush = env_is("TCNN_AMD_ADAM_IN_FLUSH", '1');
 	w.adam_in_reduce = !env_is("TCNN_AMD_ADAM_IN_REDUCE", '0');
 	w.adam_prologue = !env_is("TCNN_AMD_ADAM_PROLOGUE", '0');
+	w.adam_prologue_refused = env_is("TCNN_AMD_ADAM_PROLOGUE", 'r');
 	w.mlp_r32 = !env_is("TCNN_AMD_MLP_R32", '0');
 	w.mlp_r32a = env_01("TCNN_AMD_MLP_R32A");
 	w.mlp_regs = !env_is("TCNN_AMD_MLP_REGS", '0');

@@ -2140,6 +2140,7 @@ public:
 
 	bool takes_prologue() const override { return true; }
 	bool step_with_prologue(hipStream_t stream, float loss_scale, float* weights_full_precision, void* weights, void* gradients, const AdamPrologue& prologue) override {
+		if (switches().adam_prologue_refused) return false; // (tests: the caller's path for a prologue this launch does not take)
 		++m_current_step;
 		ensure_debias_table(stream);
 		ensure_step_width(stream);

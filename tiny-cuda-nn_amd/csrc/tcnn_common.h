@@ -53,6 +53,7 @@ struct Switches {
 	bool adam_in_flush = false;   // TCNN_AMD_ADAM_IN_FLUSH=1: Adam applied by the scatter's chunk owners
 	bool adam_in_reduce = true;   // TCNN_AMD_ADAM_IN_REDUCE=0: k_adam as a launch of its own for models without encoding parameters
 	bool adam_prologue = true;    // TCNN_AMD_ADAM_PROLOGUE=0: the scatter's finalize pass (+ slab reduction) as a launch of its own in front of k_adam
+	bool adam_prologue_refused = false; // TCNN_AMD_ADAM_PROLOGUE=refuse (tests): the optimizer is offered the prologue and turns it down, as it does for shapes its launch does not take
 	bool mlp_r32 = true;          // TCNN_AMD_MLP_R32=0: k_mlp_train_regs / k_mlp_train instead of the 32x32x16 kernels
 	int mlp_r32a = -1;            // TCNN_AMD_MLP_R32A=0 / 1: k_mlp_train_r32 / k_mlp_train_r32a whatever the batch size
 	bool mlp_regs = true;         // TCNN_AMD_MLP_REGS=0: the LDS-image kernels of k_train.hip
