@@ -10,7 +10,7 @@ from tinycudann import native
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3a"
 n_in, n_out, batch, cfg = bench.WORKLOADS[wl]
-tr = native.create_from_config(n_in, n_out, cfg).trainer if hasattr(native.create_from_config(n_in, n_out, cfg), "trainer") else native.create_from_config(n_in, n_out, cfg)
+tr = native.create_from_config(n_in, n_out, cfg).trainer
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.rand(batch, n_in, device="cuda", generator=g)
 y = torch.rand(batch, n_out, device="cuda", generator=g)
