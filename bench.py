@@ -287,9 +287,14 @@ def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=N
     if barrier is None:
         barrier = torch.cuda.synchronize
     ctx = None
-    settle_device(torch, SETTLE_MS)
+    if warmup == 0:
+        settle_device(torch, SETTLE_MS)
     for i in range(warmup):
         ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
+        if i == 0:
+            # behind the first step, not in front of it: a trainer's first step keeps the HOST busy for ~4 ms (plans, allocations, kernel
+            # attributes) while the device idles -- long enough for a settled device to fall back
+            settle_device(torch, SETTLE_MS)
     loss0 = tr.loss(ctx) if ctx is not None else float("nan")
     barrier()
     t0 = time.perf_counter()
