@@ -258,7 +258,8 @@ def settle_device(torch, ms):
     step in a fresh process, the same hump after 2 s of idling in the SAME process, none for a fresh trainer on a busy device) -- and
     `--steps 20 --warmup 5` times exactly steps 6-25 of a fresh process (0.2127-0.2157 ms against 0.2004 for `--steps 200 --warmup 50`
     on one device).  So the device is first kept busy for `ms` milliseconds with work that is NOT the workload and touches none of its
-    state -- memory-bound torch elementwise passes over a 256 MB tensor --, and the W warmup steps and the K timed steps follow at once.
+    state -- memory-bound torch elementwise passes over a 256 MB tensor -- behind the first warmup step (measure_training), and the other
+    warmup steps and the K timed steps follow at once.
     Measured with the driver's flags: 0.2077-0.2109 ms (the workload's own kernels on a scratch trainer would settle it fully, 0.204-0.206:
     not done, those would be warmup steps by another name).  Reported in the line as `device_settle_ms`; `--settle-ms 0` switches it off."""
     if ms <= 0:
