@@ -199,6 +199,13 @@ size_t tcnn_trainer_scatter_wide_fallbacks(tcnn_trainer_t t);
  * also ran the last two reductions of the backward pass -- the rounding of the grid gradient's shared chunks and the sum of the network's
  * weight-gradient slabs -- instead of a launch of their own in front of it (same results; TCNN_AMD_ADAM_PROLOGUE=0 separates them). */
 size_t tcnn_trainer_optimizer_prologue_steps(tcnn_trainer_t t);
+/* Introspection (no counterpart in the reference): backward passes of this trainer's grid encoding that ran the list-fed gradient
+ * kernel (k_grid_scatter_lists: hit lists written by the forward kernel) rather than the bit-plane, binned or atomic forms -- tests assert
+ * which kernel produced the gradients they compare with the oracle (replaces kernel_grid_backward, grid.h:215-320). */
+size_t tcnn_trainer_list_scatters(tcnn_trainer_t t);
+/* Introspection: 1 when this context owns the network's weight-gradient slabs because their reduction was left to the optimizer's
+ * launch (tcnn_trainer_optimizer_prologue_steps): they must outlive training_step()'s own scope, until that launch is enqueued. */
+int tcnn_train_ctx_keeps_weight_gradient_slabs(tcnn_trainer_t t, tcnn_train_ctx_t ctx);
 
 #ifdef __cplusplus
 }

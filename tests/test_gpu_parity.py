@@ -839,10 +839,10 @@ LIST_SCATTER_CASES = [
     (3, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 18, "base_resolution": 8, "per_level_scale": 2.0}),
     (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 17, "base_resolution": 16, "per_level_scale": 2.0}),
     (2, 4096, {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 8, "log2_hashmap_size": 14, "base_resolution": 16, "per_level_scale": 2.0}),
-    (2, 8192, {"otype": "DenseGrid", "n_levels": 6, "n_features_per_level": 2, "base_resolution": 16, "per_level_scale": 2.0}),
+    (2, 8192, {"otype": "DenseGrid", "n_levels": 8, "n_features_per_level": 2, "base_resolution": 16, "per_level_scale": 1.5}),  # (8 levels: 16 features, no padding -- a padded encoding has no level planes and hence no lists)
     (2, 8192, {"otype": "TiledGrid", "n_levels": 8, "n_features_per_level": 2, "base_resolution": 128, "per_level_scale": 1.5}),
     (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 16, "per_level_scale": 2.0, "interpolation": "Nearest"}),
-    (3, 4096, {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 8, "per_level_scale": 2.0, "interpolation": "Smoothstep"}),
+    (3, 4096, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 8, "per_level_scale": 1.5, "interpolation": "Smoothstep"}),
     (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 16, "per_level_scale": 2.0, "hash": "Prime"}),
 ]
 
@@ -875,6 +875,58 @@ def test_hit_list_scatter_is_exact(tcnn, oracle, monkeypatch, n_in, n, enc_cfg):
         g2, out2, _ = grads(env)
         assert np.array_equal(out2, out), env
         assert np.array_equal(g2, g), env
+
+
+def _exact_step_against_oracle(tcnn, oracle, cfg, n_in, n, modes, seed=5, x_seed=42):
+    """One or more training_step(external_dL_dy) passes of a LINEAR network with weights in {-1, 0, 1} (every sum of the MLP's backward
+    pass exact in fp32 whatever its order, so dL/d(encoded input) has the oracle's bits): yields (trainer, grid gradient bits, the oracle's
+    exact scatter grid.h:215-320 of the same dL/d(encoded input)) after every pass."""
+    cfg = {**cfg, "network": {**cfg["network"], "activation": "None"}}
+    ref = oracle.Trainer(n_in, 3, cfg, seed=1337)
+    tr = tcnn.Trainer(n_in, 3, cfg, seed=1337)
+    params_h, rs = _linear_net_params(oracle, ref.model, seed)
+    tr.set_params(_t(params_h.view(np.float16)))
+    n_net = ref.model.network.n_params
+    want = np.zeros(ref.model.encoding.n_params, dtype=np.uint16)
+    for step, mode in enumerate(modes):
+        x = oracle.Pcg32(x_seed + step).uniform_strided(n * n_in).reshape(n, n_in)
+        x[:8] = np.float32([[0.0] * n_in, [1.0] * n_in, [0.5] * n_in, [0.999999] * n_in, [1e-7] * n_in, [0.25] * n_in, [0.75] * n_in, [0.125] * n_in])  # cell corners and edges
+        dy = oracle.half_bits(_exact_external_dy(rs, n, ref.model.padded_output_width))
+        out, ctx = ref.model.forward(x, params_h)
+        _, dnet_in = ref.model.backward(x, params_h, ctx, out, dy)
+        ref.model.encoding.backward_exact(x, dnet_in, want, accumulate=step > 0)
+        tr.training_step(_t(x), None, run_optimizer=False, gradient_mode=mode, external_dL_dy=_t(dy.view(np.float16)))
+        yield tr, _bits(tr.param_gradients())[n_net:], want
+
+
+@pytest.mark.parametrize("n_in,n,enc_cfg", LIST_SCATTER_CASES)
+def test_hit_list_scatter_matches_oracle(tcnn, oracle, monkeypatch, n_in, n, enc_cfg):
+    """k_grid_scatter_lists against the ORACLE (orc_grid_backward_exact restating grid.h:215-320 with one final rounding), bit for bit, for every
+    grid shape of LIST_SCATTER_CASES, GradientMode::Overwrite and then Accumulate on top of it (trainer.h:147-149, grid.h:858 skipped).  The
+    list-fed kernel is forced (TCNN_AMD_SCATTER_LISTS=1) and the test asserts that it is the kernel that ran."""
+    from tinycudann.native import GRADIENT_ACCUMULATE, GRADIENT_OVERWRITE
+
+    monkeypatch.setenv("TCNN_AMD_SCATTER_LISTS", "1")
+    cfg = {**CONFIG_C3B, "encoding": enc_cfg}
+    passes = 0
+    for tr, got, want in _exact_step_against_oracle(tcnn, oracle, cfg, n_in, n, (GRADIENT_OVERWRITE, GRADIENT_ACCUMULATE)):
+        passes += 1
+        assert tr.list_scatters() == passes, "the list-fed scatter did not run"
+        assert np.count_nonzero(want) > 0
+        assert np.array_equal(got, want), f"pass {passes}"
+
+
+def test_hit_list_scatter_matches_oracle_at_the_bench_size(tcnn, oracle):
+    """BASELINE config 3a at 2^18 samples with DEFAULT switches -- the path bench.py times: hit lists written by k_grid_fwd_planes, dL/d(encoded
+    input) as level planes, k_grid_scatter_lists with packed 32-bit sums -- bit-identical to the oracle's exact scatter (grid.h:215-320)."""
+    from tinycudann.native import GRADIENT_OVERWRITE
+
+    for tr, got, want in _exact_step_against_oracle(tcnn, oracle, CONFIG_C3A, 2, 1 << 18, (GRADIENT_OVERWRITE,)):
+        assert tr.list_scatters() == 1, "the default scatter of the bench configuration is the list-fed kernel"
+        fb = tr.scatter_wide_fallbacks()
+        assert fb >= 0  # (how many tasks summed in 64 bits: data dependent -- this test's gradients are ~1e3 times a training step's)
+        assert np.count_nonzero(want) > 5_000_000
+        assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("shape", ["one_cell", "one_row", "chunk_edge", "mixed"])

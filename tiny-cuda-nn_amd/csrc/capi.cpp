@@ -349,6 +349,10 @@ size_t tcnn_trainer_optimizer_prologue_steps(tcnn_trainer_t t) {
 size_t tcnn_trainer_scatter_wide_fallbacks(tcnn_trainer_t t) {
 	try { return (size_t)t->trainer->scatter_wide_fallbacks(); } catch (const std::exception& e) { g_last_error = e.what(); return (size_t)-1; }
 }
+size_t tcnn_trainer_list_scatters(tcnn_trainer_t t) { return (size_t)t->trainer->list_scatters(); }
+int tcnn_train_ctx_keeps_weight_gradient_slabs(tcnn_trainer_t t, tcnn_train_ctx_t ctx) {
+	return (t && ctx && ctx->ctx && ctx->ctx->model_ctx && t->trainer->model().context_keeps_slabs(*ctx->ctx->model_ctx)) ? 1 : 0;
+}
 uint32_t tcnn_trainer_padded_output_width(tcnn_trainer_t t) { return t->trainer->model().padded_output_width(); }
 float* tcnn_trainer_params_full_precision(tcnn_trainer_t t) { return t->trainer->params_full_precision(); }
 void* tcnn_trainer_params(tcnn_trainer_t t) { return t->trainer->params(); }

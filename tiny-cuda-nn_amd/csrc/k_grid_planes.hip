@@ -11,8 +11,10 @@
 //     a workgroup's item (FP_THREADS x FP_SPT samples of one level) is counting-sorted by chunk in LDS -- a rank per element from one
 //     returning LDS add on the chunk's counter, a 64-lane scan for the chunks' offsets -- and leaves as ONE contiguous, chunk-sorted run
 //     in the item's own region of the level's pool (coalesced stores) with its 65 offsets beside it.  No global atomics.  The scatter
-//     then walks the items' runs of its chunk instead of scanning a bit plane.  Before: bit planes over samples per (level, chunk),
-//     built in LDS with integer ORs (or ballots for levels with few chunks); kept for callers without lists.
+//     then walks the items' runs of its chunk instead of scanning a bit plane.  Round 5: an element is a cell ROW with its two entries and
+//     its two half weights (8 bytes + a 16-bit sample number) -- this kernel has them in registers anyway, and the owner then needs neither coordinates nor hashes.
+//     Before: bit planes over samples per (level, chunk), built in LDS with integer ORs (or ballots for levels with few chunks); kept
+//     for callers without lists.
 #include "grid_device.h"
 #include "mlp_side_jobs.h"
 
@@ -25,6 +27,14 @@ namespace tcnn_amd {
 namespace {
 
 constexpr int FP_THREADS = 128; // 2 waves per workgroup
+// ... and with hit lists: a work item is FP_LIST_THREADS x FP_SPT samples, and the item's run of a chunk (samples x rows / chunks elements
+// of 8 bytes) is what the chunk's owner reads in one piece -- 16 elements = 128 bytes from a 512-sample item, and every piece drags the
+// rest of its first and last 128-byte line along (measured in the owners: 19 us per task from such runs, 10 from one contiguous list,
+// profiles/r05_scatter_dev.txt)
+#ifndef TCNN_FP_LIST_THREADS
+#define TCNN_FP_LIST_THREADS 256
+#endif
+constexpr int FP_LIST_THREADS = TCNN_FP_LIST_THREADS;
 
 constexpr int FP_MAX_CHUNKS = GRID_FILTER_MAX_CHUNKS; // bit planes per level: levels cut into more chunks get no filter (they are binned, k_grid_bin.hip)
 constexpr int FP_PER_LANE = FP_MAX_CHUNKS / 64;       // chunks whose words one lane carries out (chunk = lane + 64 j)
@@ -33,25 +43,29 @@ constexpr int FP_PER_LANE = FP_MAX_CHUNKS / 64;       // chunks whose words one 
 // Shapes: 4 (16 gathers in flight per thread; 8 is kept for A/B runs), and 2 for the big 3-D grids whose 8 corners x 4 features would
 // not fit the registers.
 template <int D, int F, int FP_SPT, bool LISTS>
-__global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
+__global__ void __launch_bounds__(LISTS ? FP_LIST_THREADS : FP_THREADS) k_grid_fwd_planes(
 	const GridMeta* __restrict__ meta, const uint32_t* __restrict__ work, const uint32_t max_items, const uint32_t blocks_per_xcd, const uint32_t n, const MatView x,
 	const half_t* __restrict__ grid, half_t* __restrict__ out, unsigned long long* __restrict__ bits, const MlpPrepJob prep, const GridHitLists lists
 ) {
 	typedef typename VecOf<half_t, F>::type vecF;
+	constexpr int THREADS = LISTS ? FP_LIST_THREADS : FP_THREADS;
 	if (prep.image) { // side job (mlp_side_jobs.h): the fragment images of the network this batch is encoded for; independent of everything below
 		const uint32_t total = (prep.desc.n_frags_fwd + prep.desc.n_frags_bwd + prep.desc.n_frags_r32) * 512;
-		for (uint32_t e = blockIdx.x * FP_THREADS + threadIdx.x; e < total; e += gridDim.x * FP_THREADS) mlp_prep_element(prep.desc, (const half_t*)prep.params, (half_t*)prep.image, e);
+		for (uint32_t e = blockIdx.x * THREADS + threadIdx.x; e < total; e += gridDim.x * THREADS) mlp_prep_element(prep.desc, (const half_t*)prep.params, (half_t*)prep.image, e);
 	}
 	constexpr int FP_WAVE_SAMPLES = 64 * FP_SPT;
-	constexpr int FP_ITEM_SAMPLES = FP_THREADS * FP_SPT;
+	constexpr int FP_ITEM_SAMPLES = THREADS * FP_SPT;
 	constexpr int STAGE_ELEMS = FP_ITEM_SAMPLES << (D - 1); // one element per (sample, row) of an item
 	// bit planes (!LISTS) or the item's counting sort (LISTS): the staged elements, counters, offsets
-	__shared__ __attribute__((aligned(16))) unsigned long long lds_raw[LISTS ? STAGE_ELEMS / 2 + 72 : (FP_THREADS / 64) * FP_SPT * FP_MAX_CHUNKS];
+	constexpr int STAGE_U64 = STAGE_ELEMS * (int)GRID_HIT_WORDS / 2 + STAGE_ELEMS / 4; // the item's elements: 8 bytes each + their 16-bit sample numbers
+	static_assert(!LISTS || FP_ITEM_SAMPLES <= 65536, "16-bit sample numbers inside an item");
+	__shared__ __attribute__((aligned(16))) unsigned long long lds_raw[LISTS ? STAGE_U64 + 72 : (FP_THREADS / 64) * FP_SPT * FP_MAX_CHUNKS];
 	typedef unsigned long long plane_row[FP_SPT][FP_MAX_CHUNKS];
 	plane_row* planes = (plane_row*)lds_raw; // [FP_THREADS / 64][FP_SPT][FP_MAX_CHUNKS]
 	typedef __attribute__((address_space(3))) uint32_t lds_u32;
-	uint32_t* l_stage = (uint32_t*)lds_raw;                 // [STAGE_ELEMS] the item's elements in chunk order
-	uint32_t* l_cnt = (uint32_t*)(lds_raw + STAGE_ELEMS / 2); // [64] elements of this item per chunk (zero between items)
+	uint32_t* l_stage = (uint32_t*)lds_raw;                 // [STAGE_ELEMS][GRID_HIT_WORDS] the item's elements in chunk order
+	uint16_t* l_sidx = (uint16_t*)(lds_raw + STAGE_ELEMS * (int)GRID_HIT_WORDS / 2); // [STAGE_ELEMS] their samples, relative to the item's first
+	uint32_t* l_cnt = (uint32_t*)(lds_raw + STAGE_U64);     // [64] elements of this item per chunk (zero between items)
 	uint32_t* l_off = l_cnt + 64;                           // [64] first staged position of the chunk
 	uint32_t* l_total = l_cnt + 128;
 	static_assert(FP_MAX_CHUNKS == 64, "one lane per chunk");
@@ -59,7 +73,7 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 		if (threadIdx.x < 64) l_cnt[threadIdx.x] = 0;
 		// the counter set of the next forward launch on this stream (nobody reads it any more: the scatter that did has finished)
 		if (blockIdx.x == gridDim.x - 1 && lists.zero_counts) {
-			for (uint32_t e = threadIdx.x; e < meta->n_levels * GRID_HIT_COUNT_STRIDE; e += FP_THREADS) lists.zero_counts[e] = 0;
+			for (uint32_t e = threadIdx.x; e < meta->n_levels * GRID_HIT_COUNT_STRIDE; e += THREADS) lists.zero_counts[e] = 0;
 		}
 		__syncthreads();
 	}
@@ -93,7 +107,8 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 		const bool want_bits = !LISTS && bits != nullptr && n_chunks > 1 && n_chunks <= FP_MAX_CHUNKS;
 		const bool lds_or = want_bits && n_chunks > 8;
 		const bool want_lists = LISTS && n_chunks > 1 && n_chunks <= FP_MAX_CHUNKS; // workgroup-uniform: depends on the level only
-		uint32_t cr[FP_SPT][R_ROWS]; // per (sample, element): corner mask << 24 | chunk << 16 | rank inside (item, chunk); ~0: no element
+		uint32_t cr[FP_SPT][R_ROWS]; // per (sample, row): chunk << 16 | rank inside (item, chunk); ~0: no element
+		uint32_t ipair[FP_SPT][R_ROWS]; // ... and its word 1: entry of corner A | entry of corner B << 16, relative to the chunk (0xffff: none)
 		const bool nearest = interpolation == (uint32_t)InterpolationType::Nearest;
 
 		if (lds_or) {
@@ -136,7 +151,11 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 			for (int d = 0; d < D; ++d) cell[d] = pos_fract(xin[d], lv.scale, interpolation, &pos[k][d], &pd);
 			touched[k] = 0;
 			sel[k] = 0;
-			uint32_t ch_a[R], ch_b[R]; // LISTS: the chunks of row r's two corners
+			if constexpr (LISTS) {
+#pragma unroll
+				for (int r = 0; r < R_ROWS; ++r) { cr[k][r] = 0xffffffffu; ipair[k][r] = 0; }
+			}
+			const bool lists_here = LISTS && want_lists && base + k * 64 + lane < n;
 #pragma unroll
 			for (int r = 0; r < R; ++r) {
 				if (r > 0 && nearest) { P[k][r] = P[k][0]; E[k][r] = E[k][0]; continue; }
@@ -162,54 +181,25 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 					if (!nearest) note_chunk(k, idx1);
 				}
 				if constexpr (LISTS) {
-					if (want_lists) {
-						ch_a[r] = scatter_chunk(lv, idx0);
-						ch_b[r] = nearest ? ch_a[r] : scatter_chunk(lv, idx1);
-					}
-				}
-			}
-			if constexpr (LISTS) {
-				// One element per (sample, chunk) holding corners of the sample: row r's corner A opens an element unless an earlier row's
-				// chunk is the same (dense levels: both rows of a cell usually lie in one chunk -- one element, one record gather in the
-				// scatter); the B corners join the element of their chunk, or -- a row that straddles two chunks, one in ~8000 -- go to
-				// that chunk's list directly.
-#pragma unroll
-				for (int r = 0; r < R_ROWS; ++r) cr[k][r] = 0xffffffffu;
-				if (want_lists && base + k * 64 + lane < n) {
-					uint32_t pmask[R_ROWS];
-					bool used[R_ROWS];
-#pragma unroll
-					for (int r = 0; r < R_ROWS; ++r) {
-						used[r] = !(nearest && r > 0);
-						pmask[r] = 1u << (2 * r);
-#pragma unroll
-						for (int j = 0; j < r; ++j) {
-							if (used[r] && used[j] && ch_a[j] == ch_a[r]) { pmask[j] |= 1u << (2 * r); used[r] = false; }
-						}
-					}
-					if (!nearest) {
-#pragma unroll
-						for (int r = 0; r < R_ROWS; ++r) {
-							bool placed = false;
-#pragma unroll
-							for (int j = 0; j < R_ROWS; ++j) {
-								if (!placed && used[j] && ch_a[j] == ch_b[r]) { pmask[j] |= 2u << (2 * r); placed = true; }
-							}
-							if (!placed) { // the row straddles two chunks: corner B goes to the level's straggler list
+					// One element per (sample, row), in the list of corner A's chunk; corner B rides along when it lies in the same chunk -- else (a
+					// row that straddles two chunks, one in ~8000 on hashed levels) it goes to the level's straggler list.
+					if (lists_here) {
+						const uint32_t ch_a = scatter_chunk(lv, idx0), first = ch_a * lv.scatter_per_chunk;
+						uint32_t rel_b = idx0 - first; // no corner B in this chunk: the element names A's entry twice and gives the second a zero weight
+						if (!nearest) {
+							const uint32_t ch_b = scatter_chunk(lv, idx1);
+							if (ch_b == ch_a) rel_b = idx1 - first;
+							else {
 								const uint32_t at = atomicAdd(&lists.counts[level * GRID_HIT_COUNT_STRIDE], 1u);
 								if (at < lists.straggler_capacity) {
 									typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-									*(u2*)&lists.stragglers[((size_t)level * lists.straggler_capacity + at) * 2] = u2{i | (2u << (2 * r)) << HIT_SHIFT, ch_b[r]};
+									*(u2*)&lists.stragglers[((size_t)level * lists.straggler_capacity + at) * 2] = u2{i | (2u << (2 * r)) << HIT_SHIFT, ch_b};
 								}
 							}
 						}
-					}
-#pragma unroll
-					for (int r = 0; r < R_ROWS; ++r) {
-						if (used[r]) {
-							const uint32_t rank = __hip_atomic_fetch_add((lds_u32*)&l_cnt[ch_a[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-							cr[k][r] = pmask[r] << 24 | ch_a[r] << 16 | rank;
-						}
+						ipair[k][r] = (idx0 - first) | rel_b << 16;
+						const uint32_t rank = __hip_atomic_fetch_add((lds_u32*)&l_cnt[ch_a], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						cr[k][r] = ch_a << 16 | rank;
 					}
 				}
 			}
@@ -227,10 +217,14 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 						if (lane >= (uint32_t)o) incl += up;
 					}
 					l_off[lane] = incl - cnt;
-					uint32_t* heads = lists.heads + ((size_t)level * lists.n_items + (w & 0xffffffu)) * GRID_HIT_HEADS;
-					heads[lane] = incl - cnt;
-					if (lane == 63) { heads[64] = incl; *l_total = incl; }
+					uint32_t* heads = lists.heads + (size_t)level * GRID_HIT_HEADS * lists.n_items + (w & 0xffffffu); // [chunk][item]
+#ifdef TCNN_AMD_DEV
+					if (!(lists.dev_flags & 4u))
+#endif
+					heads[(size_t)lane * lists.n_items] = incl - cnt;
+					if (lane == 63) { heads[(size_t)64 * lists.n_items] = incl; *l_total = incl; }
 				}
+				__syncthreads(); // the chunks' offsets are there (the gathers of phase 1 are in flight meanwhile)
 			}
 		}
 
@@ -249,6 +243,9 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 				v[2 * r + 1] = (s & 4u) ? E[k][r] : ((s & 2u) ? hi : lo);
 			}
 			half_t acc[F];
+			half_t whs[C]; // the corners' weights as halves: what the scatter multiplies dL/dy with (grid.h:254)
+#pragma unroll
+			for (int idx = 0; idx < C; ++idx) whs[idx] = (half_t)1.0f;
 			if (nearest) { // grid.h:121-140
 #pragma unroll
 				for (int f = 0; f < F; ++f) acc[f] = v[0][f];
@@ -262,6 +259,7 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 					for (int d = 0; d < D; ++d) weight *= (idx & (1 << d)) == 0 ? 1 - pos[k][d] : pos[k][d];
 					asm volatile("" : "+v"(weight)); // round to fp32 first, then to fp16 (see k_grid.hip)
 					const half_t wh = (half_t)weight;
+					whs[idx] = wh;
 #pragma unroll
 					for (int f = 0; f < F; ++f) {
 						half_t val;
@@ -276,23 +274,41 @@ __global__ void __launch_bounds__(FP_THREADS) k_grid_fwd_planes(
 				for (int f = 0; f < F; ++f) { if constexpr (F == 1) o = acc[f]; else o[f] = acc[f]; }
 				*(vecF*)&lout[(size_t)i * F] = o;
 			}
+			if constexpr (LISTS) { // this sample's elements, staged at their place in chunk order
+				if (want_lists) {
+#pragma unroll
+					for (int r = 0; r < R_ROWS; ++r) {
+						const uint32_t v = cr[k][r];
+						if (v != 0xffffffffu) {
+							const uint32_t at = l_off[v >> 16] + (v & 0xffffu);
+							typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+							const uint32_t pr = ipair[k][r];
+							const bool no_b = (pr >> 16) == (pr & 0xffffu); // (two corners of a row are never the same entry)
+							*(u2*)(l_stage + at * GRID_HIT_WORDS) = u2{pr, (uint32_t)__builtin_bit_cast(uint16_t, whs[2 * r]) | (no_b ? 0u : (uint32_t)__builtin_bit_cast(uint16_t, whs[2 * r + 1]) << 16)};
+							l_sidx[at] = (uint16_t)(wave * FP_WAVE_SAMPLES + k * 64 + lane);
+						}
+					}
+				}
+			}
 		}
 
 		// ---- phase 3 (LISTS): the item's elements, staged in chunk order, leave as one run into the item's region of the level's pool
 		if constexpr (LISTS) {
 			if (want_lists) {
-				__syncthreads(); // the chunks' offsets are there
-#pragma unroll
-				for (int k = 0; k < FP_SPT; ++k)
-#pragma unroll
-					for (int r = 0; r < R_ROWS; ++r) {
-						const uint32_t v = cr[k][r];
-						if (v != 0xffffffffu) l_stage[l_off[(v >> 16) & 0xffu] + (v & 0xffffu)] = (base + k * 64 + lane) | (v >> 24) << HIT_SHIFT;
-					}
 				__syncthreads();
-				const uint32_t total = *l_total;
-				uint32_t* dst = lists.elems + ((size_t)level * lists.n_items + (w & 0xffffffu)) * lists.item_capacity;
-				for (uint32_t p = tid; p < total; p += FP_THREADS) dst[p] = l_stage[p];
+				typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+				// (a region is a whole number of 16-byte quads: the last one of a run may carry a few words of the item before)
+				const uint32_t total = *l_total, quads = (total * GRID_HIT_WORDS + 3) / 4, squads = (total + 7) / 8;
+				const size_t region = ((size_t)level * lists.n_items + (w & 0xffffffu)) * lists.item_capacity;
+				u4* dst = (u4*)(lists.elems + region * GRID_HIT_WORDS);
+				u4* sdst = (u4*)(lists.sidx + region);
+#ifdef TCNN_AMD_DEV
+				if (!(lists.dev_flags & 1u))
+#endif
+				{ // (plain stores: streamed ones cost the scatter 13 us -- it reads the lists out of the Infinity Cache, which streamed stores pass by)
+					for (uint32_t p = tid; p < quads; p += THREADS) dst[p] = ((const u4*)l_stage)[p];
+					for (uint32_t p = tid; p < squads; p += THREADS) sdst[p] = ((const u4*)l_sidx)[p];
+				}
 			}
 		}
 		// ---- phase 3: bit planes.  Lane c ends up with the FP_SPT consecutive words of chunk c (and of chunk c + 64): dense runs per lane.
@@ -338,7 +354,9 @@ void launch_planes(hipStream_t s, const GridMeta* dm, const uint32_t* work, uint
 	MlpPrepJob prep{};
 	if (prep_job) prep = *prep_job;
 	if (hit_lists) {
-		hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT, true>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
+		if constexpr (SPT == 8) throw std::runtime_error{"grid_forward_planes: hit lists come from the 2- and 4-samples-per-thread shapes"};
+		else
+		hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT, true>), dim3(8 * blocks_per_xcd), dim3(FP_LIST_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
 		                   nullptr, prep, *hit_lists);
 	} else {
 		hipLaunchKernelGGL((k_grid_fwd_planes<D, F, SPT, false>), dim3(8 * blocks_per_xcd), dim3(FP_THREADS), 0, s, dm, work, max_items, blocks_per_xcd, n, x, (const half_t*)grid, (half_t*)out,
@@ -355,7 +373,7 @@ uint32_t max_scatter_chunks(const GridMeta& meta) {
 
 } // namespace
 
-uint32_t grid_hit_item_samples(const GridMeta& meta) { return FP_THREADS * grid_planes_spt(meta); }
+uint32_t grid_hit_item_samples(const GridMeta& meta) { return FP_LIST_THREADS * grid_planes_spt(meta); }
 
 // samples per thread of the kernel shape used for this grid (see k_grid_fwd_planes)
 uint32_t grid_planes_spt(const GridMeta& meta) {
@@ -379,8 +397,9 @@ bool grid_planes_supported(const GridMeta& meta, uint32_t n) {
 // Work list: [0..7] = number of items of XCD x, then 8 runs of max_items entries (level << 24 | item index inside the level).
 // Levels are laid end to end in order and the sequence is cut into 8 runs of equal estimated cost, so every XCD gathers
 // from at most a few consecutive levels (usually two) and each table is pulled into at most two L2s.
-void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd) {
-	const uint32_t items_per_level = div_round_up(n, FP_THREADS * grid_planes_spt(meta));
+void grid_planes_plan(const GridMeta& meta, uint32_t n, bool hit_lists, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd) {
+	const uint32_t threads = hit_lists ? FP_LIST_THREADS : FP_THREADS;
+	const uint32_t items_per_level = div_round_up(n, threads * grid_planes_spt(meta));
 	// relative cost of one item: tables beyond a few hundred KB miss the per-CU cache on nearly every corner pair
 	float coarse_cost = 0.6f;
 #ifdef TCNN_AMD_DEV
@@ -443,8 +462,8 @@ void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& w
 		work[b] = (uint32_t)runs[b].size();
 		std::copy(runs[b].begin(), runs[b].end(), work.begin() + 8 + (size_t)b * max_items);
 	}
-	// 8 workgroups (16 waves) per CU on each XCD's 32 CUs, fewer when there is less work
-	blocks_per_xcd = std::max(1u, std::min(256u, max_items));
+	// 16 waves per CU on each XCD's 32 CUs (8 workgroups of 128 threads), fewer when there is less work
+	blocks_per_xcd = std::max(1u, std::min(256u * FP_THREADS / threads, max_items));
 #ifdef TCNN_AMD_DEV
 	if (const char* e = getenv("TCNN_AMD_FWD_BLOCKS_PER_XCD")) blocks_per_xcd = std::max(1, atoi(e)); // laboratory knob
 #endif
@@ -455,7 +474,7 @@ void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMet
 	CHECK_THROW(grid_planes_supported(meta, n));
 	CHECK_THROW(!hit_lists || (hit_lists->elems && hit_lists->heads && hit_lists->stragglers && hit_lists->counts && n <= grid_hit_max_samples(meta) &&
 	                           hit_lists->item_samples == grid_hit_item_samples(meta) && hit_lists->n_items == div_round_up(n, hit_lists->item_samples) &&
-	                           hit_lists->item_capacity >= (hit_lists->item_samples << (meta.n_pos_dims - 1))));
+	                           hit_lists->sidx && hit_lists->item_capacity >= (hit_lists->item_samples << (meta.n_pos_dims - 1)) && hit_lists->item_capacity % 8 == 0));
 	const uint32_t F = meta.n_features_per_level;
 #define TCNN_PLANES_F(D, SPT) \
 	switch (F) { \

@@ -8,8 +8,13 @@
 // random ds_add_u64.  This kernel changes the three things those numbers name:
 //   * hits arrive as a stream: the forward kernel (k_grid_planes.hip) appends one element per (sample, cell row) to the list of the chunk
 //     the row's corners fall into (GridHitLists, tcnn_common.h).  The owner reads its list front to back with coalesced loads -- no scan,
-//     no compaction queue -- and an element says which corners of the sample's cell are meant, so the owner hashes the rows named and
-//     tests nothing (the filter form located all 2^D corners of a sample and tested each against the chunk);
+//     no compaction queue.  Round 5: an element carries the row's two entries (relative to the chunk) and its two half weights, and the
+//     gradient arrives as a stream too: k_grid_list_gradients (below, the launch in front of the owners') copies dL/dy into list order --
+//     per item it loads the item's 2 KB slice of the level's gradient plane into LDS and writes every element's F halves at the
+//     element's position -- so the owner reads elements and gradients side by side with dense loads: no gather, no coordinates, no
+//     pos_fract, no hash.  (Round 4's owner gathered a 16-byte record per element: every such gather pulls a 128-byte line from the L2
+//     into the CU, ~3 clocks per lane whatever it carries -- 40 us of the kernel's 59 - 66, and only while the record plane was resident
+//     in the XCD's L2, i.e. for batches of 2^17 .. 2^19 samples.  profiles/r05_scatter_timeline.txt);
 //   * both features of an entry travel in ONE ds_add_u64 as 2 x int32 (low half sign-extended into the high one; decoded as
 //     lo = (int32) s, hi = (s - lo) >> 32): half the LDS atomics and half the LDS footprint.  Exactness is not given up: each task sums
 //     |product| over everything it adds; while that sum stays below 2^31 fixed-point units (|value| < 128) no half of any entry can have
@@ -53,50 +58,34 @@ constexpr float SL_PACKED_BOUND = 120.0f;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) float lds_f32; // (explicit: a generic pointer to LDS selected against a global one does not compile on gfx950)
 
-template <int D, int F, bool REC>
+template <int D, int F>
 struct ScatterCtx {
 	typedef typename VecOf<half_t, F>::type vecF;
 	GridLevel lv;
 	uint32_t primes[D];
 	uint32_t hash_type, interpolation;
 	uint32_t level, n;
-	const uint4* recs;          // REC: record plane of this level (pair)
-	MatView x;                  // !REC
-	const half_t* dy;           // !REC: dL_dy + level * dy_stride_level
+	MatView x;
+	const half_t* dy;           // dL_dy + level * dy_stride_level
 	uint32_t dy_stride_sample;
 };
 
-template <int D, int F, bool REC>
-__device__ inline void sl_fetch(const ScatterCtx<D, F, REC>& c, const uint32_t i, float (&xin)[D], typename ScatterCtx<D, F, REC>::vecF& gv) {
-	typedef typename ScatterCtx<D, F, REC>::vecF vecF;
-	constexpr bool PAIRED = REC && D == 2 && F == 2;
-	if constexpr (REC) {
-		const uint4 r = c.recs[i];
-		const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-		for (int d = 0; d < D; ++d) xin[d] = __builtin_bit_cast(float, w[d]);
-		if constexpr (PAIRED) {
-			gv = __builtin_bit_cast(vecF, (c.level & 1u) ? w[3] : w[2]);
-		} else if constexpr (F == 2) {
-			gv = __builtin_bit_cast(vecF, w[D]);
-		} else {
-			typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-			gv = __builtin_bit_cast(vecF, (u2{w[2], w[3]}));
-		}
-	} else {
-		load_coords<D>(c.x, i, xin);
-		gv = *(const vecF*)&c.dy[(size_t)i * c.dy_stride_sample];
-	}
+// coordinates and dL/dy of one sample: the levels that are one chunk (streamed in sample order) and the stragglers
+template <int D, int F>
+__device__ inline void sl_fetch(const ScatterCtx<D, F>& c, const uint32_t i, float (&xin)[D], typename ScatterCtx<D, F>::vecF& gv) {
+	typedef typename ScatterCtx<D, F>::vecF vecF;
+	load_coords<D>(c.x, i, xin);
+	gv = *(const vecF*)&c.dy[(size_t)i * c.dy_stride_sample];
 }
 
-// The cell of one sample: positions and weights' factors, once per element (grid.h:147-160, common_device.h:856-868)
+// The cell of one sample: positions and weights' factors, once per sample (grid.h:147-160, common_device.h:856-868)
 template <int D>
 struct CellPos {
 	uint32_t cell[D];
 	float pos[D];
 };
-template <int D, int F, bool REC>
-__device__ inline CellPos<D> sl_cell(const ScatterCtx<D, F, REC>& c, const float (&xin)[D]) {
+template <int D, int F>
+__device__ inline CellPos<D> sl_cell(const ScatterCtx<D, F>& c, const float (&xin)[D]) {
 	CellPos<D> p;
 	float unused;
 #pragma unroll
@@ -104,10 +93,66 @@ __device__ inline CellPos<D> sl_cell(const ScatterCtx<D, F, REC>& c, const float
 	return p;
 }
 
-// One cell row of one sample: corners A (cell_0) and B (cell_0 + 1) of row `row` (bit d - 1: cell_d + 1; per lane), each added if its flag
-// is set and its entry lies in [e0, e0 + n_sub).  PACKED: accumulators are uint64 [entry][F / 2] holding two int32 sums; else int64 [entry][F].
-template <int D, int F, bool REC, bool PACKED>
-__device__ inline void sl_add_row(const ScatterCtx<D, F, REC>& c, lds_u64* acc, const uint32_t e0, const uint32_t n_sub, const CellPos<D>& p, const typename ScatterCtx<D, F, REC>::vecF& gv,
+// One contribution: (GRAD_T) weight * grad in fp16 (grid.h:254), all F features, into entry `index` of the accumulators.
+// PACKED: accumulators are uint64 [entry][F / 2] holding two int32 sums; else int64 [entry][F].
+template <int F, bool PACKED, typename vecF>
+__device__ inline void sl_add_entry(lds_u64* acc, const uint32_t index, const half_t w, const vecF& gv, float& bound) {
+	if constexpr (PACKED) {
+#pragma unroll
+		for (int j = 0; j < F / 2; ++j) {
+			const float p0 = (float)(half_t)(w * gv[2 * j]), p1 = (float)(half_t)(w * gv[2 * j + 1]);
+			bound += __builtin_fabsf(p0);
+			bound += __builtin_fabsf(p1);
+			const int f0 = (int)(p0 * 16777216.0f), f1 = (int)(p1 * 16777216.0f); // exact below 128; beyond it the bound has failed anyway
+			const uint32_t lo = (uint32_t)f0, hi = (uint32_t)(f1 + (f0 >> 31));     // f0 + f1 2^32 as one 64-bit integer
+			__hip_atomic_fetch_add(acc + index * (F / 2) + j, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	} else {
+#pragma unroll
+		for (int f = 0; f < F; ++f) {
+			const half_t pr = w * gv[f];
+			__hip_atomic_fetch_add(acc + index * F + f, (unsigned long long)half_to_fixed_fast(pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+}
+
+// Both corners of a listed element into packed accumulators, all F features: the same products and the same integers as sl_add_entry's,
+// in half the vector instructions -- the owners are bound by their vector instructions once nothing gathers (5 - 6 us of a task's 8 with
+// every load and LDS add taken out, profiles/r05_scatter_dev.txt) --: the two features of a pair in one packed multiply (weight A is the
+// low half of `weights`, weight B the high one), half -> scaled float in one v_fma_mix_f32 (exact: a half times 2^24), and the task's
+// bound from the ELEMENT: weight A + weight B <= 1.0005, so |g| bounds the two products' sum -- two instructions per pair instead of
+// four.  No test per corner: an element without a corner B names A's entry twice, the second time with weight +0 (GridHitLists).
+template <int F, typename vecF>
+__device__ inline void sl_add_element_packed(lds_u64* acc, const uint32_t entries, const uint32_t weights, const vecF& gv, float& bound) {
+	typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+	const float two24 = 16777216.0f;
+	lds_u64* pa = (lds_u64*)((__attribute__((address_space(3))) char*)acc + (entries & 0xffffu) * (F * 4u));
+	lds_u64* pb = (lds_u64*)((__attribute__((address_space(3))) char*)acc + (entries >> 16) * (F * 4u));
+#pragma unroll
+	for (int j = 0; j < F / 2; ++j) {
+		const uint32_t g2 = __builtin_bit_cast(uint32_t, (h2{gv[2 * j], gv[2 * j + 1]}));
+		uint32_t qa, qb;
+		asm("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(qa) : "v"(g2), "v"(weights));               // (GRAD_T) weight * grad in fp16, grid.h:254
+		asm("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(qb) : "v"(g2), "v"(weights));
+		asm("v_fma_mix_f32 %0, |%1|, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(bound) : "v"(g2));
+		asm("v_fma_mix_f32 %0, |%1|, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(bound) : "v"(g2));
+		auto add = [&](lds_u64* at, const uint32_t q) {
+			float s0, s1;
+			asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(s0) : "v"(q), "v"(two24));
+			asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(s1) : "v"(q), "v"(two24));
+			const int f0 = (int)s0, f1 = (int)s1;                                 // exact below 128; beyond it the bound has failed anyway
+			const uint32_t lo = (uint32_t)f0, hi = (uint32_t)(f1 + (f0 >> 31));   // f0 + f1 2^32 as one 64-bit integer
+			__hip_atomic_fetch_add(at + j, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		};
+		add(pa, qa);
+		add(pb, qb);
+	}
+}
+
+// One cell row of one sample from its coordinates: corners A (cell_0) and B (cell_0 + 1) of row `row` (bit d - 1: cell_d + 1; per lane), each
+// added if its flag is set and its entry lies in [e0, e0 + n_sub).  The streamed levels and the stragglers; listed elements bring entries and weights along.
+template <int D, int F, bool PACKED>
+__device__ inline void sl_add_row(const ScatterCtx<D, F>& c, lds_u64* acc, const uint32_t e0, const uint32_t n_sub, const CellPos<D>& p, const typename ScatterCtx<D, F>::vecF& gv,
                                   const uint32_t row, const bool want_a, const bool want_b, float& bound) {
 	const bool nearest = c.interpolation == (uint32_t)InterpolationType::Nearest;
 	uint32_t local[D];
@@ -125,65 +170,26 @@ __device__ inline void sl_add_row(const ScatterCtx<D, F, REC>& c, lds_u64* acc, 
 	local[0] += 1;
 	const uint32_t ib = level_index<D, false>(c.lv, c.primes, c.hash_type, local) - e0;
 	asm volatile("" : "+v"(wa), "+v"(wb)); // keep the fp32 rounding of the weight products (see k_grid_fwd)
-	auto add = [&](const uint32_t index, const float weight) {
-		const half_t w = (half_t)weight;
-		if constexpr (PACKED) {
-#pragma unroll
-			for (int j = 0; j < F / 2; ++j) {
-				const float p0 = (float)(half_t)(w * gv[2 * j]), p1 = (float)(half_t)(w * gv[2 * j + 1]); // (GRAD_T)weight * grad in fp16, grid.h:254
-				bound += __builtin_fabsf(p0);
-				bound += __builtin_fabsf(p1);
-				const int f0 = (int)(p0 * 16777216.0f), f1 = (int)(p1 * 16777216.0f); // exact below 128; beyond it the bound has failed anyway
-				const uint32_t lo = (uint32_t)f0, hi = (uint32_t)(f1 + (f0 >> 31));     // f0 + f1 2^32 as one 64-bit integer
-				__hip_atomic_fetch_add(acc + index * (F / 2) + j, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-		} else {
-#pragma unroll
-			for (int f = 0; f < F; ++f) {
-				const half_t pr = w * gv[f];
-				__hip_atomic_fetch_add(acc + index * F + f, (unsigned long long)half_to_fixed_fast(pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-		}
-	};
-	if (want_a && ia < n_sub) add(ia, wa);
-	if (want_b && ib < n_sub) add(ib, wb);
-}
-
-// All corners of an element's mask: the rows named in it, the lowest first, each lane its own.  Two rounds without a loop (around a loop the
-// register allocator splits the live ranges of the records still in flight, and every copy of such a register is a wait for its load): a
-// hashed level's element holds one row (the rows of a cell fall into different chunks), so the second round -- both rows of a cell in
-// this chunk: dense levels -- is skipped by the whole wave; 3-D cells have four rows and take two more.
-template <int D, int F, bool REC, bool PACKED>
-__device__ inline void sl_add_masked(const ScatterCtx<D, F, REC>& c, lds_u64* acc, const uint32_t e0, const uint32_t n_sub, const float (&xin)[D], const typename ScatterCtx<D, F, REC>::vecF& gv,
-                                     uint32_t m, float& bound) {
-	constexpr int R = 1 << (D - 1);
-	const CellPos<D> p = sl_cell<D, F, REC>(c, xin);
-#pragma unroll
-	for (int round = 0; round < R; ++round) {
-		if (round > 0 && __builtin_amdgcn_ballot_w64(m != 0) == 0) break; // (unrolled: a forward branch)
-		if (m != 0) {
-			const uint32_t row = (uint32_t)__builtin_ctz(m) >> 1;
-			const uint32_t two = (m >> (2 * row)) & 3u;
-			m &= ~(3u << (2 * row));
-			sl_add_row<D, F, REC, PACKED>(c, acc, e0, n_sub, p, gv, row, (two & 1u) != 0, (two & 2u) != 0, bound);
-		}
-	}
+	if (want_a && ia < n_sub) sl_add_entry<F, PACKED>(acc, ia, (half_t)wa, gv, bound);
+	if (want_b && ib < n_sub) sl_add_entry<F, PACKED>(acc, ib, (half_t)wb, gv, bound);
 }
 
 // Where a listed task's elements are: the items' runs of its chunk (GridHitLists, tcnn_common.h)
 struct ScatterRuns {
-	const uint32_t* elems;      // this level's pool: [n_items][item_capacity]
-	const uint32_t* heads;      // this level's offsets: [n_items][GRID_HIT_HEADS], already advanced to the task's chunk
-	const uint32_t* stragglers; // this level's {element, chunk} pairs
+	uint32_t dev_flags;         // laboratory build (TCNN_AMD_SCATTER_DEV): 1 linear element addresses, 2 no LDS adds, 4 no element / gradient loads (timing only: wrong results)
+	const uint32_t* elems;      // this level's pool: [n_items][item_capacity][GRID_HIT_WORDS]
+	const half_t* gvals;        // dL/dy of the elements' samples, same positions: [n_items][item_capacity][F]
+	const uint32_t* heads;      // this level's offsets, already advanced to the task's chunk: heads[item] = where the run starts, heads[n_items + item] = where it ends
+	const uint32_t* stragglers; // this level's {sample | corner bit, chunk} pairs
 	uint32_t n_stragglers, n_items, item_capacity, chunk;
 };
 
 // The accumulation pass of one task: over the runs of its chunk in the items [begin, end) of a level cut into chunks, or over the samples
-// [begin, end) of a level that is one chunk.
-template <int D, int F, bool REC, bool PACKED>
-__device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, const uint32_t e0, const uint32_t n_sub, const bool listed, const ScatterRuns& runs, const bool with_stragglers,
-                                const uint32_t begin, const uint32_t end, const uint32_t wave, const uint32_t lane, char* wave_lds, const uint32_t first_h0, const uint32_t first_h1) {
-	typedef typename ScatterCtx<D, F, REC>::vecF vecF;
+// [begin, end) of a level that is one chunk.  Entries [e0, e0 + n_sub) of the level are this pass's (the whole chunk, or a part of it in the 64-bit passes).
+template <int D, int F, bool PACKED>
+__device__ inline float sl_pass(const ScatterCtx<D, F>& c, lds_u64* acc, const uint32_t e0, const uint32_t n_sub, const bool listed, const ScatterRuns& runs, const bool with_stragglers,
+                                const uint32_t begin, const uint32_t end, const uint32_t wave, const uint32_t lane, char* wave_lds, const uint32_t first_h0, const uint32_t first_h1, const uint32_t group) {
+	typedef typename ScatterCtx<D, F>::vecF vecF;
 	float bound = 0;
 	const bool nearest = c.interpolation == (uint32_t)InterpolationType::Nearest;
 	constexpr uint32_t R = 1u << (D - 1);
@@ -198,16 +204,16 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 		vecF pg, qg;
 		bool p_valid = false;
 		auto whole = [&](const float (&xin)[D], const vecF& gv) {
-			const CellPos<D> p = sl_cell<D, F, REC>(c, xin);
+			const CellPos<D> p = sl_cell<D, F>(c, xin);
 #pragma unroll
 			for (uint32_t row = 0; row < R; ++row) {
 				if (row > 0 && nearest) break; // grid.h:232-246: the cell's own entry, weight 1
-				sl_add_row<D, F, REC, PACKED>(c, acc, e0, n_sub, p, gv, row, true, !nearest, bound);
+				sl_add_row<D, F, PACKED>(c, acc, e0, n_sub, p, gv, row, true, !nearest, bound);
 			}
 		};
 		for (uint32_t i0 = w_begin; i0 < w_end; i0 += 64) {
 			const uint32_t i = i0 + lane;
-			sl_fetch<D, F, REC>(c, min(i, w_end - 1), qx, qg);
+			sl_fetch<D, F>(c, min(i, w_end - 1), qx, qg);
 			if (p_valid) whole(px, pg);
 #pragma unroll
 			for (int d = 0; d < D; ++d) px[d] = qx[d];
@@ -217,36 +223,40 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 		if (p_valid) whole(px, pg);
 		return bound;
 	}
-	// Listed.  A wave takes 64 items at a time, one per lane: the lane reads where its item's run of this chunk starts and ends, a scan
+	// Listed.  A wave takes `group` items at a time (64, or fewer where the task has fewer than 64 items per wave), one per lane: the lane reads where its item's run of this chunk starts and ends, a scan
 	// over the lanes numbers the runs' elements 0 .. T - 1, and every lane writes its own number into a wave-private byte table at its
 	// elements' positions (~16 each) -- element e is then TWO LDS reads away: table[e] names the lane, positions[lane] where its run
 	// lies.  (First form: a 6-step search over the lanes' running totals with ds_bpermute per element -- 7 cross-lane reads and ~20 vector
 	// instructions per 64 elements, and the kernel is bound by its vector instructions: 28 us per task against 21 with plain lists.)
 	//
-	// Then a software pipeline over batches of 64 SL_SB elements, NS = SL_LEAD + 2 register sets that rotate STATICALLY (the loop is
-	// unrolled NS times; a set is never copied -- a move of a register whose load is still in flight is a wait for it): per step the
-	// elements of batch j + LEAD + 1 are requested, the records of batch j + LEAD gathered by the elements that have arrived, and batch j
-	// is added.  Loads return in order, so the compiler's counted waits leave everything younger in flight.  All loads are raw buffer
-	// loads without a branch around them: a lane past the last element reads from beyond the descriptor's range (-> zero: no corner
-	// wanted), and an element without corners gathers from beyond the record plane (-> zeros, nothing requested).  (With `if (element)
-	// load` the compiler waited with vmcnt(0) right behind every gather -- the loaded value has to be merged with the default at the end
-	// of the branch -- and nothing was ever in flight.)
-	constexpr int NS = SL_LEAD + 2;
+	// Then a software pipeline over steps of 64 SL_SB elements in FOUR stages, each working on what the stage before asked for a step
+	// earlier, so that nothing waits for what it has just requested: (A) the owner bytes of step j + LEAD + 2, (B) with those the runs'
+	// positions of step j + LEAD + 1, (C) with those the loads of step j + LEAD -- 8 + 2 F bytes per element, elements and gradients at the
+	// same position, dense along a run --, (D) step j is added.  NS = LEAD + 3 register sets rotate STATICALLY (the loop is unrolled NS
+	// times; a set is never copied -- a move of a register whose load is still in flight is a wait for it).  LDS operations and loads each
+	// return in order, so the compiler's counted waits leave everything younger in flight.  All loads are raw buffer loads without a
+	// branch around them: a lane past the last element reads from beyond the descriptor's range (no memory access, zeros) and adds
+	// nothing.  (With `if (element) load` the compiler waited with vmcnt(0) right behind every load -- the loaded value has to be merged
+	// with the default at the end of the branch -- and nothing was ever in flight.  Round 5's first form looked the position up right in
+	// front of the loads: two dependent LDS reads queued behind the step's LDS adds, 7 of a task's 17 us.)
+	constexpr int NS = SL_LEAD + 3;
 	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-	const auto rs_pool = __builtin_amdgcn_make_buffer_rsrc((void*)runs.elems, 0, (int)(runs.n_items * runs.item_capacity * 4u), 0x00020000);
-	const auto rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)c.recs, 0, (int)(c.n * 16u), 0x00020000);
+	constexpr uint32_t OOB = 0xffffffe0u; // beyond every descriptor below (their sizes are below 2^31: grid_backward_lists checks)
+	const auto rs_pool = __builtin_amdgcn_make_buffer_rsrc((void*)runs.elems, 0, (int)(runs.n_items * runs.item_capacity * (GRID_HIT_WORDS * 4u)), 0x00020000);
+	const auto rs_gv = __builtin_amdgcn_make_buffer_rsrc((void*)runs.gvals, 0, (int)(runs.n_items * runs.item_capacity * (F * 2u)), 0x00020000);
+	const uint32_t rel0 = e0 - runs.chunk * c.lv.scatter_per_chunk; // the elements' entries are relative to the chunk's first one (the packed pass owns the whole chunk: 0)
 	constexpr uint32_t BATCH = 64 * SL_SB;
-	const uint32_t n_groups = (end - begin + 63) / 64;
+	const uint32_t n_groups = (end - begin + group - 1) / group;
 	for (uint32_t g = wave; g < n_groups; g += SL_WAVES) { // wave-uniform
-		const uint32_t item0 = begin + g * 64, item = item0 + lane;
+		const uint32_t item0 = begin + g * group, item = item0 + lane;
 		uint32_t h0 = first_h0, h1 = first_h1; // the wave's first group: requested when the task began, under the zeroing of the accumulators
 		if (g != wave) {
-			const uint32_t* hd = runs.heads + (size_t)min(item, end - 1) * GRID_HIT_HEADS;
+			const uint32_t* hd = runs.heads + min(item, end - 1);
 			h0 = hd[0];
-			h1 = hd[1];
+			h1 = hd[runs.n_items];
 		}
-		const uint32_t cnt = item < end ? h1 - h0 : 0u;
+		const uint32_t cnt = (lane < group && item < end) ? h1 - h0 : 0u;
 		uint32_t incl = cnt;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
@@ -260,58 +270,73 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 		for (uint32_t w0 = 0; w0 < total; w0 += SL_WINDOW) { // (one window unless the runs are far longer than the ~16 elements of a uniform batch)
 		const uint32_t w1 = min(total, w0 + SL_WINDOW);
 		for (uint32_t j = max(incl - cnt, w0); j < min(incl, w1); ++j) owner[j - w0] = (uint8_t)lane;
-		uint32_t el[NS][SL_SB];
-		u32x4 rec[NS][SL_SB];    // REC: the record
-		float xs[NS][SL_SB][D];  // else: coordinates and gradient by loads of their own (an element without corners reads sample 0's)
+		uint32_t ob[NS][SL_SB], ps[NS][SL_SB];
+		u32x2 el[NS][SL_SB];
 		vecF gs[NS][SL_SB];
-		auto load_elems = [&](const int set, const uint32_t b0) {
+		auto stage_a = [&](const int set, const uint32_t b0) {
+#pragma unroll
+			for (int s = 0; s < SL_SB; ++s) {
+				const uint32_t e = b0 + s * 64 + lane;
+				ob[set][s] = owner[e < w1 ? e - w0 : 0u];
+			}
+		};
+		auto stage_b = [&](const int set, const uint32_t b0) {
+#pragma unroll
+			for (int s = 0; s < SL_SB; ++s) ps[set][s] = run_pos[ob[set][s]] + (b0 + s * 64 + lane);
+		};
+		auto stage_c = [&](const int set, const uint32_t b0) {
 #pragma unroll
 			for (int s = 0; s < SL_SB; ++s) {
 				const uint32_t e = b0 + s * 64 + lane;
 				const bool have = e < w1;
-				const uint32_t at = run_pos[owner[have ? e - w0 : 0u]] + e;
-				el[set][s] = __builtin_amdgcn_raw_buffer_load_b32(rs_pool, have ? at * 4u : 0xfffffffcu, 0, 0);
+				uint32_t at = ps[set][s];
+#ifdef TCNN_AMD_DEV
+				if (runs.dev_flags & 1u) at = item0 * runs.item_capacity + e;
+				if (runs.dev_flags & 8u) at = item0 * runs.item_capacity + e + (at >> 30);
+				if (runs.dev_flags & 4u) { el[set][s] = u32x2{(e * 2654435761u >> 19) | (e * 40503u >> 3) << 16, 0x38003800u}; for (int f = 0; f < F; ++f) gs[set][s][f] = (half_t)0.00390625f; continue; }
+#endif
+				el[set][s] = __builtin_amdgcn_raw_buffer_load_b64(rs_pool, have ? at * (GRID_HIT_WORDS * 4u) : OOB, 0, 0);
+				const uint32_t goff = have ? at * (F * 2u) : OOB;
+				if constexpr (F == 2) gs[set][s] = __builtin_bit_cast(vecF, __builtin_amdgcn_raw_buffer_load_b32(rs_gv, goff, 0, 0));
+				else if constexpr (F == 4) gs[set][s] = __builtin_bit_cast(vecF, __builtin_amdgcn_raw_buffer_load_b64(rs_gv, goff, 0, 0));
+				else gs[set][s] = __builtin_bit_cast(vecF, __builtin_amdgcn_raw_buffer_load_b128(rs_gv, goff, 0, 0));
 			}
 		};
-		auto gather = [&](const int set) {
+		auto stage_d = [&](const int set, const uint32_t b0) {
 #pragma unroll
 			for (int s = 0; s < SL_SB; ++s) {
-				const uint32_t e = el[set][s];
-				if constexpr (REC) rec[set][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (e >> HIT_SHIFT) ? (e & HIT_ID_MASK) * 16u : 0xfffffff0u, 0, 0);
-				else sl_fetch<D, F, REC>(c, (e >> HIT_SHIFT) ? (e & HIT_ID_MASK) : 0u, xs[set][s], gs[set][s]);
-			}
-		};
-		auto accumulate = [&](const int set) {
-#pragma unroll
-			for (int s = 0; s < SL_SB; ++s) {
-				float xin[D];
-				vecF gv;
-				if constexpr (REC) {
-					const u32x4 rv = rec[set][s];
-					const uint32_t r[4] = {rv.x, rv.y, rv.z, rv.w}; // (never r[d] on the vector itself with a loop variable: the compiler read r[0] for every d)
-#pragma unroll
-					for (int d = 0; d < D; ++d) xin[d] = __builtin_bit_cast(float, r[d]);
-					constexpr bool PAIRED = D == 2 && F == 2;
-					if constexpr (PAIRED) gv = __builtin_bit_cast(vecF, (c.level & 1u) ? r[3] : r[2]);
-					else if constexpr (F == 2) gv = __builtin_bit_cast(vecF, r[D]);
-					else gv = __builtin_bit_cast(vecF, (u32x2{r[2], r[3]}));
+				const u32x2 ev = el[set][s];
+				uint32_t word0 = ev.x;
+				const uint32_t word1 = ev.y; // (never ev[i] with a loop variable inside a bit_cast: the compiler read element 0 for every i)
+				const bool have = b0 + s * 64 + lane < w1;
+#ifdef TCNN_AMD_DEV
+				if (runs.dev_flags & 2u) { bound += (float)(word0) * (float)word1 * (float)gs[set][s][0]; continue; }
+#endif
+				if constexpr (PACKED) {
+					// no branch: a lane without an element has loaded zeros -- weights +0, gradient +0 -- and adds them to an entry of its own
+					// (entry `lane`: every chunk has more than 64 entries) instead of all such lanes queueing at entry 0
+					word0 = have ? word0 : lane * 0x10001u;
+					sl_add_element_packed<F>(acc, word0, word1, gs[set][s], bound);
 				} else {
-#pragma unroll
-					for (int d = 0; d < D; ++d) xin[d] = xs[set][s][d];
-					gv = gs[set][s];
+					const uint32_t ia = (word0 & 0xffffu) - rel0, ib = (word0 >> 16) - rel0;
+					const half_t wa = __builtin_bit_cast(half_t, (uint16_t)word1), wb = __builtin_bit_cast(half_t, (uint16_t)(word1 >> 16));
+					if (have && ia < n_sub) sl_add_entry<F, false>(acc, ia, wa, gs[set][s], bound);
+					if (have && ib < n_sub) sl_add_entry<F, false>(acc, ib, wb, gs[set][s], bound);
 				}
-				sl_add_masked<D, F, REC, PACKED>(c, acc, e0, n_sub, xin, gv, el[set][s] >> HIT_SHIFT, bound);
 			}
 		};
+		// fill: A for steps 0 .. LEAD + 1, B for 0 .. LEAD, C for 0 .. LEAD - 1
 #pragma unroll
-		for (int b = 0; b <= SL_LEAD; ++b) load_elems(b, w0 + b * BATCH);
+		for (int b = 0; b < SL_LEAD + 2; ++b) stage_a(b, w0 + b * BATCH);
 #pragma unroll
-		for (int b = 0; b < SL_LEAD; ++b) gather(b);
+		for (int b = 0; b < SL_LEAD + 1; ++b) stage_b(b, w0 + b * BATCH);
+#pragma unroll
+		for (int b = 0; b < SL_LEAD; ++b) stage_c(b, w0 + b * BATCH);
 		const uint32_t quarter = max((w1 - w0) / 4u, 1u);
 		for (uint32_t b0 = w0; b0 < w1; b0 += NS * BATCH) {
 			// The two workgroups of a CU share its address path, and the arbiter serves the older wave first: left alone the older workgroup
-			// runs as if it had the CU to itself (a task in 14 us) and the younger one takes the rest (30 us).  Priority by progress
-			// instead: whoever is further from the end of its run goes first.
+			// runs as if it had the CU to itself and the younger one takes the rest.  Priority by progress instead: whoever is further from
+			// the end of its run goes first.
 			{
 				const uint32_t done = (b0 - w0) / quarter; // wave-uniform
 				if (done == 0) __builtin_amdgcn_s_setprio(3);
@@ -320,10 +345,12 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 				else __builtin_amdgcn_s_setprio(0);
 			}
 #pragma unroll
-			for (int u = 0; u < NS; ++u) { // batch j = (b0 - w0) / BATCH + u lives in set u (j is a multiple of NS at u = 0)
-				load_elems((u + SL_LEAD + 1) % NS, b0 + (u + SL_LEAD + 1) * BATCH);
-				gather((u + SL_LEAD) % NS);
-				accumulate(u);
+			for (int u = 0; u < NS; ++u) { // step j = (b0 - w0) / BATCH + u lives in set u (j is a multiple of NS at u = 0)
+				if (b0 + u * BATCH >= w1) break; // wave-uniform
+				stage_a((u + SL_LEAD + 2) % NS, b0 + (u + SL_LEAD + 2) * BATCH);
+				stage_b((u + SL_LEAD + 1) % NS, b0 + (u + SL_LEAD + 1) * BATCH);
+				stage_c((u + SL_LEAD) % NS, b0 + (u + SL_LEAD) * BATCH);
+				stage_d(u, b0 + u * BATCH);
 			}
 		}
 		__builtin_amdgcn_s_setprio(0);
@@ -336,19 +363,88 @@ __device__ inline float sl_pass(const ScatterCtx<D, F, REC>& c, lds_u64* acc, co
 			if (ch == runs.chunk) {
 				float xin[D];
 				vecF gv;
-				sl_fetch<D, F, REC>(c, e & HIT_ID_MASK, xin, gv);
-				const CellPos<D> cp = sl_cell<D, F, REC>(c, xin);
+				sl_fetch<D, F>(c, e & HIT_ID_MASK, xin, gv);
+				const CellPos<D> cp = sl_cell<D, F>(c, xin);
 				uint32_t m = e >> HIT_SHIFT;
 				while (m != 0) {
 					const uint32_t row = (uint32_t)__builtin_ctz(m) >> 1;
 					const uint32_t two = (m >> (2 * row)) & 3u;
 					m &= ~(3u << (2 * row));
-					sl_add_row<D, F, REC, PACKED>(c, acc, e0, n_sub, cp, gv, row, (two & 1u) != 0, (two & 2u) != 0, bound);
+					sl_add_row<D, F, PACKED>(c, acc, e0, n_sub, cp, gv, row, (two & 1u) != 0, (two & 2u) != 0, bound);
 				}
 			}
 		}
 	}
 	return bound;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dL/dy into list order
+// One workgroup per (item, level) of a listed level: the item's slice of the level's gradient plane (item_samples x F halves: 2 KB) goes
+// into LDS with dense loads, then every element of the item -- all chunks' runs, front to back -- takes its sample's F halves from there
+// and stores them at the element's own position in `gvals`.  Dense loads, dense stores, 2 + 2 F bytes in and 2 F bytes out per element; what
+// the owners' gathers cost (a 128-byte line from the L2 per element) is paid here once per 32 samples instead.
+constexpr uint32_t LG_THREADS = 256;
+struct ListGradArgs {
+	const GridMeta* meta;
+	GridHitLists lists;
+	const half_t* dL_dy;
+	uint32_t dy_stride_sample, dy_stride_level, n;
+	half_t* gvals; // [n_levels][n_items][item_capacity][F]
+};
+
+template <int F>
+__global__ void __launch_bounds__(LG_THREADS) k_grid_list_gradients(const ListGradArgs a) {
+	typedef typename VecOf<half_t, F>::type vecF;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const uint32_t level = blockIdx.y, item = blockIdx.x;
+	const uint32_t n_chunks = a.meta->levels[level].scatter_n_chunks;
+	if (n_chunks <= 1 || n_chunks > GRID_FILTER_MAX_CHUNKS || a.meta->levels[level].scatter_binned) return; // (workgroup-uniform) not a listed level
+	const GridHitLists& hl = a.lists;
+	vecF* g = (vecF*)smem;
+	const uint32_t first = item * hl.item_samples;
+	const half_t* dy = a.dL_dy + (size_t)level * a.dy_stride_level;
+	const uint32_t total = hl.heads[((size_t)level * GRID_HIT_HEADS + GRID_FILTER_MAX_CHUNKS) * hl.n_items + item];
+	const size_t region = ((size_t)level * hl.n_items + item) * hl.item_capacity;
+	const uint16_t* sidx = hl.sidx + region;
+	// Everything this workgroup reads is requested before anything is waited for: the item's sample numbers, four elements per thread and
+	// step (one 8-byte load; the forward kernel wrote whole quads of them -- what lies beyond the item's last element is stale but readable:
+	// clamped, and stored into positions nobody reads), then the item's slice of the gradient plane on its way into LDS.
+	typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+	constexpr uint32_t PRE = 4; // steps whose sample numbers are in registers before the barrier (8 Ki elements per item: every shape in use)
+	u16x4 sv[PRE];
+#pragma unroll
+	for (uint32_t k = 0; k < PRE; ++k) {
+		const uint32_t p = (k * LG_THREADS + threadIdx.x) * 4;
+		sv[k] = p < total ? *(const u16x4*)(sidx + p) : u16x4{0, 0, 0, 0};
+	}
+	for (uint32_t s = threadIdx.x; s < hl.item_samples; s += LG_THREADS) {
+		const uint32_t i = min(first + s, a.n - 1);
+		g[s] = *(const vecF*)&dy[(size_t)i * a.dy_stride_sample];
+	}
+	__syncthreads();
+	vecF* out = (vecF*)a.gvals + region;
+	const uint32_t last = hl.item_samples - 1;
+	auto place = [&](const uint32_t p, const u16x4 v) {
+		const vecF v0 = g[min((uint32_t)v[0], last)], v1 = g[min((uint32_t)v[1], last)], v2 = g[min((uint32_t)v[2], last)], v3 = g[min((uint32_t)v[3], last)];
+		if constexpr (F == 2) {
+			typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+			*(u4*)(out + p) = u4{__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1), __builtin_bit_cast(uint32_t, v2), __builtin_bit_cast(uint32_t, v3)};
+		} else {
+			out[p] = v0; out[p + 1] = v1; out[p + 2] = v2; out[p + 3] = v3;
+		}
+	};
+#pragma unroll
+	for (uint32_t k = 0; k < PRE; ++k) {
+		const uint32_t p = (k * LG_THREADS + threadIdx.x) * 4;
+		if (p < total) place(p, sv[k]);
+	}
+	for (uint32_t p = (PRE * LG_THREADS + threadIdx.x) * 4; p < total; p += LG_THREADS * 4) place(p, *(const u16x4*)(sidx + p));
+}
+
+template <int F>
+void launch_list_gradients(hipStream_t s, const ListGradArgs& a, uint32_t n_levels) {
+	hipLaunchKernelGGL((k_grid_list_gradients<F>), dim3(a.lists.n_items, n_levels), dim3(LG_THREADS), a.lists.item_samples * F * 2, s, a);
+	HIP_CHECK_THROW(hipGetLastError());
 }
 
 struct ScatterListsArgs {
@@ -360,103 +456,16 @@ struct ScatterListsArgs {
 	uint32_t dy_stride_sample, dy_stride_level;
 	half_t* grad;
 	GridHitLists lists;
+	uint32_t dev_flags;
+	const half_t* gvals;        // dL/dy in list order (k_grid_list_gradients): [n_levels][n_items][item_capacity][F]
 	unsigned long long* scratch;
 	int accumulate_mode, force_wide;
 	unsigned long long* dbg_times;
 	uint32_t* fallback_count;
-	AdamInFlush adam; // w_fp != nullptr: the single owner of a chunk applies the optimizer's update to it as it flushes (sl_flush_adam)
 };
 
-// The single owner of a chunk has the chunk's FINAL gradient in LDS when it flushes: adam.h:48-119 runs on it at once -- the same adam_one
-// on the same half gradient as k_adam afterwards, so the same bits (tests: test_adam_in_the_scatter_flush_is_bit_identical) -- and the 28 bytes
-// of optimizer state per parameter stream from and to HBM while the CU's other workgroup gathers from its L2: the two kernels' bounds are
-// different resources.  (Round 2 built this into k_grid_scatter, one 16-wave workgroup per CU, and measured it equal to the two launches: a
-// lone workgroup's accumulators sit idle while it streams.  Two workgroups per CU are what makes it pay.)
-// grad_quad(q) -> the four half gradients of parameters 4 q .. 4 q + 3 of the chunk; p0: the chunk's first parameter; window: LDS floats.
-template <typename GradQuad>
-__device__ inline void sl_flush_adam(const AdamInFlush& adam, const size_t p0, const uint32_t n_quads, half_t* __restrict__ g, lds_f32* window, const uint32_t window_floats, const uint32_t tid, GradQuad&& grad_quad) {
-	typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-	float* __restrict__ wf_p = adam.w_fp + p0;
-	float* __restrict__ m1_p = adam.m1 + p0;
-	float* __restrict__ m2_p = adam.m2 + p0;
-	uint32_t* __restrict__ st_p = (uint32_t*)adam.steps + p0; // uint16 counts (adam.steps16): addressed through st16_p
-	uint16_t* __restrict__ st16_p = (uint16_t*)adam.steps + p0;
-	half_t* __restrict__ wh_p = (half_t*)adam.w_half + p0;
-	// the most recent steps of the debiasing table -- all that parameters touched in the last few thousand steps ask for -- in LDS
-	const uint32_t common = adam.args.common_step;
-	const uint32_t window_base = common + 1 > window_floats ? common + 1 - window_floats : 0; // window[i] = table[window_base + i], up to table[common]
-	for (uint32_t i = tid; i < window_floats; i += SL_THREADS) if (window_base + i <= common) window[i] = adam.debias_table[window_base + i];
-	__syncthreads();
-	const float debias = window[common - window_base];
-	const auto debias_of = [&](const uint32_t t) { return t >= window_base ? window[t - window_base] : adam.debias_table[t]; };
-	constexpr int Q = 4; // quads per thread in flight
-	for (uint32_t q0 = tid; q0 < n_quads; q0 += Q * SL_THREADS) {
-		h4 gq[Q], old[Q];
-		bool live[Q], has_old[Q];
-		float4 wf[Q], a1[Q], a2[Q];
-		uint4 st[Q];
-#pragma unroll
-		for (int k = 0; k < Q; ++k) {
-			const uint32_t q = q0 + k * SL_THREADS;
-			live[k] = q < n_quads;
-			has_old[k] = false;
-			if (live[k]) {
-				gq[k] = grad_quad(q);
-				*(h4*)(g + 4 * (size_t)q) = gq[k];
-				const bool z0 = gq[k][0] == (half_t)0.0f, z1 = gq[k][1] == (half_t)0.0f, z2 = gq[k][2] == (half_t)0.0f, z3 = gq[k][3] == (half_t)0.0f;
-				live[k] = !(z0 && z1 && z2 && z3); // adam.h:76-79: a grid parameter with a zero gradient is left alone -- nothing else of it is read
-				has_old[k] = live[k] && (z0 || z1 || z2 || z3);
-			}
-			if (live[k]) {
-				wf[k] = *(const float4*)(wf_p + 4 * (size_t)q);
-				a1[k] = *(const float4*)(m1_p + 4 * (size_t)q);
-				a2[k] = *(const float4*)(m2_p + 4 * (size_t)q);
-				if (adam.steps16) {
-					typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-					const u16x4 sv = *(const u16x4*)(st16_p + 4 * (size_t)q);
-					st[k] = uint4{sv[0], sv[1], sv[2], sv[3]};
-				} else {
-					st[k] = *(const uint4*)(st_p + 4 * (size_t)q);
-				}
-				if (has_old[k]) old[k] = *(const h4*)(wh_p + 4 * (size_t)q);
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < Q; ++k) {
-			if (!live[k]) continue;
-			const size_t i4 = 4 * (size_t)(q0 + k * SL_THREADS);
-			half_t wh[4];
-			bool up[4];
-			adam_one(adam.args, debias_of, debias, false, gq[k][0], wf[k].x, wh[0], a1[k].x, a2[k].x, st[k].x, up[0]);
-			adam_one(adam.args, debias_of, debias, false, gq[k][1], wf[k].y, wh[1], a1[k].y, a2[k].y, st[k].y, up[1]);
-			adam_one(adam.args, debias_of, debias, false, gq[k][2], wf[k].z, wh[2], a1[k].z, a2[k].z, st[k].z, up[2]);
-			adam_one(adam.args, debias_of, debias, false, gq[k][3], wf[k].w, wh[3], a1[k].w, a2[k].w, st[k].w, up[3]);
-			*(float4*)(wf_p + i4) = wf[k];
-			*(float4*)(m1_p + i4) = a1[k];
-			*(float4*)(m2_p + i4) = a2[k];
-			if (adam.steps16) {
-				typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-				*(u16x4*)(st16_p + i4) = u16x4{(uint16_t)st[k].x, (uint16_t)st[k].y, (uint16_t)st[k].z, (uint16_t)st[k].w};
-			} else {
-				*(uint4*)(st_p + i4) = st[k];
-			}
-			// parameters that were not updated keep their half value, whatever it is: quads with a zero gradient somewhere brought their old
-			// halves along, so that the quad is stored whole
-			if (up[0] && up[1] && up[2] && up[3]) {
-				*(h4*)(wh_p + i4) = h4{wh[0], wh[1], wh[2], wh[3]};
-			} else if (has_old[k]) {
-				*(h4*)(wh_p + i4) = h4{up[0] ? wh[0] : old[k][0], up[1] ? wh[1] : old[k][1], up[2] ? wh[2] : old[k][2], up[3] ? wh[3] : old[k][3]};
-			} else { // a non-zero half gradient that became zero when the loss scale was divided out
-#pragma unroll
-				for (int e = 0; e < 4; ++e) if (up[e]) wh_p[i4 + e] = wh[e];
-			}
-		}
-	}
-}
-
-template <int D, int F, bool REC>
+template <int D, int F>
 __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t task_index, char* smem) {
-	const ScatterListsArgs& a_ = a; // (a local `a` below shadows the argument block)
 	const GridMeta* __restrict__ meta = a.meta;
 	const uint32_t n = a.n;
 	const MatView x = a.x;
@@ -479,7 +488,7 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 		dbg_times[4] = __builtin_readcyclecounter(); // shader clocks beside the 100 MHz clock: the task's clock rate (laboratory builds print it)
 	}
 
-	ScatterCtx<D, F, REC> c;
+	ScatterCtx<D, F> c;
 	c.lv = meta->levels[task.level];
 #pragma unroll
 	for (int d = 0; d < D; ++d) c.primes[d] = meta->primes[d];
@@ -487,8 +496,6 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 	c.interpolation = meta->interpolation;
 	c.level = task.level;
 	c.n = n;
-	constexpr bool PAIRED = REC && D == 2 && F == 2;
-	c.recs = (const uint4*)dL_dy + (size_t)(PAIRED ? task.level / 2 : task.level) * n;
 	c.x = x;
 	c.dy = dL_dy + (size_t)task.level * dy_stride_level;
 	c.dy_stride_sample = dy_stride_sample;
@@ -510,8 +517,10 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 		begin = min(s * per, hl.n_items);
 		end = min(begin + per, hl.n_items);
 		runs.chunk = scatter_chunk(c.lv, task.entry_begin);
-		runs.elems = hl.elems + (size_t)task.level * hl.n_items * hl.item_capacity;
-		runs.heads = hl.heads + (size_t)task.level * hl.n_items * GRID_HIT_HEADS + runs.chunk;
+		runs.dev_flags = a.dev_flags;
+		runs.elems = hl.elems + (size_t)task.level * hl.n_items * hl.item_capacity * GRID_HIT_WORDS;
+		runs.gvals = a.gvals + (size_t)task.level * hl.n_items * hl.item_capacity * F;
+		runs.heads = hl.heads + ((size_t)task.level * GRID_HIT_HEADS + runs.chunk) * hl.n_items;
 		runs.stragglers = hl.stragglers + (size_t)task.level * hl.straggler_capacity * 2;
 		runs.n_stragglers = min(hl.counts[task.level * GRID_HIT_COUNT_STRIDE], hl.straggler_capacity);
 		runs.n_items = hl.n_items;
@@ -519,11 +528,13 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 		with_stragglers = s == 0;
 	}
 
-	uint32_t first_h0 = 0, first_h1 = 0; // where this lane's item (of the wave's first 64) keeps its run of the chunk
+	uint32_t first_h0 = 0, first_h1 = 0; // where this lane's item (of the wave's first group) keeps its run of the chunk
+	// items per wave and turn: all eight waves busy also where the forward kernel's work items are large and a task has few of them
+	const uint32_t group = min(64u, max((end - begin + SL_WAVES - 1) / SL_WAVES, 1u));
 	if (listed && begin < end) {
-		const uint32_t* hd = runs.heads + (size_t)min(begin + wave * 64 + lane, end - 1) * GRID_HIT_HEADS;
+		const uint32_t* hd = runs.heads + min(begin + wave * group + lane, end - 1);
 		first_h0 = hd[0];
-		first_h1 = hd[1];
+		first_h1 = hd[runs.n_items];
 	}
 	typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 	auto zero_acc = [&](const uint32_t bytes) {
@@ -531,12 +542,11 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 		for (uint32_t i = tid; i < (bytes + 15) / 16; i += SL_THREADS) a4[i] = u4{0, 0, 0, 0};
 	};
 
-	// A chunk small enough for 64-bit accumulators in one pass takes them at once: nothing to verify, nothing to repeat.  These are the
-	// coarse levels, where thousands of samples add into each entry and the task-wide bound below -- sum |product| over EVERYTHING the
-	// task adds -- says little about a single entry's sum.
+	// Every task tries the packed sums first (round 4 gave chunks small enough for 64-bit accumulators in one pass those at once: half the
+	// rate on the LDS atomics -- 23 - 30 us per coarse task beside 20 for a fine one, profiles/r05_scatter_timeline.txt).  Its bound is over
+	// EVERYTHING the task adds, so tasks are cut for the same number of contributions whatever the level (grid_scatter_lists_plan).
 	const uint32_t wide_parts = (n_vals * 8 + SL_ACC_BYTES - 1) / SL_ACC_BYTES;
-	// ---------------------------------------------------------------------------------------------------- packed pass
-	bool packed_ok = !force_wide && wide_parts > 1;
+	bool packed_ok = !force_wide;
 	if (packed_ok) {
 		float init_max = 0;
 		if (init_from_grad) { // GradientMode::Accumulate, single owner: start from the existing gradient
@@ -552,7 +562,7 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 		}
 		__syncthreads();
 		if (dbg_times && tid == 0) dbg_times[1] = __builtin_amdgcn_s_memrealtime();
-		float bound = sl_pass<D, F, REC, true>(c, acc, task.entry_begin, task.n_entries, listed, runs, with_stragglers, begin, end, wave, lane, smem + SL_ACC_BYTES + 256 + wave * SL_WAVE_LDS, first_h0, first_h1);
+		float bound = sl_pass<D, F, true>(c, acc, task.entry_begin, task.n_entries, listed, runs, with_stragglers, begin, end, wave, lane, smem + SL_ACC_BYTES + 256 + wave * SL_WAVE_LDS, first_h0, first_h1, group);
 		// workgroup verdict: (sum over everything added) + (largest initial value) bounds every entry's sum
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
@@ -596,15 +606,6 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 				const int lo = (int)(uint32_t)s, hi = (int)(uint32_t)((s - (unsigned long long)(long long)lo) >> 32);
 				return __builtin_bit_cast(uint32_t, (h2{round32(lo), round32(hi)}));
 			};
-			if (a_.adam.w_fp) { // sole owner, optimizer step included (the host checked that the chunk is a whole number of aligned quads of parameters)
-				typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-				sl_flush_adam(a_.adam, ((size_t)c.lv.offset + task.entry_begin) * F, n_vals / 4, g, (lds_f32*)(smem + SL_ACC_BYTES + 256), SL_WAVES * SL_WAVE_LDS / 4, tid, [&](const uint32_t q) {
-					const unsigned long long s0 = a[2 * q], s1 = a[2 * q + 1];
-					const int l0 = (int)(uint32_t)s0, h0 = (int)(uint32_t)((s0 - (unsigned long long)(long long)l0) >> 32);
-					const int l1 = (int)(uint32_t)s1, h1 = (int)(uint32_t)((s1 - (unsigned long long)(long long)l1) >> 32);
-					return h4{round32(l0), round32(h0), round32(l1), round32(h1)};
-				});
-			} else {
 			// four accumulators = eight halves = one 16-byte store per lane where the chunk allows (its first value 16-byte aligned in the table: a
 			// quarter of the store instructions, which queue behind the other workgroup's gathers in the CU's address path)
 			const uint32_t n_pairs = n_vals / 2;
@@ -616,11 +617,10 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 				((u4*)g)[q] = u4{pair_of(s01.x), pair_of(s01.y), pair_of(s23.x), pair_of(s23.y)};
 			}
 			for (uint32_t i = 4 * n_quads + tid; i < n_pairs; i += SL_THREADS) ((uint32_t*)g)[i] = pair_of(a[i]);
-			}
 		}
 	} else {
 		// ------------------------------------------------------------------------------------------------ wide passes: 64-bit accumulators, half of the entries at a time
-		if (fallback_count && tid == 0 && !force_wide && wide_parts > 1) atomicAdd(fallback_count, 1u);
+		if (fallback_count && tid == 0 && !force_wide) atomicAdd(fallback_count, 1u);
 		long long* acc64 = (long long*)smem;
 		const uint32_t half_entries = (task.n_entries + wide_parts - 1) / wide_parts;
 		for (uint32_t part = 0; part < wide_parts; ++part) {
@@ -636,7 +636,7 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 				zero_acc(sub_vals * 8);
 			}
 			__syncthreads();
-			(void)sl_pass<D, F, REC, false>(c, acc, task.entry_begin + sub_lo, n_sub, listed, runs, with_stragglers, begin, end, wave, lane, smem + SL_ACC_BYTES + 256 + wave * SL_WAVE_LDS, first_h0, first_h1);
+			(void)sl_pass<D, F, false>(c, acc, task.entry_begin + sub_lo, n_sub, listed, runs, with_stragglers, begin, end, wave, lane, smem + SL_ACC_BYTES + 256 + wave * SL_WAVE_LDS, first_h0, first_h1, group);
 			__syncthreads();
 			if (task.flush_atomic) {
 				unsigned long long* sc = scratch + (size_t)task.scratch_begin + (size_t)sub_lo * F;
@@ -644,19 +644,12 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 					const long long v = acc64[i];
 					if (v != 0) atomicAdd(sc + i, (unsigned long long)v);
 				}
-			} else if (a_.adam.w_fp) {
-				typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-				// (the tables behind the accumulators are dead between the pass and the next part's: the barrier inside comes after every wave's pass)
-				__syncthreads();
-				sl_flush_adam(a_.adam, ((size_t)c.lv.offset + task.entry_begin + sub_lo) * F, sub_vals / 4, gs, (lds_f32*)(smem + SL_ACC_BYTES + 256), SL_WAVES * SL_WAVE_LDS / 4, tid, [&](const uint32_t q) {
-					return h4{fixed_to_half_fast(acc64[4 * q]), fixed_to_half_fast(acc64[4 * q + 1]), fixed_to_half_fast(acc64[4 * q + 2]), fixed_to_half_fast(acc64[4 * q + 3])};
-				});
 			} else {
 				typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 				for (uint32_t i = tid; i < sub_vals / 2; i += SL_THREADS) ((h2*)gs)[i] = h2{fixed_to_half_fast(acc64[2 * i]), fixed_to_half_fast(acc64[2 * i + 1])};
 			}
 		}
-		if (dbg_times && tid == 0 && (force_wide || wide_parts == 1)) dbg_times[1] = dbg_times[2] = __builtin_amdgcn_s_memrealtime();
+		if (dbg_times && tid == 0 && force_wide) dbg_times[1] = dbg_times[2] = __builtin_amdgcn_s_memrealtime();
 	}
 	if (dbg_times) {
 		__syncthreads();
@@ -671,17 +664,17 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 // b % 8, so the plan's eight per-XCD task lists are interleaved.  (Persistent workgroups pulling from per-XCD queues were built and
 // measured: 71 - 78 us against 60 -- a workgroup that stays resident keeps its place in the oldest-first arbitration of its CU for the
 // whole launch, the pops cost a global round trip per task, and stealing across XCDs runs a task away from its record plane at half speed.)
-template <int D, int F, bool REC>
+template <int D, int F>
 __global__ void __launch_bounds__(SL_THREADS, 4) k_grid_scatter_lists(const ScatterListsArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	sl_run_task<D, F, REC>(a, blockIdx.x, smem);
+	sl_run_task<D, F>(a, blockIdx.x, smem);
 }
 
-template <int D, int F, bool REC>
+template <int D, int F>
 void launch_lists(hipStream_t s, ScatterListsArgs a, uint32_t n_tasks) {
 	static bool configured = false;
 	if (!configured) { // more than 64 KiB of dynamic LDS has to be opted into once per kernel
-		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_grid_scatter_lists<D, F, REC>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES));
+		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_grid_scatter_lists<D, F>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES));
 		configured = true;
 	}
 #ifdef TCNN_AMD_DEV
@@ -695,7 +688,7 @@ void launch_lists(hipStream_t s, ScatterListsArgs a, uint32_t n_tasks) {
 		a.dbg_times = dbg;
 	}
 #endif
-	hipLaunchKernelGGL((k_grid_scatter_lists<D, F, REC>), dim3(n_tasks), dim3(SL_THREADS), SL_LDS_BYTES, s, a);
+	hipLaunchKernelGGL((k_grid_scatter_lists<D, F>), dim3(n_tasks), dim3(SL_THREADS), SL_LDS_BYTES, s, a);
 	HIP_CHECK_THROW(hipGetLastError());
 #ifdef TCNN_AMD_DEV
 	if (dbg) {
@@ -720,47 +713,37 @@ void launch_lists(hipStream_t s, ScatterListsArgs a, uint32_t n_tasks) {
 }
 
 template <int D>
-void dispatch_lists(hipStream_t s, uint32_t F, bool records, const ScatterListsArgs& a, uint32_t n_tasks) {
-#define TCNN_SL(FF, RR) return launch_lists<D, FF, RR>(s, a, n_tasks)
-	if (records) {
-		if constexpr (D == 2) {
-			if (F == 2) TCNN_SL(2, true);
-			if (F == 4) TCNN_SL(4, true);
-		} else {
-			if (F == 2) TCNN_SL(2, true);
-		}
-		throw std::runtime_error{"grid_backward_lists: scatter records need 4 D + 2 F <= 16"};
-	}
+void dispatch_lists(hipStream_t s, uint32_t F, const ScatterListsArgs& a, uint32_t n_tasks) {
 	switch (F) {
-		case 2: TCNN_SL(2, false);
-		case 4: TCNN_SL(4, false);
-		case 8: TCNN_SL(8, false);
+		case 2: return launch_lists<D, 2>(s, a, n_tasks);
+		case 4: return launch_lists<D, 4>(s, a, n_tasks);
+		case 8: return launch_lists<D, 8>(s, a, n_tasks);
 		default: throw std::runtime_error{"grid_backward_lists: needs n_features_per_level in {2, 4, 8}"};
 	}
-#undef TCNN_SL
 }
 
 } // namespace
 
 uint32_t grid_scatter_lists_lds_bytes() { return SL_LDS_BYTES; }
 
+size_t grid_list_gradients_bytes(const GridMeta& meta, const GridHitLists& lists) {
+	return (size_t)meta.n_levels * lists.n_items * lists.item_capacity * meta.n_features_per_level * 2;
+}
+
 // Tasks of the list-fed kernel, in launch order.  No measured tuning.
-//   * a level cut into chunks: one task per chunk, its single owner -- or, where a chunk's list is long (a level that could not be cut
-//     finer: no records), several tasks sharing the chunk, each a range of the list, merged through the scratch table;
+//   * a level cut into chunks: one task per chunk, its single owner -- or, where a chunk is small (cheap to merge), several tasks sharing
+//     the chunk, each a range of the items, merged through the scratch table;
 //   * a level that is one chunk: tasks over sample ranges of >= 8192 samples, merged through the scratch table;
-//   * XCD = b % 8 for block b: the tasks that GATHER from one record plane (a level; a level pair where two levels share a record) all go to
-//     one XCD -- the 4 MB plane is pulled into that L2 once and stays: with two or three planes per XCD (8 - 12 MB against 4 MB of L2) every
-//     record was fetched ~4 times and a task took 25 - 28 us instead of 22 - 24, with four planes per XCD 38 - 44 -- the tasks that stream
-//     their samples in order fill the XCDs up, longest first, and the eight lists are interleaved (padded with empty tasks).
-void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, bool paired_records, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems) {
+//   * nothing here gathers any more (round 5), so no task is tied to an XCD: the tasks are launched longest first and the dispatcher
+//     packs them (round 4 kept all tasks of a record plane on the XCD whose L2 held it: the ten fine levels of BASELINE config 3a ran on
+//     five XCDs in two rounds while three XCDs idled from 38 - 55 us on).
+void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems) {
 	const uint32_t F = meta.n_features_per_level;
 	const uint32_t rows = meta.interpolation == (uint32_t)InterpolationType::Nearest ? 1u : (1u << (meta.n_pos_dims - 1));
 	tasks.clear();
 	shared_ranges.clear();
 	scratch_elems = 0;
-	std::vector<std::pair<double, GridScatterTask>> q[8]; // (estimated cost, task)
-	double load[8] = {};
-	std::vector<std::pair<double, GridScatterTask>> loose;
+	std::vector<std::pair<double, GridScatterTask>> listed, loose; // (estimated cost, task)
 	uint32_t dbg_lo = 0, dbg_hi = meta.n_levels;
 #ifdef TCNN_AMD_DEV
 	if (const char* e = getenv("TCNN_AMD_SCATTER_LEVELS")) sscanf(e, "%u,%u", &dbg_lo, &dbg_hi); // profiling aid: levels lo..hi only (results are then incomplete!)
@@ -769,14 +752,15 @@ void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, bool paired_recor
 		const GridLevel& lv = meta.levels[l];
 		if (lv.scatter_binned || l < dbg_lo || l > dbg_hi) continue; // (binned: grid_backward_binned serves this level)
 		const uint32_t n_chunks = lv.scatter_n_chunks, per_chunk = lv.scatter_per_chunk;
-		const bool listed = n_chunks > 1;
-		// elements (listed: one gather each, ~2 corners) or samples (streamed, all corners) per chunk, and how many tasks share them
-		const double per_chunk_work = listed ? (double)n * rows / n_chunks : (double)n;
+		const bool is_listed = n_chunks > 1;
+		// elements (listed: one gather each, two corners) or samples (streamed, all corners) per chunk, and how many tasks share them
+		const double per_chunk_work = is_listed ? (double)n * rows / n_chunks : (double)n;
 		// A chunk shared by several tasks is flushed through 64-bit global atomics, one per value and task (~27 G/s chip-wide: 16 384 values
 		// are ~10 us per task, and at 2^20 samples two tasks per fine chunk were 31 M atomics -- 0.53 ms against 0.26 for single owners whose
 		// tasks simply take longer).  So only small chunks are ever shared.
 		const bool cheap_flush = per_chunk * F <= 2048;
-		const uint32_t splits = listed ? (cheap_flush ? (uint32_t)std::min(std::max(per_chunk_work / 16384.0 + 0.5, 1.0), 32.0) : 1u) : std::min(std::max(n / 8192u, 1u), 64u);
+		// (streamed: 4096 samples x 2^D corners are as many contributions as a listed task's 8192 elements x 2 have -- the packed sums' bound is over all of them)
+		const uint32_t splits = is_listed ? (cheap_flush ? (uint32_t)std::min(std::max(per_chunk_work / 16384.0 + 0.5, 1.0), 32.0) : 1u) : std::min(std::max(n / 4096u, 1u), 64u);
 		const uint32_t samples_per_split = next_multiple(div_round_up(n, splits), 64u);
 		for (uint32_t c = 0; c < n_chunks; ++c) {
 			const uint32_t begin = c * per_chunk;
@@ -799,45 +783,33 @@ void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, bool paired_recor
 				if (sb >= n) break;
 				const GridScatterTask t{l, begin, cnt, sb, std::min(n, sb + samples_per_split), shared ? 1u : 0u, scratch_begin, s | splits << 16};
 				// cost in "gathered or streamed lanes": a gathered element ~3x a streamed sample's load, plus the corners' adds and the chunk's zeroing / flush
-				const double cost = (listed ? per_chunk_work / splits * 3.0 : (double)samples_per_split * (1.0 + rows)) + cnt * F * (shared ? 1.0 : 0.25);
-				if (listed) {
-					const uint32_t xcd = (paired_records ? l / 2 : l) % 8;
-					q[xcd].emplace_back(cost, t);
-					load[xcd] += cost;
-				} else {
-					loose.emplace_back(cost, t);
-				}
+				// ... and the fewer entries a chunk has, the more of a wave's LDS adds meet at one address (measured: 18 us per task for chunks of 256 entries,
+				// 14 for chunks of 8192): the slow ones first, so that they do not end the launch
+				const double cost = (is_listed ? per_chunk_work / splits * 3.0 * (1.0 + std::min(1.0, 256.0 / std::max(cnt, 1u))) : (double)samples_per_split * (1.0 + rows)) + cnt * F * (shared ? 1.0 : 0.25);
+				(is_listed ? listed : loose).emplace_back(cost, t);
 			}
 		}
 	}
-	std::stable_sort(loose.begin(), loose.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-	for (const auto& t : loose) {
-		size_t best = 0;
-		for (size_t b = 1; b < 8; ++b) if (load[b] < load[best]) best = b;
-		q[best].push_back(t);
-		load[best] += t.first;
-	}
-	size_t longest = 0;
-	for (auto& v : q) {
-		std::stable_sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-		longest = std::max(longest, v.size());
-	}
-	for (size_t j = 0; j < longest; ++j) {
-		for (size_t b = 0; b < 8; ++b) tasks.push_back(j < q[b].size() ? q[b][j].second : GridScatterTask{0, 0, 0, 0, 0, 0, 0, 0});
-	}
+	listed.insert(listed.end(), loose.begin(), loose.end());
+	std::stable_sort(listed.begin(), listed.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+	for (const auto& t : listed) tasks.push_back(t.second);
 	while (!tasks.empty() && tasks.back().n_entries == 0) tasks.pop_back();
 }
 
 void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                          const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
-                         const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const GridHitLists& lists, bool accumulate, bool dy_records,
-                         const MlpReduceJob* reduce_job, uint32_t* fallback_count, const AdamInFlush* adam) {
+                         const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const GridHitLists& lists, void* gvals, bool accumulate,
+                         const MlpReduceJob* reduce_job, uint32_t* fallback_count) {
 	if (n_tasks == 0) return;
-	CHECK_THROW(lists.elems != nullptr && lists.heads != nullptr && lists.stragglers != nullptr && lists.counts != nullptr && lists.n_items > 0);
-	CHECK_THROW(!dy_records || grid_scatter_records_supported(meta));
-	CHECK_THROW(n <= grid_hit_max_samples(meta) && meta.hash_type != (uint32_t)HashType::Rng);
-	// every chunk must fit the 64 KiB of packed accumulators (the plan's chunks are cut for 128 KiB of 64-bit ones: the same entry count)
-	for (uint32_t l = 0; l < meta.n_levels; ++l) CHECK_THROW(meta.levels[l].scatter_binned || meta.levels[l].scatter_per_chunk * meta.n_features_per_level * 4 <= SL_ACC_BYTES);
+	CHECK_THROW(lists.elems != nullptr && lists.sidx != nullptr && lists.heads != nullptr && lists.stragglers != nullptr && lists.counts != nullptr && lists.n_items > 0 && gvals != nullptr);
+	CHECK_THROW(lists.item_capacity % 8 == 0 && lists.item_samples <= 65536 && lists.item_samples * meta.n_features_per_level * 2 <= 64 * 1024);
+	CHECK_THROW(n > 0 && n <= grid_hit_max_samples(meta) && meta.hash_type != (uint32_t)HashType::Rng);
+	// 32-bit byte offsets into a level's pool and into its dL/dy plane
+	CHECK_THROW((uint64_t)lists.n_items * lists.item_capacity * std::max<uint64_t>(GRID_HIT_WORDS * 4u, meta.n_features_per_level * 2u) < (1ull << 31));
+	// every chunk must fit the 64 KiB of packed accumulators (the plan's chunks are cut for 128 KiB of 64-bit ones: the same entry count), and the elements' 16-bit entries
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		CHECK_THROW(meta.levels[l].scatter_binned || (meta.levels[l].scatter_per_chunk * meta.n_features_per_level * 4 <= SL_ACC_BYTES && meta.levels[l].scatter_per_chunk < 0xffffu));
+	}
 	ScatterListsArgs a{};
 	a.meta = dev_meta;
 	a.tasks = dev_tasks;
@@ -848,15 +820,27 @@ void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMet
 	a.dy_stride_level = dy_stride_level;
 	a.grad = (half_t*)grad;
 	a.lists = lists;
+	a.gvals = (const half_t*)gvals;
 	a.scratch = (unsigned long long*)scratch;
 	a.accumulate_mode = accumulate ? 1 : 0;
 	a.force_wide = switches().scatter_wide ? 1 : 0; // tests: every task through the 64-bit passes
 	a.dbg_times = nullptr;
 	a.fallback_count = fallback_count;
-	if (adam) a.adam = *adam;
+#ifdef TCNN_AMD_DEV
+	if (const char* e = getenv("TCNN_AMD_SCATTER_DEV")) a.dev_flags = (uint32_t)atoi(e);
+#endif
+	{ // dL/dy into list order, then the owners
+		ListGradArgs lg{dev_meta, lists, (const half_t*)dL_dy, dy_stride_sample, dy_stride_level, n, (half_t*)gvals};
+		switch (meta.n_features_per_level) {
+			case 2: launch_list_gradients<2>(stream, lg, meta.n_levels); break;
+			case 4: launch_list_gradients<4>(stream, lg, meta.n_levels); break;
+			case 8: launch_list_gradients<8>(stream, lg, meta.n_levels); break;
+			default: throw std::runtime_error{"grid_backward_lists: needs n_features_per_level in {2, 4, 8}"};
+		}
+	}
 	switch (meta.n_pos_dims) {
-		case 2: dispatch_lists<2>(stream, meta.n_features_per_level, dy_records, a, n_tasks); break;
-		case 3: dispatch_lists<3>(stream, meta.n_features_per_level, dy_records, a, n_tasks); break;
+		case 2: dispatch_lists<2>(stream, meta.n_features_per_level, a, n_tasks); break;
+		case 3: dispatch_lists<3>(stream, meta.n_features_per_level, a, n_tasks); break;
 		default: throw std::runtime_error{"grid_backward_lists: 2 or 3 input dims"};
 	}
 	grid_scatter_finalize(stream, dev_ranges, n_ranges, scratch, grad, accumulate, reduce_job);

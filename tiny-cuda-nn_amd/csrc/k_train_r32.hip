@@ -64,7 +64,9 @@ template <typename V> __device__ inline void st32_stream(void* base, const uint3
 constexpr int R32_REGIONS = 15;
 // within a region: one matrix instruction, then V vector and D LDS instructions (sched_group_barrier masks: 0x8 MFMA, 0x2 VALU, 0x80 DS)
 #define R32_MVD(V, D) do { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, V, 0); __builtin_amdgcn_sched_group_barrier(0x80, D, 0); } while (0)
-template <int LOSS, int DIAG = 0>
+// REC: dL/d(encoded input) leaves as 16-byte scatter records {x, y, gradients of a level pair} (the bit-plane scatter, k_grid_scatter.hip);
+// else as plain level planes half2 [16][n] -- half the bytes -- for the list-fed scatter, whose elements know entries and weights (k_grid_scatter_lists.hip)
+template <int LOSS, bool REC, int DIAG = 0>
 __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const uint32_t tid = threadIdx.x;
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 	const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(a.n * 32), 0x00020000);
 	const auto rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)a.dL_dout, 0, (int)(a.n * a.dims * 2), 0x00020000);
 	const auto rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)a.L, 0, (int)(a.n * a.dims * 4), 0x00020000);
-	const auto rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)a.rec, 0, (int)(a.n * 128), 0x00020000);
+	const auto rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)a.rec, 0, (int)(a.n * (REC ? 128 : 64)), 0x00020000);
 	const uint32_t x_off = (4 * h * a.n + c) * 4; // levels 8 s + 4 h + i at + (8 s + i) n 4
 	struct In { h8 x[2]; float t[2]; float2 xs; };
 	uint32_t t_off[2];
@@ -113,7 +115,8 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		const uint32_t tb = blk * (128 * a.dims);
 		r.t[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, t_off[0], tb, 0));
 		r.t[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, t_off[1], tb, 0));
-		r.xs = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_xs, c * 8, blk * 256, 0));
+		if constexpr (REC) r.xs = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_xs, c * 8, blk * 256, 0));
+		else r.xs = float2{0, 0};
 		return r;
 	};
 	In pre{};
@@ -191,7 +194,8 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 	// ---- lane offsets of the stores
 	const uint32_t cg_off0 = (c * a.dims + h) * 2;              // compact dL_dout: output 2 r + h (+ 4 r bytes); compact L: twice that
 	const uint32_t o_off = c * 32 + h * 16;                     // out [n][16] halves: this lane stores the row's half h (16 bytes)
-	const uint32_t rec_off = (h * a.n + c) * 16;                // records: level pair 2 g + h at + g 2 n 16
+	const uint32_t rec_off = REC ? (h * a.n + c) * 16            // records: level pair 2 g + h at + g 2 n 16
+	                             : (2 * h * a.n + c) * 4;        // planes: level 4 g + 2 h + j at + (4 g + j) n 4
 
 	// weight-gradient accumulators: dW0 row tiles 0, 1; dW1 tiles (tr, tc); dWout as four 16 x 16 tiles (positions x 16 hidden features)
 	f16v wacc[6];
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 			}
 		}
 		// scatter records {x, y, gradients of levels 2 p, 2 p + 1}: registers 4 g .. 4 g + 3 are features 8 g + 4 h .. + 3, i.e. level pair p = 2 g + h
-		{
+		if constexpr (REC) {
 			const u32x4 lo = __builtin_bit_cast(u32x4, pack8(dx, 0)), hi = __builtin_bit_cast(u32x4, pack8(dx, 1));
 			const uint32_t x0 = __builtin_bit_cast(uint32_t, in.xs.x), x1 = __builtin_bit_cast(uint32_t, in.xs.y);
 			const uint32_t rb = blk * 512, pair2 = a.n * 32; // pair2: two level pairs further
@@ -420,6 +424,11 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, lo[2], lo[3]}, rs_rec, rec_off + (rb + pair2), 0, R32_REC_AUX);
 			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[0], hi[1]}, rs_rec, rec_off + (rb + 2 * pair2), 0, R32_REC_AUX);
 			__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[2], hi[3]}, rs_rec, rec_off + (rb + 3 * pair2), 0, R32_REC_AUX);
+		} else { // level planes: word 2 g + j of the tile's 8 is level 4 g + 2 h + j of sample c -- eight dense 128-byte runs per half wave
+			const u32x4 lo = __builtin_bit_cast(u32x4, pack8(dx, 0)), hi = __builtin_bit_cast(u32x4, pack8(dx, 1));
+			const uint32_t w[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+			for (int k = 0; k < 8; ++k) __builtin_amdgcn_raw_buffer_store_b32(w[k], rs_rec, rec_off, blk * 128 + n4 * (4 * (k >> 1) + (k & 1)), R32_REC_AUX);
 		}
 		R32_SB(); R32_STAMP(14);
 	}
@@ -496,7 +505,7 @@ bool mlp_train_r32_applies(const MlpDesc& d, uint32_t n, uint32_t x_plane_featur
 	if (d.activation != (uint32_t)Activation::ReLU || d.output_activation != (uint32_t)Activation::None) return false;
 	if (n == 0 || n % 32 != 0 || n > (1u << 22)) return false; // 32-bit byte offsets into [n][...] matrices
 	return x_plane_features == 2 && data_pdf == nullptr && external_dL_dy == nullptr && dims >= 1 && dims <= 4 && (loss == LossType::L2 || loss == LossType::RelativeL2) && out != nullptr &&
-	       dL_dx != nullptr && dx_plane_features == 2 && dx_record_x != nullptr && dx_record_dims == 2;
+	       dL_dx != nullptr && dx_plane_features == 2 && (dx_record_x == nullptr || dx_record_dims == 2); // records {x, y, gradients} or plain level planes
 }
 
 // Which of the two kernels: k_mlp_train_r32a (k_train_r32a.hip: weights in registers, weight-gradient tiles shared out over a workgroup's
@@ -548,8 +557,8 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 	CHECK_THROW(grid == mlp_train_r32_grid(n));
 #ifndef TCNN_AMD_DEV
 	if (r32a_chosen(n)) return mlp_train_r32a_launch(stream, a, grid, loss == LossType::L2 ? 1 : 2);
-	if (loss == LossType::L2) go(k_mlp_train_r32<1>);
-	else go(k_mlp_train_r32<2>);
+	if (loss == LossType::L2) { if (a.rec_x) go(k_mlp_train_r32<1, true>); else go(k_mlp_train_r32<1, false>); }
+	else { if (a.rec_x) go(k_mlp_train_r32<2, true>); else go(k_mlp_train_r32<2, false>); }
 #else
 	// ---- laboratory build (build.py --dev): in-kernel clocks (TCNN_AMD_MLP_TIMING), timing-only kernel variants (TCNN_AMD_MLP_DIAG), start
 	// delays (TCNN_AMD_MLP_STAGGER), workgroup placement (TCNN_AMD_MLP_WHERE).  None of this is in the product library.
@@ -560,7 +569,8 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 		HIP_CHECK_THROW(hipMemset(a.dbg, 0, (size_t)grid * 1024));
 	}
 	if (const char* e = getenv("TCNN_AMD_MLP_STAGGER")) a.stagger = (uint32_t)atoi(e);
-	static const int diag = getenv("TCNN_AMD_MLP_DIAG") ? atoi(getenv("TCNN_AMD_MLP_DIAG")) : 0;
+	static const int diag_env = getenv("TCNN_AMD_MLP_DIAG") ? atoi(getenv("TCNN_AMD_MLP_DIAG")) : 0;
+	const int diag = a.rec_x ? diag_env : 0; // (the timing-only variants exist in the record form)
 	if (r32a_chosen(n)) {
 		mlp_train_r32a_launch(stream, a, grid, loss == LossType::L2 ? 1 : 2);
 		if (a.dbg) {
@@ -613,17 +623,17 @@ void mlp_train_r32(hipStream_t stream, const MlpDesc& d, const void* image, uint
 		}
 		return;
 	}
-	if (diag == 1) go(k_mlp_train_r32<2, 1>);
-	else if (diag == 2) go(k_mlp_train_r32<2, 2>);
-	else if (diag == 3) go(k_mlp_train_r32<2, 3>);
-	else if (diag == 7) go(k_mlp_train_r32<2, 7>);
-	else if (diag == 8) go(k_mlp_train_r32<2, 8>);
-	else if (diag == 15) go(k_mlp_train_r32<2, 15>);
-	else if (diag == 16) go(k_mlp_train_r32<2, 16>);
-	else if (diag == 64) go(k_mlp_train_r32<2, 64>);
-	else if (diag == 34) go(k_mlp_train_r32<2, 34>); // the chain wave of a role split: no weight-gradient products, no transposing reads
-	else if (loss == LossType::L2) go(k_mlp_train_r32<1>);
-	else go(k_mlp_train_r32<2>);
+	if (diag == 1) go(k_mlp_train_r32<2, true, 1>);
+	else if (diag == 2) go(k_mlp_train_r32<2, true, 2>);
+	else if (diag == 3) go(k_mlp_train_r32<2, true, 3>);
+	else if (diag == 7) go(k_mlp_train_r32<2, true, 7>);
+	else if (diag == 8) go(k_mlp_train_r32<2, true, 8>);
+	else if (diag == 15) go(k_mlp_train_r32<2, true, 15>);
+	else if (diag == 16) go(k_mlp_train_r32<2, true, 16>);
+	else if (diag == 64) go(k_mlp_train_r32<2, true, 64>);
+	else if (diag == 34) go(k_mlp_train_r32<2, true, 34>); // the chain wave of a role split: no weight-gradient products, no transposing reads
+	else if (loss == LossType::L2) { if (a.rec_x) go(k_mlp_train_r32<1, true>); else go(k_mlp_train_r32<1, false>); }
+	else { if (a.rec_x) go(k_mlp_train_r32<2, true>); else go(k_mlp_train_r32<2, false>); }
 	if (a.dbg) {
 		std::vector<unsigned long long> hst((size_t)grid * (4 + R32_NW + 2 * R32_REGIONS));
 		HIP_CHECK_THROW(hipMemcpy(hst.data(), a.dbg, hst.size() * 8, hipMemcpyDeviceToHost));

@@ -43,7 +43,7 @@ constexpr int A_NPH = 4; // stamps (each costs ~200 clocks): [0] chain, [1] barr
 #define A_MVD(V, D) do { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, V, 0); __builtin_amdgcn_sched_group_barrier(0x80, D, 0); } while (0)
 
 // LOSS 1: L2, 2: RelativeL2
-template <int LOSS>
+template <int LOSS, bool REC> // REC: scatter records out, else plain level planes (k_mlp_train_r32)
 __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Args a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const uint32_t tid = threadIdx.x;
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 	const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(a.n * 32), 0x00020000);
 	const auto rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)a.dL_dout, 0, (int)(a.n * a.dims * 2), 0x00020000);
 	const auto rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)a.L, 0, (int)(a.n * a.dims * 4), 0x00020000);
-	const auto rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)a.rec, 0, (int)(a.n * 128), 0x00020000);
+	const auto rs_rec = __builtin_amdgcn_make_buffer_rsrc((void*)a.rec, 0, (int)(a.n * (REC ? 128 : 64)), 0x00020000);
 	const uint32_t x_off = (4 * h * a.n + c) * 4; // levels 8 s + 4 h + i at + (8 s + i) n 4
 	struct In { h8 x[2]; float t[2]; float2 xs; };
 	uint32_t t_off[2];
@@ -101,7 +101,8 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 		const uint32_t tb = blk * (128 * a.dims);
 		r.t[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, t_off[0], tb, 0));
 		r.t[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, t_off[1], tb, 0));
-		r.xs = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_xs, c * 8, blk * 256, 0));
+		if constexpr (REC) r.xs = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_xs, c * 8, blk * 256, 0));
+		else r.xs = float2{0, 0};
 		return r;
 	};
 	const uint32_t first = blockIdx.x * R32A_NW + wave;
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 
 	const uint32_t cg_off0 = (c * a.dims + h) * 2;
 	const uint32_t o_off = c * 32 + h * 16;
-	const uint32_t rec_off = (h * a.n + c) * 16;
+	const uint32_t rec_off = REC ? (h * a.n + c) * 16 : (2 * h * a.n + c) * 4; // records: level pair 2 g + h; planes: level 4 g + 2 h + j
 
 	// this wave's tiles: dW1 (w >> 1, w & 1), and a second one through the same instructions:
 	//   waves 0, 1: dW0's row tile w = dH0 (rows 32 w ..) X^T;
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 			dx = mfma32(w[B0 + 3], d03, dx);
 			A_SB();
 			// scatter records {x, y, gradients of levels 2 p, 2 p + 1}: registers 4 g .. 4 g + 3 are features 8 g + 4 h .. + 3, i.e. level pair p = 2 g + h
-			{
+			if constexpr (REC) {
 				const u32x4 lo = __builtin_bit_cast(u32x4, pack8(dx, 0)), hi = __builtin_bit_cast(u32x4, pack8(dx, 1));
 				const uint32_t x0 = __builtin_bit_cast(uint32_t, in.xs.x), x1 = __builtin_bit_cast(uint32_t, in.xs.y);
 				const uint32_t rb = blk * 512, pair2 = a.n * 32; // pair2: two level pairs further
@@ -331,6 +332,11 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 				__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, lo[2], lo[3]}, rs_rec, rec_off + (rb + pair2), 0, R32_REC_AUX);
 				__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[0], hi[1]}, rs_rec, rec_off + (rb + 2 * pair2), 0, R32_REC_AUX);
 				__builtin_amdgcn_raw_buffer_store_b128(u32x4{x0, x1, hi[2], hi[3]}, rs_rec, rec_off + (rb + 3 * pair2), 0, R32_REC_AUX);
+			} else { // level planes: word 2 g + j of the tile's 8 is level 4 g + 2 h + j of sample c
+				const u32x4 lo = __builtin_bit_cast(u32x4, pack8(dx, 0)), hi = __builtin_bit_cast(u32x4, pack8(dx, 1));
+				const uint32_t wd[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+				for (int k = 0; k < 8; ++k) __builtin_amdgcn_raw_buffer_store_b32(wd[k], rs_rec, rec_off, blk * 128 + n4 * (4 * (k >> 1) + (k & 1)), R32_REC_AUX);
 			}
 		} else {
 			// no block for this wave in the last trip: images of zeros make its share of every product vanish
@@ -413,8 +419,8 @@ void mlp_train_r32a_launch(hipStream_t stream, const R32Args& a, uint32_t grid, 
 		hipLaunchKernelGGL(kernel, dim3(grid), dim3(R32A_NW * 64), A_LDS_BYTES, stream, a);
 		HIP_CHECK_THROW(hipGetLastError());
 	};
-	if (loss_id == 1) go(k_mlp_train_r32a<1>);
-	else go(k_mlp_train_r32a<2>);
+	if (loss_id == 1) { if (a.rec_x) go(k_mlp_train_r32a<1, true>); else go(k_mlp_train_r32a<1, false>); }
+	else { if (a.rec_x) go(k_mlp_train_r32a<2, true>); else go(k_mlp_train_r32a<2, false>); }
 }
 
 } // namespace tcnn_amd

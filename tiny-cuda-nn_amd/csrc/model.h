@@ -273,6 +273,7 @@ public:
 	virtual bool scatter_records_usable(MatView x) const { return false; }
 	virtual uint32_t scatter_record_planes() const { return 0; } // 16-byte records per sample when scatter_records_usable()
 	virtual uint64_t scatter_wide_fallbacks() { return 0; }      // grid only: tasks of the list-fed scatter that had to take the 64-bit passes
+	virtual uint64_t list_scatters() const { return 0; }         // grid only: backward passes that ran the list-fed scatter (k_grid_scatter_lists)
 	// > 0: forward_planes() can write the encoded batch as level planes [padded / F][n][F] (no input gradients in that form)
 	virtual uint32_t forward_plane_features(uint32_t n) { return 0; }
 	// prep_job (optional): a side job the forward kernel carries along -- the fragment images of the network behind the encoding
@@ -443,12 +444,13 @@ public:
 		DeviceBuf dev_work;
 		uint32_t max_items = 0, blocks_per_xcd = 0;
 	};
-	PlanesPlan& planes_plan(uint32_t n) {
+	PlanesPlan& planes_plan(uint32_t n_, bool hit_lists) {
+		const uint32_t n = n_ | (hit_lists ? 0x80000000u : 0u); // (key; n itself is below 2^24 + 1)
 		auto it = m_planes_plans.find(n);
 		if (it != m_planes_plans.end()) return *it->second;
 		auto plan = std::make_unique<PlanesPlan>();
 		std::vector<uint32_t> work;
-		grid_planes_plan(m_meta, n, work, plan->max_items, plan->blocks_per_xcd);
+		grid_planes_plan(m_meta, n_, hit_lists, work, plan->max_items, plan->blocks_per_xcd);
 		plan->dev_work.resize(work.size() * sizeof(uint32_t));
 		HIP_CHECK_THROW(hipMemcpy(plan->dev_work.data(), work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 		return *(m_planes_plans[n] = std::move(plan));
@@ -470,14 +472,19 @@ public:
 			hl.item_capacity = hl.item_samples << (m_meta.n_pos_dims - 1);
 			hl.straggler_capacity = n << (m_meta.n_pos_dims - 1);
 			const size_t L = m_meta.n_levels;
-			const size_t elems_bytes = L * hl.n_items * hl.item_capacity * sizeof(uint32_t), heads_bytes = next_multiple_sz(L * hl.n_items * GRID_HIT_HEADS * sizeof(uint32_t), 256);
-			ctx.hit_elems = ArenaBuf{stream, elems_bytes + heads_bytes + L * hl.straggler_capacity * 2 * sizeof(uint32_t)};
+			const size_t elems_bytes = L * hl.n_items * hl.item_capacity * GRID_HIT_WORDS * sizeof(uint32_t), sidx_bytes = next_multiple_sz(L * hl.n_items * hl.item_capacity * sizeof(uint16_t), 256);
+			const size_t heads_bytes = next_multiple_sz(L * hl.n_items * GRID_HIT_HEADS * sizeof(uint32_t), 256);
+			ctx.hit_elems = ArenaBuf{stream, elems_bytes + sidx_bytes + heads_bytes + L * hl.straggler_capacity * 2 * sizeof(uint32_t)};
 			hl.elems = ctx.hit_elems.as<uint32_t>();
-			hl.heads = (uint32_t*)((char*)ctx.hit_elems.data() + elems_bytes);
-			hl.stragglers = (uint32_t*)((char*)ctx.hit_elems.data() + elems_bytes + heads_bytes);
+			hl.sidx = (uint16_t*)((char*)ctx.hit_elems.data() + elems_bytes);
+			hl.heads = (uint32_t*)((char*)ctx.hit_elems.data() + elems_bytes + sidx_bytes);
+			hl.stragglers = (uint32_t*)((char*)ctx.hit_elems.data() + elems_bytes + sidx_bytes + heads_bytes);
 			hl.counts = hc.sets[hc.next].as<uint32_t>();
 			hl.zero_counts = hc.sets[hc.next ^ 1].as<uint32_t>();
 			hc.next ^= 1;
+#ifdef TCNN_AMD_DEV
+			if (const char* e = getenv("TCNN_AMD_FWD_LISTS_DEV")) hl.dev_flags = (uint32_t)atoi(e); // 1: no copy-out, 2: plain instead of streamed stores, 4: no offsets (1 and 4: wrong results)
+#endif
 			ctx.hit_generation = ++hc.generation;
 			ctx.hit_stream = (const void*)stream;
 			ctx.n = n;
@@ -485,7 +492,7 @@ public:
 			ctx.chunk_mask = ArenaBuf{stream, (size_t)m_meta.n_levels * grid_scatter_max_chunks() * (n / 64) * sizeof(uint64_t)};
 			ctx.n = n;
 		}
-		PlanesPlan& plan = planes_plan(n);
+		PlanesPlan& plan = planes_plan(n, want_lists);
 		grid_forward_planes(stream, m_meta, dev_meta(), plan.dev_work.as<uint32_t>(), plan.max_items, plan.blocks_per_xcd, n, x, params, out_planes, ctx.chunk_mask.as<uint64_t>(), prep_job,
 		                    want_lists ? &ctx.hit_lists : nullptr);
 		return ctx;
@@ -508,22 +515,18 @@ public:
 				// hit lists of this very batch, their counters not yet handed to a later forward pass of this stream
 				const bool lists = ctx.hit_elems && ctx.n == n && ctx.hit_stream == (const void*)stream && hit_counters(stream).generation == ctx.hit_generation;
 				if (lists) { // k_grid_scatter_lists.hip: a static plan, nothing to tune
-					ListsPlan& lp = lists_plan(n, stream, dy_planes && ctx.dy_records);
+					CHECK_THROW(!ctx.dy_records); // the listed elements bring entries and weights along: dL/dy is gathered from plain level planes (or rows)
+					ListsPlan& lp = lists_plan(n, stream);
 					const uint32_t F = m_meta.n_features_per_level;
 					const uint32_t dy_stride_sample = dy_planes ? F : padded_output_width(), dy_stride_level = dy_planes ? n * F : F;
-					// the optimizer's update may ride on the flush of every chunk with a single owner (AdamInFlush; what is listed in adam_done is no
-					// longer the optimizer's to do)
-					const AdamInFlush* adam = nullptr;
-					ctx.adam_done.clear();
-					if (ctx.adam && mode == GradientMode::Overwrite) {
-						ctx.adam_done = lp.adam_ranges;
-						if (!ctx.adam_done.empty()) adam = ctx.adam;
-					}
+					ctx.adam_done.clear(); // (this kernel does not carry the optimizer's update: measured 20 % slower in round 4)
+					++m_list_scatters;
 					// the finalize pass (and the reduce job with it) may be left to the optimizer's launch: no ranges, no job -> no launch here
 					const bool defer = take_prologue(ctx, lp.dev_ranges.as<GridScatterRange>(), lp.host_ranges, lp.scratch.as<uint64_t>(), grads, mode);
+					ArenaBuf gvals{stream, grid_list_gradients_bytes(m_meta, ctx.hit_lists)}; // dL/dy in list order: written and read by the two kernels of this call
 					grid_backward_lists(stream, m_meta, dev_meta(), lp.dev_tasks.as<GridScatterTask>(), lp.n_tasks,
 					                    lp.dev_ranges.as<GridScatterRange>(), defer ? 0u : lp.n_ranges, lp.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, ctx.hit_lists,
-					                    mode == GradientMode::Accumulate, dy_planes && ctx.dy_records, defer ? nullptr : ctx.reduce_job, hit_counters(stream).fallbacks.as<uint32_t>(), adam);
+					                    gvals.data(), mode == GradientMode::Accumulate, defer ? nullptr : ctx.reduce_job, hit_counters(stream).fallbacks.as<uint32_t>());
 					if (dL_dx) {
 						CHECK_THROW(ctx.dy_dx);
 						CHECK_THROW(!dy_planes);
@@ -694,22 +697,19 @@ public:
 		DeviceBuf dev_tasks, dev_ranges, scratch;
 		std::vector<GridScatterRange> host_ranges;
 		uint32_t n_tasks = 0, n_ranges = 0;
-		ParamRanges adam_ranges; // what a launch of this plan updates itself when it is handed an AdamInFlush: the chunks with a single owner
 	};
-	ListsPlan& lists_plan(uint32_t n, hipStream_t stream, bool records) {
-		const auto key = std::make_pair(n | (records ? 0x80000000u : 0u), (const void*)stream);
+	ListsPlan& lists_plan(uint32_t n, hipStream_t stream) {
+		const auto key = std::make_pair(n, (const void*)stream);
 		auto it = m_lists_plans.find(key);
 		if (it != m_lists_plans.end()) return *it->second;
 		auto plan = std::make_unique<ListsPlan>();
 		std::vector<GridScatterTask> tasks;
 		std::vector<GridScatterRange> ranges;
 		size_t scratch_elems = 0;
-		const bool paired = records && m_meta.n_pos_dims == 2 && m_meta.n_features_per_level == 2;
-		grid_scatter_lists_plan(m_meta, n, paired, tasks, ranges, scratch_elems);
+		grid_scatter_lists_plan(m_meta, n, tasks, ranges, scratch_elems);
 		plan->n_tasks = (uint32_t)tasks.size();
 		plan->n_ranges = (uint32_t)ranges.size();
 		plan->host_ranges = ranges;
-		plan->adam_ranges = grid_scatter_adam_ranges(m_meta, tasks, true);
 		auto upload = [](DeviceBuf& b, const void* src, size_t bytes) {
 			b.resize(bytes);
 			if (bytes) HIP_CHECK_THROW(hipMemcpy(b.data(), src, bytes, hipMemcpyHostToDevice));
@@ -764,6 +764,8 @@ public:
 		return total;
 	}
 
+	uint64_t list_scatters() const override { return m_list_scatters; }
+
 	Json hyperparams() const override { // grid.h:1098-1115
 		static const char* types[] = {"Hash", "Dense", "Tiled"};
 		static const char* interps[] = {"Nearest", "Linear", "Smoothstep"};
@@ -790,6 +792,7 @@ private:
 	std::map<uint32_t, std::unique_ptr<PlanesPlan>> m_planes_plans;
 	bool m_scatter_levels_ok = true;
 	bool m_any_binned = false;
+	uint64_t m_list_scatters = 0;
 	std::vector<uint32_t> m_resolutions;
 	uint32_t m_n_features, m_log2_hashmap_size, m_base_resolution, m_n_entries;
 	float m_per_level_scale;
@@ -1684,6 +1687,9 @@ public:
 		bool fused = false;         // produced by fused_encode(): backward() goes through the fused MLP kernel
 		uint32_t oneblob_bins = 0;  // > 0: no encoded batch was written -- the MLP kernels evaluate the OneBlob encoding of the input themselves
 		ArenaBuf image;             // the network's fragment images, if the encoding's forward kernel built them on the way (MlpPrepJob)
+		// the MLP's weight-gradient slabs once their reduction was handed to a LATER launch (AdamPrologue: the optimizer's, enqueued after
+		// fused_step returns): they stay allocated as long as this context does -- the arena's rule is "consumer enqueued before the free"
+		mutable ArenaBuf slabs_kept;
 	};
 
 	// cpp_api.cu:84-95.  Without input gradients the forward pass keeps nothing but the encoded batch: backward() recomputes the
@@ -1754,6 +1760,8 @@ public:
 	void invalidate_live_image() { m_network->invalidate_live_image(); } // the parameters change(d) some other way
 	size_t image_preps() const { return m_image_preps; }                 // k_mlp_prep launches of fused steps so far (a test's view of the above)
 	uint64_t scatter_wide_fallbacks() { return m_encoding->scatter_wide_fallbacks(); }
+	uint64_t list_scatters() const { return m_encoding->list_scatters(); }
+	bool context_keeps_slabs(const ModelContext& c) const { const Ctx* x = dynamic_cast<const Ctx*>(&c); return x && (bool)x->slabs_kept; }
 	// the register-resident fused kernel (k_train_regs.hip) writes dL_doutput / L as compact [n][dims] matrices (TrainContext::compact)
 	bool fused_compact_context_supported(uint32_t n) const {
 		const bool ok = use_fused_step() && mlp_train_regs_supported(m_network->desc(), n) && m_network->padded_output_width() == 16;
@@ -1829,7 +1837,8 @@ public:
 		ArenaBuf dL_dnetwork_input;
 		const uint32_t plane_f = need_dx ? m_encoding->level_plane_features(dL_dinput != nullptr, mode) : 0;
 		// scatter records: the MLP kernel interleaves the samples' coordinates with dL/d(encoding) so that the grid scatter needs one gather per hit
-		const bool records = plane_f > 0 && m_encoding->padded_output_width() == m_encoding->output_width() && m_encoding->scatter_records_usable(input);
+		// (not with hit lists: their elements carry entries and weights, the scatter gathers dL/dy alone from plain level planes)
+		const bool records = plane_f > 0 && !ctx.encoding_ctx.hit_elems && m_encoding->padded_output_width() == m_encoding->output_width() && m_encoding->scatter_records_usable(input);
 		if (need_dx) dL_dnetwork_input = ArenaBuf{stream, records ? (size_t)n * m_encoding->scatter_record_planes() * 16 : (size_t)n * m_encoding->padded_output_width() * 2};
 		ctx.encoding_ctx.dy_records = records;
 
@@ -1916,6 +1925,7 @@ public:
 			if (ctx.encoding_ctx.reduce_job) {
 				ctx.encoding_ctx.reduce_job = nullptr;
 				if (!reduce_job.taken) mlp_reduce_slabs(stream, n_net, n_slabs, slabs.as<float>(), g, mode == GradientMode::Accumulate);
+				else if (prologue && prologue->pending && prologue->has_reduce) ctx.slabs_kept = std::move(slabs); // read by the optimizer's launch
 			}
 			if (adam_done) {
 				adam_done->clear();
@@ -3144,6 +3154,7 @@ public:
 	const void* params_unexposed() const { return m_params.data(); } // for comparisons only
 	size_t image_preps() const { return m_model->image_preps(); }
 	uint64_t scatter_wide_fallbacks() { return m_model->scatter_wide_fallbacks(); }
+	uint64_t list_scatters() const { return m_model->list_scatters(); }
 	size_t prologue_steps() const { return m_prologue_steps; }
 	void* param_gradients() const { return m_grads.data(); }
 

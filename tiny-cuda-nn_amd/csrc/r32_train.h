@@ -25,8 +25,8 @@ struct R32Args {
 	half_t* out;            // [n][16]
 	half_t* dL_dout;        // compact [n][dims]
 	float* L;               // compact [n][dims]
-	u32x4* rec;             // scatter records [8][n]: {x, y, gradients of levels 2 p, 2 p + 1}
-	const float* rec_x;     // [n][2]
+	u32x4* rec;             // scatter records [8][n]: {x, y, gradients of levels 2 p, 2 p + 1}; or (rec_x == nullptr) level planes half2 [16][n]
+	const float* rec_x;     // [n][2]; nullptr: dL/d(encoded input) leaves as plain level planes
 	float* slabs;           // [gridDim.x][n_params]
 	const h8* image;        // R32 fragments
 	uint32_t n, dims, n_params;

@@ -113,33 +113,46 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_
 // out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][GRID_FILTER_MAX_CHUNKS][n / 64], written for levels with 2 .. GRID_FILTER_MAX_CHUNKS scatter chunks.
 bool grid_planes_supported(const GridMeta& meta, uint32_t n);
 uint32_t grid_planes_spt(const GridMeta& meta);        // samples per thread of the kernel shape used for this grid
-void grid_planes_plan(const GridMeta& meta, uint32_t n, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd);
+void grid_planes_plan(const GridMeta& meta, uint32_t n, bool hit_lists, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd); // hit_lists: the shape of the kernel that writes them (larger work items)
 // prep_job (optional, mlp_side_jobs.h; passed to the kernel by value): the kernel also builds the MLP's fragment images
 struct MlpPrepJob;
-// ---- hit lists (round 4): the scatter's sample filter as a STREAM instead of bit planes to be scanned.  For every level cut into
-// 2 .. GRID_FILTER_MAX_CHUNKS chunks the forward kernel writes, per work item (grid_hit_item_samples() consecutive samples of one level), the
-// item's elements SORTED BY CHUNK into the item's own region of the level's pool, plus 65 offsets: where each chunk's run starts inside
-// the region ([64]: how many elements the item has).  An element is 32 bits: the sample in the low bits, above them one bit per corner
-// of the cell, 2^D of them -- corner 2 r + b is corner b (0: cell_0, 1: cell_0 + 1) of cell row r (bit d - 1 of r set: cell_d + 1,
-// d = 1 .. D - 1) -- set where that corner's entry lies in the run's chunk.  A chunk's owner walks the items' runs of its chunk: no scan
-// of a bit plane, no compaction queue, nothing to test per sample.  No counters, no atomics: a region's place is the item's number
-// (the first form appended to one list per chunk through a global atomic on its tail per item and chunk -- 64 lanes, one
-// instruction -- and those 5632 same-address atomics alone cost the forward kernel 15 of its 72 us).  The one exception: a row whose
-// two corners fall into different chunks (one in ~8000) sends its second corner to the level's straggler list {element, chunk}, which
-// every owner of the level scans.
-inline constexpr uint32_t grid_hit_mask_shift(uint32_t n_pos_dims) { return 32u - (1u << n_pos_dims); } // 28 (2-D), 24 (3-D)
+// ---- hit lists (round 4; round 5: elements that carry their entries and weights, gradients transposed into list order).
+// The scatter's sample filter as a STREAM instead of bit planes to be scanned.  For every level cut into 2 .. GRID_FILTER_MAX_CHUNKS chunks
+// the forward kernel writes, per work item (grid_hit_item_samples() consecutive samples of one level), the item's elements SORTED BY
+// CHUNK into the item's own region of the level's pool, plus 65 offsets: where each chunk's run starts inside the region ([64]: how
+// many elements the item has).  An element is one CELL ROW of one sample -- the two corners that differ in dimension 0 only -- and
+// carries everything the chunk's owner needs but the gradient:
+//     elems [..][0]: entry of corner A (cell_0) | entry of corner B (cell_0 + 1) << 16, both relative to the chunk's first entry;
+//     elems [..][1]: (half) weight of A | (half) weight of B << 16 -- the fp32 products of grid.h:147-160 rounded to half, as grid.h:254 uses them
+//                    (no corner B here -- Nearest interpolation, or B lies in another chunk --: A's entry again with weight +0, so that
+//                    the owner adds both corners of every element without a test: a product with +0 adds nothing);
+//     sidx  [..]   : the sample, relative to the item's first one (16 bits).
+// After the MLP kernel a streaming pass (k_grid_list_gradients, k_grid_scatter_lists.hip) brings dL/dy into the same order: per item it
+// loads the item's slice of the level's gradient plane into LDS (2 KB) and writes gvals [..] = dL/dy of element's sample, position
+// for position.  The chunk's owner then walks the items' runs of its chunk reading elems and gvals side by side -- dense loads, no
+// gather, no coordinates, no pos_fract, no hash.  (Round 4: 4-byte elements {sample, corner bits}; the owner gathered a 16-byte record
+// per element from a 4 MB plane per level pair.  Each such gather costs the CU a whole 128-byte line from its L2, ~3 clocks per lane
+// whatever the bytes used -- 40 us of the kernel's 59 - 66 at 2^18 samples, profiles/r05_scatter_timeline.txt -- and needs the plane
+// resident in the XCD's L2, which tied the form to batches of 2^17 .. 2^19.)  No counters, no atomics: a region's place is the item's
+// number.  The one exception: a row whose two corners fall into different chunks (one in ~8000 on hashed levels) sends corner B to the
+// level's straggler list {sample | corner bit << grid_hit_mask_shift, chunk}, which every owner of the level scans and evaluates from the coordinates.
+inline constexpr uint32_t grid_hit_mask_shift(uint32_t n_pos_dims) { return 32u - (1u << n_pos_dims); } // 28 (2-D), 24 (3-D): stragglers only
 constexpr uint32_t GRID_HIT_COUNT_STRIDE = 64;   // uint32 per level between the straggler counts (one memory channel each)
 constexpr uint32_t GRID_HIT_HEADS = 65;          // offsets per item: GRID_FILTER_MAX_CHUNKS + 1
+constexpr uint32_t GRID_HIT_WORDS = 2;           // uint32 per element
 struct GridHitLists {
-	uint32_t* elems = nullptr;       // [n_levels][n_items][item_capacity]
-	uint32_t* heads = nullptr;       // [n_levels][n_items][GRID_HIT_HEADS]
-	uint32_t* stragglers = nullptr;  // [n_levels][straggler_capacity][2]: {element, chunk}
+	uint32_t* elems = nullptr;       // [n_levels][n_items][item_capacity][GRID_HIT_WORDS]
+	uint16_t* sidx = nullptr;        // [n_levels][n_items][item_capacity]
+	uint32_t* heads = nullptr;       // [n_levels][GRID_HIT_HEADS][n_items]: chunk-major, so that an owner reads its chunk's offsets of consecutive items with dense loads
+	uint32_t* stragglers = nullptr;  // [n_levels][straggler_capacity][2]: {sample | corner bit, chunk}
 	uint32_t* counts = nullptr;      // [n_levels][GRID_HIT_COUNT_STRIDE]: stragglers per level; all zero when the forward kernel starts
 	uint32_t* zero_counts = nullptr; // the counter set of the NEXT forward launch on this stream: zeroed by this one
 	uint32_t n_items = 0, item_samples = 0, item_capacity = 0, straggler_capacity = 0;
+	uint32_t dev_flags = 0;          // laboratory build only (TCNN_AMD_FWD_LISTS_DEV): timing-only variants of the list output
 };
 uint32_t grid_hit_item_samples(const GridMeta& meta); // samples per work item of the forward kernel shape used for this grid (k_grid_planes.hip)
-inline uint32_t grid_hit_max_samples(const GridMeta& meta) { return 1u << grid_hit_mask_shift(meta.n_pos_dims); }
+// the kernels address the pool (12 bytes x 2^(D-1) rows per sample and level) and the straggler masks with 32 bits
+inline uint32_t grid_hit_max_samples(const GridMeta& meta) { return meta.n_pos_dims <= 2 ? (1u << 24) : (1u << 22); }
 // hit_lists (optional, instead of chunk_bits): see above
 void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const uint32_t* dev_work, uint32_t max_items, uint32_t blocks_per_xcd, uint32_t n,
                          MatView x, const void* grid, void* out_planes, uint64_t* chunk_bits, const MlpPrepJob* prep_job = nullptr, const GridHitLists* hit_lists = nullptr);
@@ -187,12 +200,13 @@ void grid_backward_lds(hipStream_t stream, const GridMeta& meta, const GridMeta*
 // passes otherwise -- tasks of its own plan (GridScatterTask::pad = split s | n_splits << 16: which share of a chunk's list), same scratch, same results.
 uint32_t grid_scatter_lists_lds_bytes();
 // the kernel's tasks in launch order (one workgroup each; block b runs on XCD b % 8: k_grid_scatter_lists.hip)
-void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, bool paired_records, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems);
+void grid_scatter_lists_plan(const GridMeta& meta, uint32_t n, std::vector<GridScatterTask>& tasks, std::vector<GridScatterRange>& shared_ranges, size_t& scratch_elems);
 void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, const GridScatterTask* dev_tasks, uint32_t n_tasks,
                          const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, uint32_t n, MatView x,
-                         const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const GridHitLists& lists, bool accumulate, bool dy_records,
-                         const MlpReduceJob* reduce_job, uint32_t* fallback_count = nullptr,
-                         const AdamInFlush* adam = nullptr); // (optional) the single owners apply the optimizer step to their chunks: grid_scatter_adam_ranges(tasks) says which parameters
+                         const void* dL_dy, uint32_t dy_stride_sample, uint32_t dy_stride_level, void* grad, const GridHitLists& lists, void* gvals, bool accumulate,
+                         const MlpReduceJob* reduce_job, uint32_t* fallback_count = nullptr);
+// gvals: workspace of grid_list_gradients_bytes(): dL/dy in list order, half [n_levels][n_items][item_capacity][F], written by the launch's first kernel
+size_t grid_list_gradients_bytes(const GridMeta& meta, const GridHitLists& lists);
 // the finalize pass of the shared chunks (+ the MLP's slab reduction), shared by both scatter kernels
 void grid_scatter_finalize(hipStream_t stream, const GridScatterRange* dev_ranges, uint32_t n_ranges, uint64_t* scratch, void* grad, bool accumulate, const MlpReduceJob* reduce_job);
 // the parameter ranges (relative to grad) a launch of `tasks` with `adam` updates itself; empty = this plan cannot carry the optimizer step

@@ -112,6 +112,8 @@ _SIGNATURES = {
     "tcnn_trainer_image_preps": (C.c_size_t, [_vp]),
     "tcnn_trainer_scatter_wide_fallbacks": (C.c_size_t, [_vp]),
     "tcnn_trainer_optimizer_prologue_steps": (C.c_size_t, [_vp]),
+    "tcnn_trainer_list_scatters": (C.c_size_t, [_vp]),
+    "tcnn_train_ctx_keeps_weight_gradient_slabs": (C.c_int, [_vp, _vp]),
     "tcnn_trainer_profile_next_step": (_int, [_vp]),
     "tcnn_trainer_profile_collect": (_int, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_u32)]),
     "tcnn_trainer_serialize": (_int, [_vp, _int, _pp, C.POINTER(_sz)]),

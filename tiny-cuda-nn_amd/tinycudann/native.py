@@ -106,6 +106,14 @@ class Trainer:
         """training steps whose optimizer launch also finished the backward pass's gradients (tcnn_amd.h: tcnn_trainer_optimizer_prologue_steps)"""
         return int(_C.lib.tcnn_trainer_optimizer_prologue_steps(self._h))
 
+    def list_scatters(self):
+        """backward passes of the grid encoding that ran the list-fed gradient kernel (tcnn_amd.h: tcnn_trainer_list_scatters)"""
+        return int(_C.lib.tcnn_trainer_list_scatters(self._h))
+
+    def context_keeps_slabs(self, ctx):
+        """whether `ctx` owns the weight-gradient slabs the optimizer's launch reduces (tcnn_amd.h: tcnn_train_ctx_keeps_weight_gradient_slabs)"""
+        return bool(_C.lib.tcnn_train_ctx_keeps_weight_gradient_slabs(self._h, ctx._h))
+
     def scatter_wide_fallbacks(self):
         """tasks of the grid gradient kernel that could not prove their packed 32-bit sums and ran the 64-bit passes (tcnn_amd.h)"""
         return int(_C.lib.tcnn_trainer_scatter_wide_fallbacks(self._h))
