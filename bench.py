@@ -179,7 +179,7 @@ def run_c4(args):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 ENCODE_KERNEL = {"c3a": "k_grid_fwd_planes", "c3b": "k_grid_fwd_planes", "c5": "k_grid_fwd_planes"}
 # (the scatter's finalize pass runs as the prologue of the optimizer's launch, k_adam_prologue; C5's binned levels keep it as a launch)
-SCATTER_KERNEL = {"c3a": "k_grid_scatter_lists", "c3b": "k_grid_scatter", "c5": "k_bin_* + k_grid_scatter (+ finalize)"}
+SCATTER_KERNEL = {"c3a": "k_grid_list_gradients + k_grid_scatter_lists", "c3b": "k_grid_scatter", "c5": "k_bin_* + k_grid_scatter (+ finalize)"}
 
 
 def hbm_piece(kernel, algorithmic_bytes, ms):
@@ -275,10 +275,12 @@ def settle_device(torch, ms):
     del a, b
 
 
-def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=None):
+def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=None, settle_ms=None):
     """`steps` timed trainer->training_step(input, target) calls (trainer.h:163-190) of workload `name` after `warmup` untimed ones.
-    Every 8th timed step (steps 4, 12, ...) also records HIP events on the launch stream around its pieces (tcnn_trainer_profile_next_step: events
-    without the system-scope fence; the eight records of such a step cost it ~10 us of dispatch bubbles, hence not on every step)."""
+    Every 8th timed step (steps 4, 12, ...; every 4th -- 2, 6, ... -- in runs of at most 32 steps, so that the driver's `--steps 20` averages
+    five launches, not two) also records HIP events on the launch stream around its pieces (tcnn_trainer_profile_next_step: events without
+    the system-scope fence; the eight records of such a step cost it ~10 us of dispatch bubbles, hence not on every step).
+    settle_ms: None = the run's --settle-ms."""
     n_in, n_out, _, cfg = WORKLOADS[name]
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
@@ -288,19 +290,21 @@ def measure_training(tcnn, torch, name, batch, steps, warmup, seed=42, barrier=N
     if barrier is None:
         barrier = torch.cuda.synchronize
     ctx = None
+    settle = SETTLE_MS if settle_ms is None else settle_ms
     if warmup == 0:
-        settle_device(torch, SETTLE_MS)
+        settle_device(torch, settle)
     for i in range(warmup):
         ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
         if i == 0:
             # behind the first step, not in front of it: a trainer's first step keeps the HOST busy for ~4 ms (plans, allocations, kernel
             # attributes) while the device idles -- long enough for a settled device to fall back
-            settle_device(torch, SETTLE_MS)
+            settle_device(torch, settle)
     loss0 = tr.loss(ctx) if ctx is not None else float("nan")
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        if i % 8 == 4 or (steps <= 4 and i == steps - 1):  # (not the first step: creating its eight events would delay the first launch of the timed region on an idle device)
+        every, phase = (4, 2) if steps <= 32 else (8, 4)
+        if i % every == phase or (steps <= 2 and i == steps - 1):  # (not the first step: creating its eight events would delay the first launch of the timed region on an idle device)
             tr.profile_next_step()
         ctx = tr.training_step(xs[i % POOL], ts[i % POOL])
     barrier()
@@ -341,6 +345,17 @@ def other_configs(tcnn, torch):
     """The other BASELINE configurations, short runs after the headline's timed region (same process, rank 0 of a single-GPU run):
     {c2, c3b, c5: training_step; c4: inference} -> ms_per_step, value, the fraction of the fp16 MFMA peak of the MLP kernel."""
     out = {}
+    # the headline's configuration at a quarter and at four times its batch: the grid gradient's dispatch (hit lists or bit planes) is chosen
+    # per grid, not per batch size, and these two points keep that choice under the driver's eyes
+    for label, batch, steps, warmup in (("c3a_2p16", 1 << 16, 60, 15), ("c3a_2p20", 1 << 20, 16, 4)):
+        try:
+            m = measure_training(tcnn, torch, "c3a", batch, steps, warmup)
+            out[label] = {"metric": METRIC["c3a"].replace("batch=256k", f"batch={batch}"), "ms_per_step": m["elapsed"] / steps * 1e3, "value": batch * steps / m["elapsed"], "unit": "samples/s",
+                          "batch": batch, "steps": steps, "pieces_ms": {k: m["pieces"][k] for k in ("encode", "mlp_kernel", "encoding_backward", "optimizer")},
+                          "scatter_tasks_summed_in_64_bits": m.get("scatter_wide_tasks")}
+        except Exception as e:
+            out[label] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     for name, steps, warmup in (("c3b", 40, 10), ("c2", 100, 20), ("c5", 12, 4)):
         try:
             batch = WORKLOADS[name][2]
@@ -394,7 +409,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--settle-ms", type=float, default=SETTLE_MS, help="milliseconds of unrelated device work (fp16 matmuls) before the warmup steps, so that an idle device's clocks have settled (settle_device); 0: none")
+    ap.add_argument("--settle-ms", type=float, default=SETTLE_MS, help="milliseconds of unrelated device work (memory-bound fp32 elementwise passes) behind the first warmup step, so that an idle device's clocks have settled (settle_device); 0: none")
     ap.add_argument("--workload", default="c3a", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -468,6 +483,21 @@ def main():
             sharded = {"error": err or "another rank could not set the sharded inference up"}
         del setup
 
+    # The same run without the settle pass, for comparison with rounds 1-3 (whose lines had none): the device idles for two seconds -- as
+    # it does in front of a fresh process's first step -- then W warmup and K timed steps (at most 20) of a new trainer, nothing in between.
+    no_settle_ms = None
+    if world == 1 and SETTLE_MS > 0 and not args.batch:
+        try:
+            k_ns, w_ns = min(args.steps, 20), min(args.warmup, 5)
+            torch.cuda.synchronize()
+            time.sleep(2.0)
+            m_ns = measure_training(tcnn, torch, args.workload, batch, k_ns, w_ns, seed=42 + rank, settle_ms=0.0)
+            no_settle_ms = {"ms_per_step": m_ns["elapsed"] / k_ns * 1e3, "steps": k_ns, "warmup": w_ns,
+                            "note": "a second run in this process behind 2 s of idling, no settle pass: the protocol of rounds 1-3"}
+        except Exception as e:
+            no_settle_ms = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         step_ms = elapsed / args.steps * 1e3
         mlp_ms = pieces["mlp_kernel"]
@@ -504,6 +534,8 @@ def main():
             "warmup": args.warmup,
             "device_settle_ms": SETTLE_MS,
             "ms_per_step": step_ms,
+            "ms_per_step_no_settle": no_settle_ms["ms_per_step"] if no_settle_ms and "ms_per_step" in no_settle_ms else None,
+            "no_settle_run": no_settle_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -528,6 +560,9 @@ def main():
                                     "encoding_backward_hbm": hbm_piece(SCATTER_KERNEL.get(args.workload), gather_bytes, pieces["encoding_backward"]),
                                     "optimizer_hbm": {"kernel": "k_adam" if args.workload == "c5" else "k_adam_prologue", "achieved": adam_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": adam_gbs / HBM_PEAK_GBS,
                                                       "bytes_per_launch": adam_bytes}},
+                         "pieces_note": "encoding_backward = the gradient kernels of the encoding (round 5: dL/dy into list order + the list-fed scatter); optimizer = its "
+                                        "launch, which since round 4 also runs the scatter's finalize pass and the sum of the MLP's weight-gradient slabs (k_adam_prologue) -- "
+                                        "those two were part of encoding_backward before",
                          "hbm_floor_frac": floor_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if step_ms > 0 else None,
                          "hbm_floor_bytes_per_step": floor_bytes},
         }

@@ -80,7 +80,9 @@ void switches_reload() {
 	w.side_jobs = !env_is("TCNN_AMD_SIDE_JOBS", '0');
 	w.live_image = !env_is("TCNN_AMD_LIVE_IMAGE", '0');
 	w.adam_steps32 = env_is("TCNN_AMD_ADAM_STEPS32", '1');
-	w.adam_in_flush = env_is("TCNN_AMD_ADAM_IN_FLUSH", '1');
+#ifdef TCNN_AMD_DEV
+	w.adam_in_flush = env_is("TCNN_AMD_ADAM_IN_FLUSH", '1'); // laboratory build only: a measured dead end (20 % slower), DESIGN.md "Dead ends measured in round 4"
+#endif
 	w.adam_in_reduce = !env_is("TCNN_AMD_ADAM_IN_REDUCE", '0');
 	w.adam_prologue = !env_is("TCNN_AMD_ADAM_PROLOGUE", '0');
 	w.adam_prologue_refused = env_is("TCNN_AMD_ADAM_PROLOGUE", 'r');

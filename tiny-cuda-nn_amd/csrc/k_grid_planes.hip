@@ -306,8 +306,18 @@ __global__ void __launch_bounds__(LISTS ? FP_LIST_THREADS : FP_THREADS) k_grid_f
 				if (!(lists.dev_flags & 1u))
 #endif
 				{ // (plain stores: streamed ones cost the scatter 13 us -- it reads the lists out of the Infinity Cache, which streamed stores pass by)
+#ifdef TCNN_AMD_DEV
+					if (lists.dev_flags & 8u) { // sc1: written through, not kept in this XCD's L2
+						const auto rs_e = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)(quads * 16u), 0x00020000);
+						const auto rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)sdst, 0, (int)(squads * 16u), 0x00020000);
+						for (uint32_t p = tid; p < quads; p += THREADS) __builtin_amdgcn_raw_buffer_store_b128(((const u4*)l_stage)[p], rs_e, p * 16u, 0, 16);
+						for (uint32_t p = tid; p < squads; p += THREADS) __builtin_amdgcn_raw_buffer_store_b128(((const u4*)l_sidx)[p], rs_s, p * 16u, 0, 16);
+					} else
+#endif
+					{
 					for (uint32_t p = tid; p < quads; p += THREADS) dst[p] = ((const u4*)l_stage)[p];
 					for (uint32_t p = tid; p < squads; p += THREADS) sdst[p] = ((const u4*)l_sidx)[p];
+					}
 				}
 			}
 		}

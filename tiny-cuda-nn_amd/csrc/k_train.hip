@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 		for (int i = 0; i < 4; ++i) rw[26 + i] = img_b[(size_t)(d.layers[0].bwd_off + i) * 64];
 	}
 	const uint32_t n_total = a.n * a.dims; // loss normalisation (relative_l2.h:58)
+	const LossScales lsc = loss_scales(n_total, a.loss_scale);
 	const uint32_t n_trips = a.n / S;
 	const uint32_t row0 = wave * NB * 16; // this wave's first row inside the LDS images
 
@@ -369,17 +370,9 @@ __global__ void __launch_bounds__(NW * 64) k_mlp_train(const MlpDesc d, const Tr
 									const uint32_t target_idx = sample * a.dims + j;
 									const float prediction = (float)ov[r];
 									const float pdf = to == 0 ? pre_pdf[b][r] : (a.data_pdf ? a.data_pdf[target_idx] : 1);
-									const float difference = prediction - (to == 0 ? pre_t[b][r] : a.target[target_idx]);
-									float gradient;
-									if (a.loss_type == (uint32_t)LossType::RelativeL2) {
-										const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-										value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total;
-										gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
-									} else {
-										value = difference * difference / pdf / n_total;
-										gradient = 2 * difference / pdf;
-									}
-									grad = (half_t)(a.loss_scale * gradient / n_total);
+									const float tgt = to == 0 ? pre_t[b][r] : a.target[target_idx];
+									if (a.loss_type == (uint32_t)LossType::RelativeL2) loss_l2_fused<true>(prediction, tgt, lsc, value, grad, a.data_pdf != nullptr, pdf);
+									else loss_l2_fused<false>(prediction, tgt, lsc, value, grad, a.data_pdf != nullptr, pdf);
 								}
 								lv[r] = value;
 								gv[r] = grad;

@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 	const uint32_t n_blocks = a.n / 32;
 	const uint32_t first = blockIdx.x * R32_NW + wave, step = gridDim.x * R32_NW;
 	const uint32_t n_total = a.n * a.dims; // loss normalisation (relative_l2.h:58)
+	const LossScales lsc = loss_scales(n_total, a.loss_scale);
 	const uint32_t n4 = a.n * 4;
 
 	// ---- global addressing: raw buffer accesses -- descriptor (scalar, per matrix) + a lane offset that never changes + a scalar offset of the
@@ -103,7 +104,10 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 	uint32_t t_off[2];
 #pragma unroll
 	for (int r = 0; r < 2; ++r) t_off[r] = (c * a.dims + min(2 * r + h, a.dims - 1)) * 4; // outputs >= dims re-read the last one (masked where used)
-	auto load_in = [&](const uint32_t blk) -> In {
+	auto load_in = [&](const uint32_t blk_) -> In {
+		// scalar for the compiler too: it is the scalar offset of every access below (left to the compiler the trip's block number lived in a
+		// vector register and every one of these loads and stores sat in a waterfall loop of its own -- v_readfirstlane, compare, branch: 22 per trip)
+		const uint32_t blk = __builtin_amdgcn_readfirstlane(blk_);
 		In r;
 #pragma unroll
 		for (int s = 0; s < 2; ++s) {
@@ -221,7 +225,8 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		for (uint32_t i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
 	}
 	uint32_t prio_phase = wave >= 4 ? 1u : 0u;
-	for (uint32_t blk = first; blk < n_blocks; blk += step) {
+	for (uint32_t blk_v = first; blk_v < n_blocks; blk_v += step) {
+		const uint32_t blk = __builtin_amdgcn_readfirstlane(blk_v); // (see load_in)
 		if (a.prio_mode == 1) { // wave-uniform
 			if (prio_phase & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 			prio_phase ^= 1u;
@@ -293,27 +298,17 @@ __global__ void __launch_bounds__(R32_NW * 64, 2) k_mlp_train_r32(const R32Args 
 		const h8 ov = pack8(o, 0); // element g: output 2 g + h (output activation None)
 		h8 dyf = h8{0, 0, 0, 0, 0, 0, 0, 0}; // dL/doutput, the B fragment of the first backward product (k = position)
 		{
-			// l2.h:40-74 / relative_l2.h:40-75, the same operations in the same order, the two output slots of a lane side by side (two
-			// independent chains of IEEE divisions); values and gradients of the live outputs go to the compact context matrices [n][dims]
+			// l2.h:40-74 / relative_l2.h:40-75 on one refined reciprocal (loss_l2_fused, mlp_device.h), the two output slots of a lane side by
+			// side; values and gradients of the live outputs go to the compact context matrices [n][dims]
 			float value[2];
 			half_t grad[2];
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
 				const float prediction = (float)ov[r];
-				const float difference = prediction - in.t[r];
-				float gradient;
 				if constexpr (DIAG & 8) {
-					value[r] = difference;
-					gradient = prediction;
-				} else if constexpr (LOSS == 2) {
-					const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-					value[r] = difference * difference / prediction_sq_plus_epsilon / n_total;
-					gradient = 2 * difference / prediction_sq_plus_epsilon;
-				} else {
-					value[r] = difference * difference / n_total;
-					gradient = 2 * difference;
-				}
-				grad[r] = (half_t)(a.loss_scale * gradient / n_total);
+					value[r] = prediction - in.t[r];
+					grad[r] = (half_t)(a.loss_scale * prediction / n_total);
+				} else loss_l2_fused<LOSS == 2>(prediction, in.t[r], lsc, value[r], grad[r]);
 			}
 			asm volatile("" : "+v"(value[0]), "+v"(value[1])); // both chains are evaluated here, in one block, not inside the masked stores below
 #pragma unroll

@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 	const uint32_t per_trip = gridDim.x * R32A_NW;
 	const uint32_t n_trips = (n_blocks + per_trip - 1) / per_trip; // the same for every wave of every workgroup: the barriers are workgroup-wide
 	const uint32_t n_total = a.n * a.dims;                         // loss normalisation (relative_l2.h:58)
+	const LossScales lsc = loss_scales(n_total, a.loss_scale);
 	const uint32_t n4 = a.n * 4;
 
 	// ---- the weights.  Fragment slots (R32Frags of this network); resident: F1, FO, B1, B0 (24 fragments)
@@ -248,18 +249,7 @@ __global__ void __launch_bounds__(R32A_NW * 64, 2) k_mlp_train_r32a(const R32Arg
 				half_t grad[2];
 #pragma unroll
 				for (int r = 0; r < 2; ++r) {
-					const float prediction = (float)ov[r];
-					const float difference = prediction - in.t[r];
-					float gradient;
-					if constexpr (LOSS == 2) {
-						const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-						value[r] = difference * difference / prediction_sq_plus_epsilon / n_total;
-						gradient = 2 * difference / prediction_sq_plus_epsilon;
-					} else {
-						value[r] = difference * difference / n_total;
-						gradient = 2 * difference;
-					}
-					grad[r] = (half_t)(a.loss_scale * gradient / n_total);
+					loss_l2_fused<LOSS == 2>((float)ov[r], in.t[r], lsc, value[r], grad[r]); // l2.h:40-74 / relative_l2.h:40-75 on one refined reciprocal (mlp_device.h)
 				}
 				asm volatile("" : "+v"(value[0]), "+v"(value[1])); // both chains are evaluated here, in one block, not inside the masked stores below
 #pragma unroll

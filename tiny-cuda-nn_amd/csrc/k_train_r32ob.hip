@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(OB_NW * 64, 1) k_mlp_train_r32ob(const ObArgs 
 	const uint32_t first = blockIdx.x * OB_NW + wave, per_trip = gridDim.x * OB_NW;
 	const uint32_t n_trips = (n_blocks + per_trip - 1) / per_trip; // the same for every wave of every workgroup: the barriers are workgroup-wide
 	const uint32_t n_total = a.n * a.dims;
+	const LossScales lsc = loss_scales(n_total, a.loss_scale);
 
 	// ---- inputs of a trip: this lane's coordinate (dimension h of sample c) and its targets
 	uint32_t t_off[2];
@@ -260,18 +261,7 @@ __global__ void __launch_bounds__(OB_NW * 64, 1) k_mlp_train_r32ob(const ObArgs 
 				half_t grad[2];
 #pragma unroll
 				for (int r = 0; r < 2; ++r) {
-					const float prediction = (float)ov[r];
-					const float difference = prediction - in.t[r];
-					float gradient;
-					if constexpr (LOSS == 2) {
-						const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-						value[r] = difference * difference / prediction_sq_plus_epsilon / n_total;
-						gradient = 2 * difference / prediction_sq_plus_epsilon;
-					} else {
-						value[r] = difference * difference / n_total;
-						gradient = 2 * difference;
-					}
-					grad[r] = (half_t)(a.loss_scale * gradient / n_total);
+					loss_l2_fused<LOSS == 2>((float)ov[r], in.t[r], lsc, value[r], grad[r]); // l2.h:40-74 / relative_l2.h:40-75 on one refined reciprocal (mlp_device.h)
 					const bool live = 2 * r + h < a.dims;
 					if (!live) { value[r] = 0.0f; grad[r] = (half_t)0.0f; }
 					dyf[r] = grad[r];
@@ -443,6 +433,7 @@ __global__ void __launch_bounds__(OB_NW * 64, 1) k_mlp_train_r32ob_acc(const ObA
 	const uint32_t n_blocks = a.n / 32;
 	const uint32_t first = blockIdx.x * OB_NW + wave, step = gridDim.x * OB_NW;
 	const uint32_t n_total = a.n * a.dims;
+	const LossScales lsc = loss_scales(n_total, a.loss_scale);
 
 	// ---- inputs of a trip: this lane's coordinate (dimension h of sample c) and its targets
 	uint32_t t_off[2];
@@ -626,18 +617,7 @@ __global__ void __launch_bounds__(OB_NW * 64, 1) k_mlp_train_r32ob_acc(const ObA
 			half_t grad[2];
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
-				const float prediction = (float)ov[r];
-				const float difference = prediction - in.t[r];
-				float gradient;
-				if constexpr (LOSS == 2) {
-					const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-					value[r] = difference * difference / prediction_sq_plus_epsilon / n_total;
-					gradient = 2 * difference / prediction_sq_plus_epsilon;
-				} else {
-					value[r] = difference * difference / n_total;
-					gradient = 2 * difference;
-				}
-				grad[r] = (half_t)(a.loss_scale * gradient / n_total);
+				loss_l2_fused<LOSS == 2>((float)ov[r], in.t[r], lsc, value[r], grad[r]); // l2.h:40-74 / relative_l2.h:40-75 on one refined reciprocal (mlp_device.h)
 				const bool live = 2 * r + h < a.dims;
 				if (!live) { value[r] = 0.0f; grad[r] = (half_t)0.0f; }
 				dyf[r] = grad[r];

@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(W_NW * 64, 1) k_mlp_train_r32w(const WArgs a) 
 	const uint32_t n_blocks = a.n / 32;
 	const uint32_t n_trips = (n_blocks + gridDim.x * W_NW - 1) / (gridDim.x * W_NW); // the same for every wave of every workgroup: the barriers are workgroup-wide
 	const uint32_t n_total = a.n * a.dims;
+	const LossScales lsc = loss_scales(n_total, a.loss_scale);
 	const uint32_t n8 = a.n * 8; // bytes per level plane
 
 	// weight fragment f: one 16-byte load per lane from the image (L2-resident: 108 KiB read by every wave of the chip)
@@ -203,18 +204,7 @@ __global__ void __launch_bounds__(W_NW * 64, 1) k_mlp_train_r32w(const WArgs a) 
 				half_t grad[2];
 #pragma unroll
 				for (int r = 0; r < 2; ++r) {
-					const float prediction = (float)ov[r];
-					const float difference = prediction - tg[r];
-					float gradient;
-					if constexpr (LOSS == 2) {
-						const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-						value[r] = difference * difference / prediction_sq_plus_epsilon / n_total;
-						gradient = 2 * difference / prediction_sq_plus_epsilon;
-					} else {
-						value[r] = difference * difference / n_total;
-						gradient = 2 * difference;
-					}
-					grad[r] = (half_t)(a.loss_scale * gradient / n_total);
+					loss_l2_fused<LOSS == 2>((float)ov[r], tg[r], lsc, value[r], grad[r]); // l2.h:40-74 / relative_l2.h:40-75 on one refined reciprocal (mlp_device.h)
 					const bool live = 2 * r + h < a.dims;
 					if (!live) { value[r] = 0.0f; grad[r] = (half_t)0.0f; }
 					dyf[r] = grad[r];

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(REGS_NW * 64, 2) k_mlp_train_regs(const MlpDes
 	const uint32_t n_blocks = a.n / 16;
 	const uint32_t first = blockIdx.x * REGS_NW + wave, step = gridDim.x * REGS_NW;
 	const uint32_t n_total = a.n * a.dims; // loss normalisation (relative_l2.h:58)
+	const LossScales lsc = loss_scales(n_total, a.loss_scale);
 	const uint32_t in_w = 16 * IN_T;
 	// OUTPUT ROWS.  The output layer's fragments are permuted while they are copied to LDS (below) so that accumulator register r
 	// of lane (c, q) holds output q + 4 r of sample c instead of 4 q + r: with n_output_dims <= 4 every lane quarter then has ONE
@@ -375,24 +376,14 @@ __global__ void __launch_bounds__(REGS_NW * 64, 2) k_mlp_train_regs(const MlpDes
 			if constexpr (LOSS == 0) {
 				gv = aux.dy;
 			} else {
-				// l2.h:40-74 / relative_l2.h:40-75, the same operations in the same order.  Values and gradients of the live
+				// l2.h:40-74 / relative_l2.h:40-75 on one refined reciprocal (loss_l2_fused, mlp_device.h).  Values and gradients of the live
 				// outputs go to the compact context matrices [n][dims].
 				char* gb = (char*)a.dL_dout + (size_t)blk * (32 * a.dims);
 				char* lb = (char*)a.L + (size_t)blk * (64 * a.dims);
 				auto loss_row = [&](const int r) {
-					const float prediction = (float)ov[r];
-					const float difference = prediction - aux.t[r];
-					const float pdf = aux.pdf[r];
-					float value, gradient;
-					if constexpr (LOSS == 2) {
-						const float prediction_sq_plus_epsilon = prediction * prediction + 0.01f;
-						value = difference * difference / prediction_sq_plus_epsilon / pdf / n_total; // pdf = 1 without data_pdf: exact
-						gradient = 2 * difference / prediction_sq_plus_epsilon / pdf;
-					} else {
-						value = difference * difference / pdf / n_total;
-						gradient = 2 * difference / pdf;
-					}
-					const half_t grad = (half_t)(a.loss_scale * gradient / n_total);
+					float value;
+					half_t grad;
+					loss_l2_fused<LOSS == 2>((float)ov[r], aux.t[r], lsc, value, grad, has_pdf, aux.pdf[r]);
 					const bool live = q + 4 * r < a.dims;
 					gv[r] = live ? grad : (half_t)0.0f;
 					if (live) st32_stream(gb + 8 * r, cg_off, grad);

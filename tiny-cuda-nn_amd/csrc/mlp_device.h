@@ -112,5 +112,29 @@ __device__ inline void store_dx_record(half_t* base, uint32_t F, uint32_t D, uin
 	}
 }
 
+
+// ---- L2 / RelativeL2 inside the fused training kernels (losses/l2.h:40-74, relative_l2.h:40-75):
+//     value = d^2 / (p^2 + 0.01) / pdf / n_total,   dL/dy = (half)(loss_scale * (2 d / (p^2 + 0.01) / pdf) / n_total),   d = p - target.
+// Floating point, so its bar is the north-star tolerance, not bit equality with the reference's order of operations: ONE reciprocal
+// (v_rcp_f32 refined by one Newton step) serves value and gradient, and the two divisions by n_total are multiplications by constants
+// computed once per kernel -- 13 dependent instructions where four IEEE divisions were ~100 (the loss was 940 of a wave's 5.9 k clocks
+// per trip in k_mlp_train_r32).  Against the reference's order (the oracle; k_loss keeps it): values within 4 ulp, >= 99.9 % of the half
+// gradients identical and the rest one half-ulp apart (tests/test_losses.py::test_fused_loss_against_the_exact_order).
+struct LossScales { float inv_n_total, scale_over_n; };
+__device__ inline LossScales loss_scales(const uint32_t n_total, const float loss_scale) { return LossScales{1.0f / (float)n_total, loss_scale / (float)n_total}; }
+template <bool RELATIVE>
+__device__ inline void loss_l2_fused(const float prediction, const float target, const LossScales& k, float& value, half_t& grad, const bool has_pdf = false, const float pdf = 1.0f) {
+	const float d = prediction - target;
+	float dr = d; // d / (p^2 + 0.01) / pdf
+	if constexpr (RELATIVE) {
+		const float q = __builtin_fmaf(prediction, prediction, 0.01f);
+		const float r0 = __builtin_amdgcn_rcpf(q);
+		dr = d * __builtin_fmaf(r0, __builtin_fmaf(-q, r0, 1.0f), r0);
+	}
+	if (has_pdf) dr = dr / pdf; // (uniform; relative_l2.h:66-70: an optional importance-sampling density)
+	value = d * dr * k.inv_n_total;
+	grad = (half_t)((dr + dr) * k.scale_over_n);
+}
+
 } // namespace
 } // namespace tcnn_amd

@@ -727,12 +727,10 @@ public:
 		if (want == 0) return false;
 		if (m_any_binned || n > grid_hit_max_samples(m_meta) || m_meta.n_pos_dims > 3 || m_meta.hash_type == (uint32_t)HashType::Rng) return false; // (Rng: its hash is a loop)
 		if (want == 1) return true;
-		// Where it pays: grids with levels of many chunks, and batches whose record planes (16 bytes per sample and level pair) an XCD's 4 MB L2
-		// can serve -- measured on C3a, step with lists / with bit planes in ms: 2^16 0.140 / 0.131 (960 tasks of a few hundred elements
-		// each are all start-up and flush), 2^17 0.164 / 0.165, 2^18 0.202 / 0.224, 2^19 0.329 / 0.340, 2^20 0.599 / 0.587, 2^21 1.247 / 1.112
-		// (planes of 16 - 32 MB: the owners' gathers run at the Infinity Cache's pace once their positions drift apart, while the
-		// bit-plane kernel's tasks, paced by their scans, stay in step and keep finding each other's lines in the L2).
-		return grid_scatter_prefers_lists(m_meta) && n >= (1u << 17) && n <= (1u << 19);
+		// Where it pays: grids with levels of many chunks, at every batch size -- nothing in the list-fed form depends on what an L2 holds
+		// (round 4's gathered 16-byte records from one plane per XCD and was kept to 2^17 .. 2^19 samples).  C3a, step with lists / with
+		// bit planes in ms (profiles/r05_sweep.txt): 2^14 0.086 / 0.088, 2^16 0.120 / 0.128, 2^18 0.194 / 0.222, 2^20 0.474 / 0.584, 2^21 0.862 / 1.123.
+		return grid_scatter_prefers_lists(m_meta);
 	}
 	static size_t next_multiple_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 	struct HitCounters {

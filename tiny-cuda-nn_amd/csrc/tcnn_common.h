@@ -50,7 +50,7 @@ struct Switches {
 	bool side_jobs = true;        // TCNN_AMD_SIDE_JOBS=0: k_mlp_prep and the slab reduction as launches of their own
 	bool live_image = true;       // TCNN_AMD_LIVE_IMAGE=0: k_mlp_prep every step
 	bool adam_steps32 = false;    // TCNN_AMD_ADAM_STEPS32=1: uint32 update counts from the start
-	bool adam_in_flush = false;   // TCNN_AMD_ADAM_IN_FLUSH=1: Adam applied by the scatter's chunk owners
+	bool adam_in_flush = false;   // laboratory build only (TCNN_AMD_ADAM_IN_FLUSH=1): Adam applied by k_grid_scatter's chunk owners -- measured slower, not in the product
 	bool adam_in_reduce = true;   // TCNN_AMD_ADAM_IN_REDUCE=0: k_adam as a launch of its own for models without encoding parameters
 	bool adam_prologue = true;    // TCNN_AMD_ADAM_PROLOGUE=0: the scatter's finalize pass (+ slab reduction) as a launch of its own in front of k_adam
 	bool adam_prologue_refused = false; // TCNN_AMD_ADAM_PROLOGUE=refuse (tests): the optimizer is offered the prologue and turns it down, as it does for shapes its launch does not take
