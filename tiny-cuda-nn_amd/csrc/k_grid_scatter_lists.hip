@@ -37,9 +37,15 @@ namespace tcnn_amd {
 namespace {
 
 constexpr uint32_t SL_ACC_BYTES = 64 * 1024;
-constexpr uint32_t SL_THREADS = 512;
+#ifndef TCNN_SL_THREADS
+#define TCNN_SL_THREADS 512
+#endif
+#ifndef TCNN_SL_WINDOW
+#define TCNN_SL_WINDOW 1536
+#endif
+constexpr uint32_t SL_THREADS = TCNN_SL_THREADS;
 constexpr uint32_t SL_WAVES = SL_THREADS / 64;
-constexpr uint32_t SL_WINDOW = 1536;                  // elements of a wave's 64 runs looked up through one fill of its owner table
+constexpr uint32_t SL_WINDOW = TCNN_SL_WINDOW;        // elements of a wave's runs looked up through one fill of its owner table
 constexpr uint32_t SL_WAVE_LDS = SL_WINDOW + 256;     // per wave: owner table (one byte per element: the lane whose run holds it), the runs' positions
 constexpr uint32_t SL_LDS_BYTES = SL_ACC_BYTES + 256 + SL_WAVES * SL_WAVE_LDS; // accumulators, the waves' bound sums and the verdict, the waves' tables
 static_assert(2 * SL_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
@@ -665,7 +671,7 @@ __device__ inline void sl_run_task(const ScatterListsArgs& a, const uint32_t tas
 // measured: 71 - 78 us against 60 -- a workgroup that stays resident keeps its place in the oldest-first arbitration of its CU for the
 // whole launch, the pops cost a global round trip per task, and stealing across XCDs runs a task away from its record plane at half speed.)
 template <int D, int F>
-__global__ void __launch_bounds__(SL_THREADS, 4) k_grid_scatter_lists(const ScatterListsArgs a) {
+__global__ void __launch_bounds__(SL_THREADS, SL_THREADS / 128) k_grid_scatter_lists(const ScatterListsArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	sl_run_task<D, F>(a, blockIdx.x, smem);
 }
