@@ -211,9 +211,11 @@ MANY_CHUNK_CASES = [
 ]
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("enc_cfg", MANY_CHUNK_CASES)
-def test_grid_gradient_exact_many_chunks(tcnn, oracle, enc_cfg):
-    """The fused step's own route to dL/dgrid for big tables: k_grid_fwd_planes writes the sample filter as up to 1024 bit
+def test_grid_gradient_exact_many_chunks(tcnn, oracle, monkeypatch, enc_cfg, wide):
+    """(wide: TCNN_AMD_SCATTER_WIDE=1 -- every chunk of k_bin_accum through its 64-bit sums instead of two 32-bit sums per LDS add; the same bits.)
+    The fused step's own route to dL/dgrid for big tables: k_grid_fwd_planes writes the sample filter as up to 1024 bit
     planes per level and k_grid_scatter walks them.  Checked bit for bit through the C ABI of a whole
     NetworkWithInputEncoding: with no activation and weights in {-1, 0, 1} every sum of the MLP's backward pass is exact
     in fp32 whatever its order, so dL/d(encoded) has the oracle's bits and the grid gradients must equal the oracle's exact
@@ -221,6 +223,8 @@ def test_grid_gradient_exact_many_chunks(tcnn, oracle, enc_cfg):
     import torch
 
     n, n_in, n_out = 4096, 3, 16
+    if wide:
+        monkeypatch.setenv("TCNN_AMD_SCATTER_WIDE", "1")
     net_cfg = {"otype": "FullyFusedMLP", "activation": "None", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2}
     m = tcnn.NetworkWithInputEncoding(n_in, n_out, enc_cfg, net_cfg)
     native = m.native_tcnn_module

@@ -267,10 +267,17 @@ __global__ void __launch_bounds__(BIN_FILL_THREADS) k_bin_fill(
 template <int F>
 __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
 	const BinArgs a, const uint32_t n_slots, const uint32_t acc_bytes, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ base, const uint16_t* __restrict__ in_idx,
-	const half_t* __restrict__ in_val, half_t* __restrict__ grad, const int accumulate_mode, unsigned long long* __restrict__ dbg
+	const half_t* __restrict__ in_val, half_t* __restrict__ grad, const int accumulate_mode, unsigned long long* __restrict__ dbg, uint32_t* __restrict__ fallback_count, const int force_wide
 ) {
 	typedef typename VecOf<half_t, F>::type vecF;
 	typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	// Round 5: two features of an entry in ONE 64-bit LDS add as 2 x int32 (low half sign-extended into the high one), as in
+	// k_grid_scatter_lists.hip -- the adds are what this kernel's time is (LDS integer atomics: 3.9 us per chunk of 4096 entries x 4 features).
+	// The same proof: while sum |contribution| over everything the chunk receives (+ the largest existing gradient in Accumulate mode) stays
+	// below 120 of the 128 that 2^31 units of 2^-24 hold, no half can have overflowed; a chunk whose bound fails is zeroed and added again
+	// in 64 bits -- slower, never different (counted in *fallback_count).
+	__shared__ uint32_t s_bound[2][2]; // per chunk parity: {sum of the waves' |contribution| sums in units of 2^-20, largest |initial value| as float bits}
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	long long* acc = (long long*)smem;
 	lds_u64* acc_lds = (lds_u64*)smem;
@@ -287,6 +294,7 @@ __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
 	__shared__ SlotInfo slots[MAX_N_LEVELS + 1];
 	const uint32_t tid = threadIdx.x;
 
+	if (tid < 4) ((uint32_t*)s_bound)[tid] = 0;
 	if (tid == 0) { // chunks of all binned levels, numbered consecutively
 		uint32_t t = 0;
 		for (uint32_t s = 0; s < n_slots; ++s) {
@@ -332,9 +340,24 @@ __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
 #pragma unroll
 		for (int f = 0; f < F; ++f) __hip_atomic_fetch_add(acc_lds + entry * F + f, (unsigned long long)half_to_fixed_fast(c[f]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	};
+	float bsum = 0, bmax = 0; // this thread's share of the chunk's bound
+	auto pack2 = [](const float p0, const float p1) -> unsigned long long {
+		const int f0 = (int)(p0 * 16777216.0f), f1 = (int)(p1 * 16777216.0f); // exact below 128; beyond it the bound has failed anyway
+		return (unsigned long long)(uint32_t)f0 | ((unsigned long long)(uint32_t)(f1 + (f0 >> 31)) << 32); // f0 + f1 2^32 as one 64-bit integer
+	};
+	auto add_packed = [&](const uint32_t entry, const vecF& c) {
+#pragma unroll
+		for (int j = 0; j < F / 2; ++j) {
+			const float p0 = (float)c[2 * j], p1 = (float)c[2 * j + 1];
+			bsum += __builtin_fabsf(p0);
+			bsum += __builtin_fabsf(p1);
+			__hip_atomic_fetch_add(acc_lds + entry * (F / 2) + j, pack2(p0, p1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	};
 
 	uint32_t t = blockIdx.x;
 	if (t >= n_tasks) return;
+	uint32_t chunk_parity = 0;
 	Task cur, next;
 	locate(t, cur);
 	prefetch(cur);
@@ -345,18 +368,56 @@ __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
 		const uint32_t n_vals = entry_begin < si.size ? min(si.per_chunk, si.size - entry_begin) * F : 0u;
 		half_t* __restrict__ g = grad + ((size_t)si.offset + entry_begin) * F;
 
-		// ---- adds
-		if (accumulate_mode) { // GradientMode::Accumulate: the existing gradient joins the sum
-			for (uint32_t i = tid; i < n_vals; i += BIN_ACC_THREADS)
-				__hip_atomic_fetch_add(acc_lds + i, (unsigned long long)half_to_fixed(g[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
+		// ---- adds: packed (two 32-bit sums per LDS add) while the chunk's bound holds
+		const uint32_t par = chunk_parity;
+		chunk_parity ^= 1u;
+		const size_t list_at = (size_t)cur.slot * a.n * a.per_sample + cur.first;
+		bool packed_ok = !force_wide;
+		if (packed_ok) {
+			bsum = 0;
+			bmax = 0;
+			if (accumulate_mode) { // GradientMode::Accumulate: the existing gradient joins the sum
+				for (uint32_t i = tid; i < n_vals / 2; i += BIN_ACC_THREADS) {
+					const float g0 = (float)g[2 * i], g1 = (float)g[2 * i + 1];
+					bmax = fmaxf(bmax, fmaxf(__builtin_fabsf(g0), __builtin_fabsf(g1)));
+					if (!(__builtin_fabsf(g0) < 128.0f) || !(__builtin_fabsf(g1) < 128.0f)) bmax = 1e30f; // also NaN / inf
+					__hip_atomic_fetch_add(acc_lds + i, pack2(g0, g1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
 #pragma unroll
-		for (int p = 0; p < PRE; ++p) if (tid + p * BIN_ACC_THREADS < cur.count) add(e[p], v[p]);
-		{
-			const size_t at = (size_t)cur.slot * a.n * a.per_sample + cur.first;
-			for (uint32_t j = tid + PRE * BIN_ACC_THREADS; j < cur.count; j += BIN_ACC_THREADS) add(in_idx[at + j], ((const vecF*)in_val)[at + j]);
+			for (int p = 0; p < PRE; ++p) if (tid + p * BIN_ACC_THREADS < cur.count) add_packed(e[p], v[p]);
+			for (uint32_t j = tid + PRE * BIN_ACC_THREADS; j < cur.count; j += BIN_ACC_THREADS) add_packed(in_idx[list_at + j], ((const vecF*)in_val)[list_at + j]);
+			// the chunk's bound: the waves' sums meet in one LDS word (integers: the order does not matter), read behind the barrier the adds need anyway
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				bsum += __shfl_xor(bsum, o);
+				bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+			}
+			if ((tid & 63u) == 0) {
+				const float capped = bsum < 127.0f ? bsum : 127.0f; // (NaN compares false: 127)
+				__hip_atomic_fetch_add((lds_u32*)&s_bound[par][0], (uint32_t)(capped * 1048576.0f) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_fetch_max((lds_u32*)&s_bound[par][1], __builtin_bit_cast(uint32_t, bmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			lds_barrier(); // LDS only: a full __syncthreads() would also wait for the loads and stores in flight
+			packed_ok = (float)s_bound[par][0] * (1.0f / 1048576.0f) + __builtin_bit_cast(float, s_bound[par][1]) < 120.0f;
+			if (tid == 0) { s_bound[par ^ 1u][0] = 0; s_bound[par ^ 1u][1] = 0; } // the next chunk's words (nobody touches them before the flush's barrier)
 		}
-		lds_barrier(); // LDS only: a full __syncthreads() would also wait for the loads and stores in flight
+		if (!packed_ok) { // 64-bit sums: nothing to prove
+			if (!force_wide) {
+				if (fallback_count && tid == 0) atomicAdd(fallback_count, 1u);
+				typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+				for (uint32_t i = tid; i < (n_vals * 4 + 15) / 16; i += BIN_ACC_THREADS) ((u4*)smem)[i] = u4{0, 0, 0, 0}; // what the packed sums used
+				lds_barrier();
+			}
+			if (accumulate_mode) {
+				for (uint32_t i = tid; i < n_vals; i += BIN_ACC_THREADS)
+					__hip_atomic_fetch_add(acc_lds + i, (unsigned long long)half_to_fixed(g[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+#pragma unroll
+			for (int p = 0; p < PRE; ++p) if (tid + p * BIN_ACC_THREADS < cur.count) add(e[p], v[p]);
+			for (uint32_t j = tid + PRE * BIN_ACC_THREADS; j < cur.count; j += BIN_ACC_THREADS) add(in_idx[list_at + j], ((const vecF*)in_val)[list_at + j]);
+			lds_barrier();
+		}
 		lap(t_add);
 
 		// ---- next chunk's list on its way; the one after that located
@@ -370,6 +431,18 @@ __global__ void __launch_bounds__(BIN_ACC_THREADS) k_bin_accum(
 		// ---- flush: round once (two values per 4-byte store; n_vals is even because F >= 2), leave the accumulators zero
 		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 		typedef long long i64x2 __attribute__((ext_vector_type(2)));
+		if (packed_ok) { // one 64-bit word = the two sums of a pair; both fit 32 bits (that is what the bound proved)
+			auto round32 = [](const int v) -> half_t {
+				if (__builtin_expect((uint32_t)(v + (1 << 24)) < (1u << 25), 1)) return (half_t)((float)v * 5.9604644775390625e-08f); // |value| < 1: exact as a float, one rounding
+				return fixed_to_half((long long)v);
+			};
+			for (uint32_t i = tid; i < n_vals / 2; i += BIN_ACC_THREADS) {
+				const unsigned long long sum = ((unsigned long long*)acc)[i];
+				((unsigned long long*)acc)[i] = 0;
+				const int lo = (int)(uint32_t)sum, hi = (int)(uint32_t)((sum - (unsigned long long)(long long)lo) >> 32);
+				((h2*)g)[i] = h2{round32(lo), round32(hi)};
+			}
+		} else
 		for (uint32_t i = tid; i < n_vals / 2; i += BIN_ACC_THREADS) {
 			const i64x2 s = ((i64x2*)acc)[i];
 			((i64x2*)acc)[i] = i64x2{0, 0};
@@ -441,7 +514,7 @@ BinLayout bin_layout(const GridMeta& meta, const GridMeta* dev_meta, uint32_t n)
 }
 
 template <int D, int F>
-void launch_binned(hipStream_t s, const BinLayout& l, MatView x, const void* dy, uint32_t dss, uint32_t dsl, void* grad, bool accumulate, char* ws) {
+void launch_binned(hipStream_t s, const BinLayout& l, MatView x, const void* dy, uint32_t dss, uint32_t dsl, void* grad, bool accumulate, char* ws, uint32_t* fallback_count) {
 	const BinArgs& a = l.args;
 	uint32_t* counts = (uint32_t*)(ws + l.counts_off);
 	uint32_t* rel = (uint32_t*)(ws + l.rel_off);
@@ -466,7 +539,7 @@ void launch_binned(hipStream_t s, const BinLayout& l, MatView x, const void* dy,
 	static int timing_left = 3;
 	unsigned long long* dbg = nullptr;
 	if (timing && timing_left > 0) HIP_CHECK_THROW(hipMalloc(&dbg, acc_blocks * 4 * 8));
-	hipLaunchKernelGGL((k_bin_accum<F>), dim3(acc_blocks), dim3(BIN_ACC_THREADS), acc_bytes, s, a, l.n_slots, acc_bytes, totals, base, idx, val, (half_t*)grad, accumulate ? 1 : 0, dbg);
+	hipLaunchKernelGGL((k_bin_accum<F>), dim3(acc_blocks), dim3(BIN_ACC_THREADS), acc_bytes, s, a, l.n_slots, acc_bytes, totals, base, idx, val, (half_t*)grad, accumulate ? 1 : 0, dbg, fallback_count, switches().scatter_wide ? 1 : 0);
 	if (dbg) {
 		std::vector<unsigned long long> h(acc_blocks * 4);
 		HIP_CHECK_THROW(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
@@ -502,7 +575,7 @@ bool grid_bin_supported(const GridMeta& meta) {
 size_t grid_bin_workspace_bytes(const GridMeta& meta, uint32_t n) { return bin_layout(meta, nullptr, n).bytes; }
 
 void grid_backward_binned(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, MatView x, const void* dL_dy, uint32_t dy_stride_sample,
-                          uint32_t dy_stride_level, void* grad, bool accumulate, void* workspace) {
+                          uint32_t dy_stride_level, void* grad, bool accumulate, void* workspace, uint32_t* fallback_count) {
 	const BinLayout l = bin_layout(meta, dev_meta, n);
 	if (l.n_slots == 0 || n == 0) return;
 	CHECK_THROW(grid_bin_supported(meta) && workspace != nullptr);
@@ -514,8 +587,8 @@ void grid_backward_binned(hipStream_t stream, const GridMeta& meta, const GridMe
 	const uint32_t F = meta.n_features_per_level;
 	char* ws = (char*)workspace;
 #define TCNN_BIN(D) \
-	if (F == 2) launch_binned<D, 2>(stream, l, x, dL_dy, dy_stride_sample, dy_stride_level, grad, accumulate, ws); \
-	else launch_binned<D, 4>(stream, l, x, dL_dy, dy_stride_sample, dy_stride_level, grad, accumulate, ws);
+	if (F == 2) launch_binned<D, 2>(stream, l, x, dL_dy, dy_stride_sample, dy_stride_level, grad, accumulate, ws, fallback_count); \
+	else launch_binned<D, 4>(stream, l, x, dL_dy, dy_stride_sample, dy_stride_level, grad, accumulate, ws, fallback_count);
 	switch (meta.n_pos_dims) {
 		case 2: TCNN_BIN(2) break;
 		case 3: TCNN_BIN(3) break;

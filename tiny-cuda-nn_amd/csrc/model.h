@@ -560,7 +560,8 @@ public:
 				if (m_any_binned) { // levels cut into more than 64 chunks (k_grid_bin.hip)
 					CHECK_THROW(!(dy_planes && ctx.dy_records));
 					ArenaBuf workspace{stream, grid_bin_workspace_bytes(m_meta, n)};
-					grid_backward_binned(stream, m_meta, dev_meta(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, mode == GradientMode::Accumulate, workspace.data());
+					grid_backward_binned(stream, m_meta, dev_meta(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, mode == GradientMode::Accumulate, workspace.data(),
+					                     hit_counters(stream).fallbacks.as<uint32_t>());
 				}
 				if (tune) {
 					HIP_CHECK_THROW(hipStreamSynchronize(stream));

@@ -247,7 +247,8 @@ uint32_t grid_bin_max_chunks();                // chunks per level (4096)
 uint32_t grid_bin_acc_bytes();                 // LDS accumulators per workgroup = chunk size of binned levels
 size_t grid_bin_workspace_bytes(const GridMeta& meta, uint32_t n);
 void grid_backward_binned(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_meta, uint32_t n, MatView x, const void* dL_dy, uint32_t dy_stride_sample,
-                          uint32_t dy_stride_level, void* grad, bool accumulate, void* workspace);
+                          uint32_t dy_stride_level, void* grad, bool accumulate, void* workspace,
+                          uint32_t* fallback_count = nullptr); // (optional, device) chunks whose packed 32-bit sums could not be proven and were added again in 64 bits
 void grid_backward_input(hipStream_t stream, const GridMeta& meta, bool fp32, uint32_t n, const void* dL_dy, uint32_t dy_stride, const float* dy_dx, MatViewMut dL_dx);
 // second-order input gradients (k_grid_bwdbwd.hip; grid.h:352-650): each of grad (accumulated in place, GT = float if fp32_grad),
 // dL_ddLdy (T [n][dy_stride], needs dy_dx) and dL_dx (overwritten, needs grid) is optional
