@@ -829,10 +829,19 @@ def test_bench_configuration_scatter_forms_agree_at_full_batch(tcnn, oracle, mon
     g, out = grads({**fixed, "TCNN_AMD_GRID_SCATTER": "atomic"})
     assert np.array_equal(out, base_out)
     a, b = _f32(g), _f32(base_g)
-    # the reference's own formulation: at this batch the coarse levels take thousands of packed-fp16 atomic adds per entry, each one
-    # rounding the running sum -- 5.5 % of the gradient's norm measured here (the switch is read per model since round 4; before, the first
-    # model of the process decided and this variant never ran)
-    assert float(np.linalg.norm(a - b)) <= 1e-1 * float(np.linalg.norm(b))
+    # The reference's own formulation (grid.h:252-255,303-319: packed-fp16 atomic adds, every one rounding the running sum) against the exact
+    # sum, with a bound DERIVED from the hits instead of a constant: an entry of a level with h hits per entry on average accumulates h
+    # roundings of 2^-11 of its running sum -- which the final value bounds up to cancellation among its contributions (factor 2) -- so
+    # |error_e| <= 2 * 2^-11 * h_level * |exact_e|, and in norm over all entries that is the bound below.  (Measured: 5.5 % of the gradient's
+    # norm, nearly all of it on the coarse levels, where an entry takes thousands of adds.)
+    offsets = oracle.Trainer(2, 3, CONFIG_C3A, seed=1337).model.encoding.offsets.astype(np.int64) * 2  # parameters (2 features per entry)
+    allowed = np.zeros_like(b, dtype=np.float64)
+    for lo, hi in zip(offsets[:-1], offsets[1:]):
+        hits_per_entry = max(1.0, n * 4 / ((hi - lo) / 2))
+        allowed[lo:hi] = 2.0 * 2.0 ** -11 * hits_per_entry * np.abs(b[lo:hi].astype(np.float64))
+    assert float(np.linalg.norm(a - b)) <= float(np.linalg.norm(allowed)), (float(np.linalg.norm(a - b)), float(np.linalg.norm(allowed)), float(np.linalg.norm(b)))
+    fine = slice(int(offsets[6]), int(offsets[-1]))  # the hashed levels (2 hits per entry): the same kernel within 1 % there -- a real defect would show here
+    assert float(np.linalg.norm(a[fine] - b[fine])) <= 1e-2 * float(np.linalg.norm(b[fine]))
     assert np.array_equal(g == 0, base_g == 0) or np.count_nonzero((g == 0) != (base_g == 0)) < 1000  # the same entries are touched (an fp16 sum may cancel to zero)
 
 

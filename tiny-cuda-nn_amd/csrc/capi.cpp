@@ -7,6 +7,7 @@
 
 #include "model.h"
 
+#include <mutex>
 #include <string>
 
 using namespace tcnn_amd;
@@ -14,6 +15,7 @@ using namespace tcnn_amd;
 namespace {
 thread_local std::string g_last_error;
 tcnn_amd::Switches g_switches;
+std::mutex g_switches_mutex; // the switches are PROCESS-WIDE: every tcnn_create_* call re-reads the environment for all live models (tcnn_common.h)
 
 bool env_is(const char* name, char c) {
 	const char* e = getenv(name);
@@ -67,7 +69,10 @@ struct tcnn_train_ctx_s {
 };
 
 namespace tcnn_amd {
-const Switches& switches() { return g_switches; }
+Switches switches() {
+	std::lock_guard<std::mutex> lock{g_switches_mutex};
+	return g_switches;
+}
 void switches_reload() {
 	Switches w;
 	w.grid_planes = !env_is("TCNN_AMD_GRID_PLANES", '0');
@@ -91,6 +96,7 @@ void switches_reload() {
 	w.mlp_regs = !env_is("TCNN_AMD_MLP_REGS", '0');
 	w.mlp_fast = !env_is("TCNN_AMD_MLP_FAST", '0');
 	if (const char* e = getenv("TCNN_AMD_MLP_PRIO")) w.mlp_prio = (uint32_t)atoi(e);
+	std::lock_guard<std::mutex> lock{g_switches_mutex};
 	g_switches = w;
 }
 } // namespace tcnn_amd

@@ -398,58 +398,77 @@ struct ListGradArgs {
 	half_t* gvals; // [n_levels][n_items][item_capacity][F]
 };
 
+constexpr uint32_t LG_ITEMS = 2; // items per workgroup: the loads of both are in flight together (one item each: 12.5 us for 58 MB at 2^18 samples -- latency, not bytes)
 template <int F>
 __global__ void __launch_bounds__(LG_THREADS) k_grid_list_gradients(const ListGradArgs a) {
 	typedef typename VecOf<half_t, F>::type vecF;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	const uint32_t level = blockIdx.y, item = blockIdx.x;
+	const uint32_t level = blockIdx.y;
 	const uint32_t n_chunks = a.meta->levels[level].scatter_n_chunks;
 	if (n_chunks <= 1 || n_chunks > GRID_FILTER_MAX_CHUNKS || a.meta->levels[level].scatter_binned) return; // (workgroup-uniform) not a listed level
 	const GridHitLists& hl = a.lists;
-	vecF* g = (vecF*)smem;
-	const uint32_t first = item * hl.item_samples;
 	const half_t* dy = a.dL_dy + (size_t)level * a.dy_stride_level;
-	const uint32_t total = hl.heads[((size_t)level * GRID_HIT_HEADS + GRID_FILTER_MAX_CHUNKS) * hl.n_items + item];
-	const size_t region = ((size_t)level * hl.n_items + item) * hl.item_capacity;
-	const uint16_t* sidx = hl.sidx + region;
-	// Everything this workgroup reads is requested before anything is waited for: the item's sample numbers, four elements per thread and
-	// step (one 8-byte load; the forward kernel wrote whole quads of them -- what lies beyond the item's last element is stale but readable:
-	// clamped, and stored into positions nobody reads), then the item's slice of the gradient plane on its way into LDS.
+	// Everything this workgroup reads is requested before anything is waited for: the items' sample numbers, four elements per thread and
+	// step (one 8-byte load; the forward kernel wrote whole quads of them -- what lies beyond an item's last element is stale but readable:
+	// clamped, and stored into positions nobody reads), then the items' slices of the gradient plane on their way into LDS.
 	typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-	constexpr uint32_t PRE = 4; // steps whose sample numbers are in registers before the barrier (8 Ki elements per item: every shape in use)
-	u16x4 sv[PRE];
+	constexpr uint32_t PRE = 4; // steps whose sample numbers are in registers before the barrier (4 Ki elements per item: every shape in use)
+	u16x4 sv[LG_ITEMS][PRE];
+	uint32_t total[LG_ITEMS];
+	size_t region[LG_ITEMS];
 #pragma unroll
-	for (uint32_t k = 0; k < PRE; ++k) {
-		const uint32_t p = (k * LG_THREADS + threadIdx.x) * 4;
-		sv[k] = p < total ? *(const u16x4*)(sidx + p) : u16x4{0, 0, 0, 0};
+	for (uint32_t it = 0; it < LG_ITEMS; ++it) {
+		const uint32_t item = blockIdx.x * LG_ITEMS + it;
+		total[it] = item < hl.n_items ? hl.heads[((size_t)level * GRID_HIT_HEADS + GRID_FILTER_MAX_CHUNKS) * hl.n_items + item] : 0u;
+		region[it] = ((size_t)level * hl.n_items + min(item, hl.n_items - 1)) * hl.item_capacity;
 	}
-	for (uint32_t s = threadIdx.x; s < hl.item_samples; s += LG_THREADS) {
-		const uint32_t i = min(first + s, a.n - 1);
-		g[s] = *(const vecF*)&dy[(size_t)i * a.dy_stride_sample];
+#pragma unroll
+	for (uint32_t it = 0; it < LG_ITEMS; ++it) {
+		const uint16_t* sidx = hl.sidx + region[it];
+#pragma unroll
+		for (uint32_t k = 0; k < PRE; ++k) {
+			const uint32_t p = (k * LG_THREADS + threadIdx.x) * 4;
+			sv[it][k] = p < total[it] ? *(const u16x4*)(sidx + p) : u16x4{0, 0, 0, 0};
+		}
+	}
+#pragma unroll
+	for (uint32_t it = 0; it < LG_ITEMS; ++it) {
+		vecF* g = (vecF*)smem + it * hl.item_samples;
+		const uint32_t first = (blockIdx.x * LG_ITEMS + it) * hl.item_samples;
+		if (total[it] == 0) continue; // (workgroup-uniform)
+		for (uint32_t s = threadIdx.x; s < hl.item_samples; s += LG_THREADS) {
+			const uint32_t i = min(first + s, a.n - 1);
+			g[s] = *(const vecF*)&dy[(size_t)i * a.dy_stride_sample];
+		}
 	}
 	__syncthreads();
-	vecF* out = (vecF*)a.gvals + region;
 	const uint32_t last = hl.item_samples - 1;
-	auto place = [&](const uint32_t p, const u16x4 v) {
-		const vecF v0 = g[min((uint32_t)v[0], last)], v1 = g[min((uint32_t)v[1], last)], v2 = g[min((uint32_t)v[2], last)], v3 = g[min((uint32_t)v[3], last)];
-		if constexpr (F == 2) {
-			typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-			*(u4*)(out + p) = u4{__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1), __builtin_bit_cast(uint32_t, v2), __builtin_bit_cast(uint32_t, v3)};
-		} else {
-			out[p] = v0; out[p + 1] = v1; out[p + 2] = v2; out[p + 3] = v3;
-		}
-	};
 #pragma unroll
-	for (uint32_t k = 0; k < PRE; ++k) {
-		const uint32_t p = (k * LG_THREADS + threadIdx.x) * 4;
-		if (p < total) place(p, sv[k]);
+	for (uint32_t it = 0; it < LG_ITEMS; ++it) {
+		const vecF* g = (const vecF*)smem + it * hl.item_samples;
+		vecF* out = (vecF*)a.gvals + region[it];
+		const uint16_t* sidx = hl.sidx + region[it];
+		auto place = [&](const uint32_t p, const u16x4 v) {
+			const vecF v0 = g[min((uint32_t)v[0], last)], v1 = g[min((uint32_t)v[1], last)], v2 = g[min((uint32_t)v[2], last)], v3 = g[min((uint32_t)v[3], last)];
+			if constexpr (F == 2) {
+				typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+				*(u4*)(out + p) = u4{__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1), __builtin_bit_cast(uint32_t, v2), __builtin_bit_cast(uint32_t, v3)};
+			} else {
+				out[p] = v0; out[p + 1] = v1; out[p + 2] = v2; out[p + 3] = v3;
+			}
+		};
+#pragma unroll
+		for (uint32_t k = 0; k < PRE; ++k) {
+			const uint32_t p = (k * LG_THREADS + threadIdx.x) * 4;
+			if (p < total[it]) place(p, sv[it][k]);
+		}
+		for (uint32_t p = (PRE * LG_THREADS + threadIdx.x) * 4; p < total[it]; p += LG_THREADS * 4) place(p, *(const u16x4*)(sidx + p));
 	}
-	for (uint32_t p = (PRE * LG_THREADS + threadIdx.x) * 4; p < total; p += LG_THREADS * 4) place(p, *(const u16x4*)(sidx + p));
 }
 
 template <int F>
 void launch_list_gradients(hipStream_t s, const ListGradArgs& a, uint32_t n_levels) {
-	hipLaunchKernelGGL((k_grid_list_gradients<F>), dim3(a.lists.n_items, n_levels), dim3(LG_THREADS), a.lists.item_samples * F * 2, s, a);
+	hipLaunchKernelGGL((k_grid_list_gradients<F>), dim3(div_round_up(a.lists.n_items, LG_ITEMS), n_levels), dim3(LG_THREADS), LG_ITEMS * a.lists.item_samples * F * 2, s, a);
 	HIP_CHECK_THROW(hipGetLastError());
 }
 
@@ -808,7 +827,7 @@ void grid_backward_lists(hipStream_t stream, const GridMeta& meta, const GridMet
                          const MlpReduceJob* reduce_job, uint32_t* fallback_count) {
 	if (n_tasks == 0) return;
 	CHECK_THROW(lists.elems != nullptr && lists.sidx != nullptr && lists.heads != nullptr && lists.stragglers != nullptr && lists.counts != nullptr && lists.n_items > 0 && gvals != nullptr);
-	CHECK_THROW(lists.item_capacity % 8 == 0 && lists.item_samples <= 65536 && lists.item_samples * meta.n_features_per_level * 2 <= 64 * 1024);
+	CHECK_THROW(lists.item_capacity % 8 == 0 && lists.item_samples <= 65536 && lists.item_samples * meta.n_features_per_level * 2 * 2 <= 64 * 1024); // (k_grid_list_gradients: the slices of two items in LDS)
 	CHECK_THROW(n > 0 && n <= grid_hit_max_samples(meta) && meta.hash_type != (uint32_t)HashType::Rng);
 	// 32-bit byte offsets into a level's pool and into its dL/dy plane
 	CHECK_THROW((uint64_t)lists.n_items * lists.item_capacity * std::max<uint64_t>(GRID_HIT_WORDS * 4u, meta.n_features_per_level * 2u) < (1ull << 31));

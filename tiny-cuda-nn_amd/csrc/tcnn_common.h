@@ -37,8 +37,10 @@ constexpr uint32_t MAX_MLP_LAYERS = 16;
 inline uint32_t div_round_up(uint32_t v, uint32_t d) { return (v + d - 1) / d; }
 
 // The A/B switches of the training step and of inference (DESIGN.md "Switches"): every one defaults to the fast path, none changes a result
-// beyond what is stated there.  They are read from the environment ONCE PER MODEL -- when create_from_config / a module constructor runs
-// (switches_reload, capi.cpp) -- not per step: a process that wants another setting sets the variable and creates a new model.
+// beyond what is stated there.  They are read from the environment when create_from_config / a module constructor runs (switches_reload,
+// capi.cpp) -- not per step -- and the set is PROCESS-WIDE: creating a model under another environment changes the kernels of every live
+// model from its next call on (reads and the reload are serialised by a lock).  A process that wants another setting sets the variable and
+// creates its models afterwards; tests that compare two settings build one model at a time.
 struct Switches {
 	bool grid_planes = true;      // TCNN_AMD_GRID_PLANES=0: the AoS forward kernel inside the fused training step
 	bool grid_scatter_lds = true; // TCNN_AMD_GRID_SCATTER=atomic: the reference-shaped global-atomic gradient kernel
@@ -60,7 +62,7 @@ struct Switches {
 	bool mlp_fast = true;         // TCNN_AMD_MLP_FAST=0: k_mlp_train_regs with run-time formats
 	uint32_t mlp_prio = 1;        // TCNN_AMD_MLP_PRIO: wave priorities of the MLP kernels (0 none, 1 alternating per trip, 2, 3)
 };
-const Switches& switches();
+Switches switches(); // a copy of the process-wide set, taken under its lock
 void switches_reload();
 inline uint32_t next_multiple(uint32_t v, uint32_t d) { return div_round_up(v, d) * d; }
 
