@@ -851,6 +851,7 @@ LIST_SCATTER_CASES = [
     (2, 4096 + 256, CONFIG_C3B["encoding"]),
     (3, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 18, "base_resolution": 8, "per_level_scale": 2.0}),
     (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 17, "base_resolution": 16, "per_level_scale": 2.0}),
+    (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 17, "base_resolution": 16, "per_level_scale": 1.5}),  # (a level of 6724 entries: more than the 4096 one chunk holds at F = 4, fewer than 8192)
     (2, 4096, {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 8, "log2_hashmap_size": 14, "base_resolution": 16, "per_level_scale": 2.0}),
     (2, 8192, {"otype": "DenseGrid", "n_levels": 8, "n_features_per_level": 2, "base_resolution": 16, "per_level_scale": 1.5}),  # (8 levels: 16 features, no padding -- a padded encoding has no level planes and hence no lists)
     (2, 8192, {"otype": "TiledGrid", "n_levels": 8, "n_features_per_level": 2, "base_resolution": 128, "per_level_scale": 1.5}),

@@ -638,14 +638,25 @@ void grid_scatter_setup_levels(GridMeta& meta) {
 		const uint32_t bin_capacity = grid_bin_acc_bytes() / (meta.n_features_per_level * 8); // the binned kernels have their own chunk size
 		lv.scatter_binned = (lv.scatter_n_chunks > bin_above && div_round_up(lv.size, bin_capacity) <= grid_bin_max_chunks() && grid_bin_supported(meta)) ? 1u : 0u;
 		if (lv.scatter_binned) cut(lv, bin_capacity);
+	}
+	bool any_binned = false;
+	for (uint32_t l = 0; l < meta.n_levels; ++l) any_binned |= meta.levels[l].scatter_binned != 0;
+	for (uint32_t l = 0; l < meta.n_levels; ++l) {
+		GridLevel& lv = meta.levels[l];
 		// Round 4: a level that fits fewer chunks than the filter can describe is cut finer anyway -- into up to 64 chunks of at least 256
 		// entries -- where the scatter gathers one record per hit (the forms with records).  Every chunk then has ONE owner whatever the
 		// level's size: a level of 16 384 entries used to be 2 chunks shared by ~35 workgroups each (split over the samples), every one
 		// of them flushing 16 384 64-bit global atomics into the scratch table (~10 us per task, measured) for the finalize pass to round;
-		// as 64 chunks of 256 entries it is 64 tasks like those of the hashed levels, no scratch, no atomics.  Levels below 8192 entries
-		// stay one chunk: their tasks stream the samples in order (no gathers) and their flush is small.  TCNN_AMD_SCATTER_FINE_CUT=0: as before.
+		// as 64 chunks of 256 entries it is 64 tasks like those of the hashed levels, no scratch, no atomics.  Levels that fit ONE chunk
+		// (8192 entries at two features per entry) stay one chunk: their tasks stream the samples in order (no gathers) and their flush is small.
+		// (Round 5: where the hit lists feed the scatter the limit is the chunk's capacity, not 8192 entries -- with four features a level of
+		// 4097 .. 8191 entries was TWO chunks with one owner each, 2^18 elements per task where the others have 8192: 0.79 ms for the launch.
+		// A grid with binned levels never takes the lists (model.h hit_lists_usable), and its bit-plane tasks, split over the samples, serve
+		// such a level better as two chunks than as sixteen: 87 against 110 us.  profiles/r05_shape_sweep.txt.)
+		// TCNN_AMD_SCATTER_FINE_CUT=0: as before.
 		static const bool fine_cut = [] { const char* e = getenv("TCNN_AMD_SCATTER_FINE_CUT"); return !(e && e[0] == '0'); }();
-		if (fine_cut && prefers_lists && !lv.scatter_binned && lv.size >= 8192 && lv.scatter_n_chunks < SCATTER_MAX_CHUNKS) {
+		const uint32_t cut_from = any_binned ? std::max(capacity, 8192u) : capacity;
+		if (fine_cut && prefers_lists && !lv.scatter_binned && lv.size >= cut_from && lv.scatter_n_chunks < SCATTER_MAX_CHUNKS) {
 			const uint32_t per_chunk = std::min(capacity, std::max(256u, next_multiple(div_round_up(lv.size, SCATTER_MAX_CHUNKS), 8u)));
 			cut(lv, per_chunk);
 		}

@@ -126,22 +126,27 @@ __device__ inline void sl_add_entry(lds_u64* acc, const uint32_t index, const ha
 // in half the vector instructions -- the owners are bound by their vector instructions once nothing gathers (5 - 6 us of a task's 8 with
 // every load and LDS add taken out, profiles/r05_scatter_dev.txt) --: the two features of a pair in one packed multiply (weight A is the
 // low half of `weights`, weight B the high one), half -> scaled float in one v_fma_mix_f32 (exact: a half times 2^24), and the task's
-// bound from the ELEMENT: weight A + weight B <= 1.0005, so |g| bounds the two products' sum -- two instructions per pair instead of
-// four.  No test per corner: an element without a corner B names A's entry twice, the second time with weight +0 (GridHitLists).
+// bound from the ELEMENT: |g| (weight A + weight B) bounds the two products' sum within the half roundings the limit's margin covers -- one
+// instruction per element and two per pair instead of four per pair.  (With |g| alone, the weights' sum taken as 1, a sample's 2^(D-1) row
+// elements each charged the whole |g|: the bound came out 2x (2-D) / 4x (3-D) the sum it stands for, and 838 of a 3-D grid's ~1000 tasks went
+// through the 64-bit passes for nothing, profiles/r05_shape_sweep.txt.)  No test per corner: an element without a corner B names A's entry
+// twice, the second time with weight +0 (GridHitLists).
 template <int F, typename vecF>
 __device__ inline void sl_add_element_packed(lds_u64* acc, const uint32_t entries, const uint32_t weights, const vecF& gv, float& bound) {
 	typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 	const float two24 = 16777216.0f;
 	lds_u64* pa = (lds_u64*)((__attribute__((address_space(3))) char*)acc + (entries & 0xffffu) * (F * 4u));
 	lds_u64* pb = (lds_u64*)((__attribute__((address_space(3))) char*)acc + (entries >> 16) * (F * 4u));
+	float ws; // weight A + weight B
+	asm("v_fma_mix_f32 %0, %1, 1.0, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(ws) : "v"(weights));
 #pragma unroll
 	for (int j = 0; j < F / 2; ++j) {
 		const uint32_t g2 = __builtin_bit_cast(uint32_t, (h2{gv[2 * j], gv[2 * j + 1]}));
 		uint32_t qa, qb;
 		asm("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(qa) : "v"(g2), "v"(weights));               // (GRAD_T) weight * grad in fp16, grid.h:254
 		asm("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(qb) : "v"(g2), "v"(weights));
-		asm("v_fma_mix_f32 %0, |%1|, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(bound) : "v"(g2));
-		asm("v_fma_mix_f32 %0, |%1|, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(bound) : "v"(g2));
+		asm("v_fma_mix_f32 %0, |%1|, %2, %0 op_sel_hi:[1,0,0]" : "+v"(bound) : "v"(g2), "v"(ws));
+		asm("v_fma_mix_f32 %0, |%1|, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(bound) : "v"(g2), "v"(ws));
 		auto add = [&](lds_u64* at, const uint32_t q) {
 			float s0, s1;
 			asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(s0) : "v"(q), "v"(two24));
