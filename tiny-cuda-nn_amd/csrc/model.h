@@ -731,6 +731,11 @@ public:
 		// Where it pays: grids with levels of many chunks, at every batch size -- nothing in the list-fed form depends on what an L2 holds
 		// (round 4's gathered 16-byte records from one plane per XCD and was kept to 2^17 .. 2^19 samples).  C3a, step with lists / with
 		// bit planes in ms (profiles/r05_sweep.txt): 2^14 0.086 / 0.088, 2^16 0.120 / 0.128, 2^18 0.194 / 0.222, 2^20 0.474 / 0.584, 2^21 0.862 / 1.123.
+		// Below 2^16 samples a 2-D grid's bit planes are level with them or ahead -- two launches and 64 KiB of accumulators per task for a hundred
+		// elements; other 2-D grids at 2^12 / 2^14 / 2^16 (profiles/r05_shape_sweep.txt): T = 2^17 0.057 / 0.047, 0.056 / 0.051, 0.079 / 0.079;
+		// F = 4 0.063 / 0.034, 0.050 / 0.040, 0.060 / 0.058.  In 3-D the bit-plane form tests four rows per sample and chunk and loses everywhere
+		// (2^12: 0.098 / 0.147, 2^18: 0.33 / 1.44).
+		if (m_meta.n_pos_dims == 2 && n < (1u << 16)) return false;
 		return grid_scatter_prefers_lists(m_meta);
 	}
 	static size_t next_multiple_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
