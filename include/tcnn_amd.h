@@ -203,6 +203,7 @@ size_t tcnn_trainer_optimizer_prologue_steps(tcnn_trainer_t t);
  * kernel (k_grid_scatter_lists: hit lists written by the forward kernel) rather than the bit-plane, binned or atomic forms -- tests assert
  * which kernel produced the gradients they compare with the oracle (replaces kernel_grid_backward, grid.h:215-320). */
 size_t tcnn_trainer_list_scatters(tcnn_trainer_t t);
+size_t tcnn_module_list_scatters(tcnn_module_t m); /* the same count for a module's grid encoding(s) (callers with their own network) */
 /* Introspection: 1 when this context owns the network's weight-gradient slabs because their reduction was left to the optimizer's
  * launch (tcnn_trainer_optimizer_prologue_steps): they must outlive training_step()'s own scope, until that launch is enqueued. */
 int tcnn_train_ctx_keeps_weight_gradient_slabs(tcnn_trainer_t t, tcnn_train_ctx_t ctx);

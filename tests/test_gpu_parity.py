@@ -156,6 +156,57 @@ SCATTER_CASES = [
 ]
 
 
+ROWS_CASES = [
+    # (n_in, encoding config, n, list-fed gradient kernel expected): the encoded batch as a MATRIX (callers with their own network)
+    (2, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0}, 65536, True),
+    (2, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0}, 4096, False),  # (2-D below 2^16 samples: bit planes)
+    (3, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 18, "base_resolution": 8, "per_level_scale": 2.0}, 8192, True),
+    (3, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 16, "base_resolution": 8, "per_level_scale": 2.0}, 4096, False),
+    (2, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 17, "base_resolution": 16, "per_level_scale": 1.5}, 65536, True),
+    (2, {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 8, "log2_hashmap_size": 12, "base_resolution": 16, "per_level_scale": 2.0}, 2048, False),
+    (3, {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 2, "log2_hashmap_size": 18, "base_resolution": 8, "per_level_scale": 2.0}, 4096, True),  # (12 features: an Encoding module pads to a multiple of F only)
+]
+
+
+@pytest.mark.parametrize("n_in,enc_cfg,n,lists", ROWS_CASES)
+def test_encoded_matrix_through_the_plane_kernel(tcnn, oracle, monkeypatch, n_in, enc_cfg, n, lists):
+    """tcnn_module_forward / _backward of an Encoding module (the PyTorch binding's path, bindings.cpp:79-174; also a grid nested in a
+    Composite): the matrix [n][features] comes from k_grid_fwd_planes + k_planes_to_rows and, where the grid takes them, dL/dgrid from the hit
+    lists with dL/dy transposed into level planes -- the same bits as the AoS kernel's output (TCNN_AMD_GRID_ROWS_PLANES=0), the oracle's
+    output (grid.h:58-213) and the oracle's exact gradient (grid.h:215-320 with one final rounding)."""
+    ref = oracle.create_encoding(n_in, enc_cfg, alignment=0)
+    params_h = oracle.half_bits(oracle.Pcg32(3).uniform_strided(ref.n_params, -1.0, 1.0))
+    x = oracle.Pcg32(42).uniform_strided(n * n_in).reshape(n, n_in)
+    x[:4] = np.float32([[0.0] * n_in, [1.0] * n_in, [0.5] * n_in, [0.999999] * n_in])
+    width = ref.padded_output_width
+    dy = oracle.half_bits(oracle.Pcg32(9).uniform_strided(n * width, -2.0, 2.0).reshape(n, width))
+    dy[::7] = 0
+    want_g = np.zeros(ref.n_params, dtype=np.uint16)
+    ref.backward_exact(x, dy, want_g)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        native = tcnn.Encoding(n_in, enc_cfg).native_tcnn_module
+        xt, pt = _t(x), _t(params_h.view(np.float16)).requires_grad_(True)
+        ctx, out = native.fwd(xt, pt)
+        _, g = native.bwd(ctx, xt, pt, out, _t(dy.view(np.float16)))
+        with_grad = _bits(out).copy()
+        _, out_inf = native.fwd(xt, pt.detach())  # inference: no context, no lists
+        res = with_grad, _bits(out_inf).copy(), _bits(g).copy(), native.list_scatters()
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
+
+    out, out_inf, g, n_lists = run({})
+    out0, out_inf0, g0, n_lists0 = run({"TCNN_AMD_GRID_ROWS_PLANES": "0"})
+    assert n_lists == (1 if lists else 0) and n_lists0 == 0
+    assert np.array_equal(out, out0) and np.array_equal(out_inf, out0) and np.array_equal(out_inf0, out0)
+    assert np.array_equal(g, want_g) and np.array_equal(g0, want_g)
+    want_out, _ = ref.forward(x, params_h)
+    assert np.array_equal(out.reshape(n, width), want_out)
+
+
 @pytest.mark.parametrize("n_in,enc_cfg,n", SCATTER_CASES)
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_grid_gradient_exact(tcnn, oracle, n_in, enc_cfg, n, accumulate):

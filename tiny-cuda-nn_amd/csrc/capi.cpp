@@ -76,6 +76,7 @@ Switches switches() {
 void switches_reload() {
 	Switches w;
 	w.grid_planes = !env_is("TCNN_AMD_GRID_PLANES", '0');
+	w.grid_rows_planes = !env_is("TCNN_AMD_GRID_ROWS_PLANES", '0');
 	{ const char* e = getenv("TCNN_AMD_GRID_SCATTER"); w.grid_scatter_lds = !(e && std::string{e} == "atomic"); }
 	w.scatter_records = !env_is("TCNN_AMD_SCATTER_RECORDS", '0');
 	w.scatter_tune = !env_is("TCNN_AMD_SCATTER_TUNE", '0');
@@ -229,6 +230,7 @@ void tcnn_context_destroy(tcnn_context_t ctx) { delete ctx; }
 uint32_t tcnn_module_n_input_dims(tcnn_module_t m) { return m->model->input_width(); }
 uint32_t tcnn_module_n_output_dims(tcnn_module_t m) { return m->model->padded_output_width(); }
 size_t tcnn_module_n_params(tcnn_module_t m) { return m->model->n_params(); }
+size_t tcnn_module_list_scatters(tcnn_module_t m) { return (size_t)m->model->list_scatters(); }
 int tcnn_module_param_precision(tcnn_module_t m) { return (int)m->model->precision(); }
 int tcnn_module_output_precision(tcnn_module_t m) { return (int)m->model->precision(); }
 

@@ -499,4 +499,60 @@ void grid_forward_planes(hipStream_t stream, const GridMeta& meta, const GridMet
 #undef TCNN_PLANES_F
 }
 
+// Level planes [level][n][F] (what k_grid_fwd_planes writes) -> rows [n][row_words] of the same halves, as 32-bit words: 64 samples per
+// workgroup through LDS, both sides coalesced (a level's 64 x F / 2 words are contiguous in the planes, a tile's 64 rows in the output).
+namespace {
+constexpr uint32_t PR_THREADS = 256, PR_SAMPLES = 64, PR_MAX_WORDS = 128;
+__global__ void __launch_bounds__(PR_THREADS) k_planes_to_rows(const uint32_t* __restrict__ planes, uint32_t* __restrict__ rows, const uint32_t n, const uint32_t words_per_level,
+                                                                const uint32_t words, const uint32_t row_words) {
+	__shared__ uint32_t tile[PR_SAMPLES * (PR_MAX_WORDS + 1)];
+	const uint32_t i0 = blockIdx.x * PR_SAMPLES, pitch = words + 1;
+	const uint32_t per_level = PR_SAMPLES * words_per_level;
+	for (uint32_t idx = threadIdx.x; idx < PR_SAMPLES * words; idx += PR_THREADS) {
+		const uint32_t l = idx / per_level, r = idx - l * per_level;
+		const uint32_t i = r / words_per_level, k = r - i * words_per_level;
+		tile[i * pitch + l * words_per_level + k] = planes[((size_t)l * n + i0) * words_per_level + r];
+	}
+	__syncthreads();
+	for (uint32_t idx = threadIdx.x; idx < PR_SAMPLES * words; idx += PR_THREADS) {
+		const uint32_t i = idx / words, w = idx - i * words;
+		rows[(size_t)(i0 + i) * row_words + w] = tile[i * pitch + w];
+	}
+}
+// the other way round: rows [n][row_words] -> level planes (dL/dy of a caller's own network for the list-fed gradient kernel, whose streamed
+// tasks read a level's gradients sample after sample)
+__global__ void __launch_bounds__(PR_THREADS) k_rows_to_planes(const uint32_t* __restrict__ rows, uint32_t* __restrict__ planes, const uint32_t n, const uint32_t words_per_level,
+                                                                const uint32_t words, const uint32_t row_words) {
+	__shared__ uint32_t tile[PR_SAMPLES * (PR_MAX_WORDS + 1)];
+	const uint32_t i0 = blockIdx.x * PR_SAMPLES, pitch = words + 1;
+	const uint32_t per_level = PR_SAMPLES * words_per_level;
+	for (uint32_t idx = threadIdx.x; idx < PR_SAMPLES * words; idx += PR_THREADS) {
+		const uint32_t i = idx / words, w = idx - i * words;
+		tile[i * pitch + w] = rows[(size_t)(i0 + i) * row_words + w];
+	}
+	__syncthreads();
+	for (uint32_t idx = threadIdx.x; idx < PR_SAMPLES * words; idx += PR_THREADS) {
+		const uint32_t l = idx / per_level, r = idx - l * per_level;
+		const uint32_t i = r / words_per_level, k = r - i * words_per_level;
+		planes[((size_t)l * n + i0) * words_per_level + r] = tile[i * pitch + l * words_per_level + k];
+	}
+}
+} // namespace
+
+bool grid_planes_to_rows_supported(const GridMeta& meta, uint32_t n) {
+	return n > 0 && n % PR_SAMPLES == 0 && meta.n_features_per_level % 2 == 0 && meta.n_levels * meta.n_features_per_level / 2 <= PR_MAX_WORDS;
+}
+
+void grid_planes_to_rows(hipStream_t stream, const GridMeta& meta, uint32_t n, const void* planes, void* rows, uint32_t row_stride) {
+	CHECK_THROW(grid_planes_to_rows_supported(meta, n) && row_stride % 2 == 0 && row_stride >= meta.n_levels * meta.n_features_per_level);
+	const uint32_t wpl = meta.n_features_per_level / 2;
+	hipLaunchKernelGGL(k_planes_to_rows, dim3(n / PR_SAMPLES), dim3(PR_THREADS), 0, stream, (const uint32_t*)planes, (uint32_t*)rows, n, wpl, meta.n_levels * wpl, row_stride / 2);
+}
+
+void grid_rows_to_planes(hipStream_t stream, const GridMeta& meta, uint32_t n, const void* rows, uint32_t row_stride, void* planes) {
+	CHECK_THROW(grid_planes_to_rows_supported(meta, n) && row_stride % 2 == 0 && row_stride >= meta.n_levels * meta.n_features_per_level);
+	const uint32_t wpl = meta.n_features_per_level / 2;
+	hipLaunchKernelGGL(k_rows_to_planes, dim3(n / PR_SAMPLES), dim3(PR_THREADS), 0, stream, (const uint32_t*)rows, (uint32_t*)planes, n, wpl, meta.n_levels * wpl, row_stride / 2);
+}
+
 } // namespace tcnn_amd

@@ -421,6 +421,15 @@ public:
 	EncodingContext forward(hipStream_t stream, uint32_t n, MatView x, const void* params, void* out, bool prepare_input_gradients, bool prepare_param_gradients) override {
 		EncodingContext ctx;
 		if ((!out && !prepare_input_gradients) || padded_output_width() == 0 || n == 0) return ctx;
+		// The encoded batch as a matrix (callers with their own network: the PyTorch Encoding module, a grid nested in a Composite): the level-plane
+		// kernel -- XCD-aware, and the one that writes the hit lists the fast gradient kernel reads -- and a transposition behind it, instead of
+		// the AoS kernel and the bit-plane gradient kernel (3-D, F = 2, 2^18 samples through the PyTorch module: 1.74 -> ms forward + backward).
+		if (out && !prepare_input_gradients && switches().grid_rows_planes && forward_plane_features(n) > 0 && grid_planes_to_rows_supported(m_meta, n)) {
+			ArenaBuf planes{stream, (size_t)n * m_n_features * sizeof(uint16_t)};
+			ctx = forward_planes(stream, n, x, params, planes.data(), prepare_param_gradients);
+			grid_planes_to_rows(stream, m_meta, n, planes.data(), out, padded_output_width());
+			return ctx;
+		}
 		if (prepare_input_gradients) ctx.dy_dx = ArenaBuf{stream, (size_t)n * m_n_features * m_meta.n_pos_dims * sizeof(float)};
 		const bool want_filter = prepare_param_gradients && lds_scatter_usable() && n % 64 == 0;
 		ArenaBuf mask;
@@ -518,14 +527,23 @@ public:
 					CHECK_THROW(!ctx.dy_records); // the listed elements bring entries and weights along: dL/dy is gathered from plain level planes (or rows)
 					ListsPlan& lp = lists_plan(n, stream);
 					const uint32_t F = m_meta.n_features_per_level;
-					const uint32_t dy_stride_sample = dy_planes ? F : padded_output_width(), dy_stride_level = dy_planes ? n * F : F;
+					// dL/dy as rows (a caller's own network): into level planes first -- the streamed tasks read a level's gradients sample after
+					// sample, 4 bytes out of every row's 64 otherwise (2^18 samples: the owners 82 us from rows, 42 from planes; the transposition 12)
+					ArenaBuf dy_as_planes;
+					if (!dy_planes && grid_planes_to_rows_supported(m_meta, n)) {
+						dy_as_planes = ArenaBuf{stream, (size_t)n * m_n_features * sizeof(uint16_t)};
+						grid_rows_to_planes(stream, m_meta, n, dL_dy, padded_output_width(), dy_as_planes.data());
+					}
+					const bool planes_now = dy_planes || dy_as_planes;
+					const void* dy_src = dy_as_planes ? dy_as_planes.data() : dL_dy;
+					const uint32_t dy_stride_sample = planes_now ? F : padded_output_width(), dy_stride_level = planes_now ? n * F : F;
 					ctx.adam_done.clear(); // (this kernel does not carry the optimizer's update: measured 20 % slower in round 4)
 					++m_list_scatters;
 					// the finalize pass (and the reduce job with it) may be left to the optimizer's launch: no ranges, no job -> no launch here
 					const bool defer = take_prologue(ctx, lp.dev_ranges.as<GridScatterRange>(), lp.host_ranges, lp.scratch.as<uint64_t>(), grads, mode);
 					ArenaBuf gvals{stream, grid_list_gradients_bytes(m_meta, ctx.hit_lists)}; // dL/dy in list order: written and read by the two kernels of this call
 					grid_backward_lists(stream, m_meta, dev_meta(), lp.dev_tasks.as<GridScatterTask>(), lp.n_tasks,
-					                    lp.dev_ranges.as<GridScatterRange>(), defer ? 0u : lp.n_ranges, lp.scratch.as<uint64_t>(), n, x, dL_dy, dy_stride_sample, dy_stride_level, grads, ctx.hit_lists,
+					                    lp.dev_ranges.as<GridScatterRange>(), defer ? 0u : lp.n_ranges, lp.scratch.as<uint64_t>(), n, x, dy_src, dy_stride_sample, dy_stride_level, grads, ctx.hit_lists,
 					                    gvals.data(), mode == GradientMode::Accumulate, defer ? nullptr : ctx.reduce_job, hit_counters(stream).fallbacks.as<uint32_t>());
 					if (dL_dx) {
 						CHECK_THROW(ctx.dy_dx);
@@ -1245,6 +1263,14 @@ private:
 		}
 		return m_nested.front()->padded_output_width();
 	}
+public:
+	uint64_t list_scatters() const override {
+		uint64_t total = 0;
+		for (const auto& e : m_nested) total += e->list_scatters();
+		return total;
+	}
+
+private:
 	uint32_t m_n_dims;
 	Json m_config;
 	Reduction m_reduction = Reduction::Concatenation;
@@ -1535,6 +1561,7 @@ public:
 	virtual Precision precision() const = 0;
 	virtual std::vector<std::pair<uint32_t, uint32_t>> layer_sizes() const = 0;
 	virtual void initialize_params(Pcg32& rng, float* params_full_precision, float scale) = 0;
+	virtual uint64_t list_scatters() const { return 0; } // backward passes of the model's grid encoding(s) that ran the list-fed gradient kernel
 	virtual void inference(hipStream_t stream, uint32_t n, MatView input, void* output, const void* params) = 0;
 	// float output of the unpadded width (object.h:147-176: inference + trim_and_cast_from); models may fuse the conversion
 	virtual void inference_f32(hipStream_t stream, uint32_t n, MatView input, MatViewMut output, const void* params) {
@@ -1764,7 +1791,7 @@ public:
 	void invalidate_live_image() { m_network->invalidate_live_image(); } // the parameters change(d) some other way
 	size_t image_preps() const { return m_image_preps; }                 // k_mlp_prep launches of fused steps so far (a test's view of the above)
 	uint64_t scatter_wide_fallbacks() { return m_encoding->scatter_wide_fallbacks(); }
-	uint64_t list_scatters() const { return m_encoding->list_scatters(); }
+	uint64_t list_scatters() const override { return m_encoding->list_scatters(); }
 	bool context_keeps_slabs(const ModelContext& c) const { const Ctx* x = dynamic_cast<const Ctx*>(&c); return x && (bool)x->slabs_kept; }
 	// the register-resident fused kernel (k_train_regs.hip) writes dL_doutput / L as compact [n][dims] matrices (TrainContext::compact)
 	bool fused_compact_context_supported(uint32_t n) const {
@@ -1967,6 +1994,7 @@ public:
 	Precision precision() const override { return m_precision; }
 	std::vector<std::pair<uint32_t, uint32_t>> layer_sizes() const override { return {}; }
 	void initialize_params(Pcg32& rng, float* params_full_precision, float scale) override { m_encoding->initialize_params(rng, params_full_precision, scale); }
+	uint64_t list_scatters() const override { return m_encoding->list_scatters(); }
 
 	struct Ctx : public ModelContext {
 		EncodingContext encoding_ctx;

@@ -43,6 +43,7 @@ inline uint32_t div_round_up(uint32_t v, uint32_t d) { return (v + d - 1) / d; }
 // creates its models afterwards; tests that compare two settings build one model at a time.
 struct Switches {
 	bool grid_planes = true;      // TCNN_AMD_GRID_PLANES=0: the AoS forward kernel inside the fused training step
+	bool grid_rows_planes = true; // TCNN_AMD_GRID_ROWS_PLANES=0: callers that want the encoded batch as a matrix get k_grid_fwd (AoS) instead of the plane kernel + a transposition
 	bool grid_scatter_lds = true; // TCNN_AMD_GRID_SCATTER=atomic: the reference-shaped global-atomic gradient kernel
 	bool scatter_records = true;  // TCNN_AMD_SCATTER_RECORDS=0: gradient planes instead of {coordinates, gradient} records
 	bool scatter_tune = true;     // TCNN_AMD_SCATTER_TUNE=0: the untuned task list of k_grid_scatter
@@ -114,6 +115,10 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_
 // ---- training-step forward (k_grid_planes.hip): half, F >= 2, D in {2, 3}; level-major and XCD-aware.
 // out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][GRID_FILTER_MAX_CHUNKS][n / 64], written for levels with 2 .. GRID_FILTER_MAX_CHUNKS scatter chunks.
 bool grid_planes_supported(const GridMeta& meta, uint32_t n);
+bool grid_planes_to_rows_supported(const GridMeta& meta, uint32_t n);
+// level planes [level][n][F] -> rows [n][row_stride] (halves; the callers that want the encoded batch as a matrix, k_grid_planes.hip)
+void grid_planes_to_rows(hipStream_t stream, const GridMeta& meta, uint32_t n, const void* planes, void* rows, uint32_t row_stride);
+void grid_rows_to_planes(hipStream_t stream, const GridMeta& meta, uint32_t n, const void* rows, uint32_t row_stride, void* planes);
 uint32_t grid_planes_spt(const GridMeta& meta);        // samples per thread of the kernel shape used for this grid
 void grid_planes_plan(const GridMeta& meta, uint32_t n, bool hit_lists, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd); // hit_lists: the shape of the kernel that writes them (larger work items)
 // prep_job (optional, mlp_side_jobs.h; passed to the kernel by value): the kernel also builds the MLP's fragment images

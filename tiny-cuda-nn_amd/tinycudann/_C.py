@@ -76,6 +76,7 @@ _SIGNATURES = {
     "tcnn_module_n_input_dims": (_u32, [_vp]),
     "tcnn_module_n_output_dims": (_u32, [_vp]),
     "tcnn_module_n_params": (_sz, [_vp]),
+    "tcnn_module_list_scatters": (_sz, [_vp]),
     "tcnn_module_param_precision": (_int, [_vp]),
     "tcnn_module_output_precision": (_int, [_vp]),
     "tcnn_module_initialize_params": (_int, [_vp, _u64, _vp, _f32]),

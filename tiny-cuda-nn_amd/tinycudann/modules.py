@@ -62,6 +62,10 @@ class NativeModule:
     def n_params(self):
         return int(_C.lib.tcnn_module_n_params(self._h))
 
+    def list_scatters(self):
+        """backward passes of the module's grid encoding(s) that ran the list-fed gradient kernel (tcnn_amd.h: tcnn_module_list_scatters)"""
+        return int(_C.lib.tcnn_module_list_scatters(self._h))
+
     def param_precision(self):
         return int(_C.lib.tcnn_module_param_precision(self._h))
 
