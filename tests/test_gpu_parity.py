@@ -259,6 +259,8 @@ MANY_CHUNK_CASES = [
     # tables cut into > 64 LDS chunks per level: 128 (2^19 entries x F = 4) and 1024 (2^22 entries x F = 4, the C5 shape)
     {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0},
     {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 4, "log2_hashmap_size": 22, "base_resolution": 64, "per_level_scale": 2.0},
+    # F = 8: 2048 entries per chunk -> 256 chunks at 2^19 entries (round 5: binned instead of the reference-shaped global atomics)
+    {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 8, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 2.0},
 ]
 
 

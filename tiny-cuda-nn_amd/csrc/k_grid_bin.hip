@@ -486,7 +486,8 @@ BinLayout bin_layout(const GridMeta& meta, const GridMeta* dev_meta, uint32_t n)
 	const bool nearest = meta.interpolation == (uint32_t)InterpolationType::Nearest;
 	a.per_sample = nearest ? 1u : (1u << meta.n_pos_dims);
 	a.tile_contribs = BIN_TILE_CONTRIBS;
-	if (const char* e = getenv("TCNN_AMD_BIN_TILE")) a.tile_contribs = std::min<uint32_t>(std::max(atoi(e), 512), BIN_TILE_CONTRIBS); // A/B runs
+	if (meta.n_features_per_level == 8) a.tile_contribs = BIN_TILE_CONTRIBS / 2; // (20 bytes per contribution in k_bin_fill's LDS instead of 12: half the tile)
+	if (const char* e = getenv("TCNN_AMD_BIN_TILE")) a.tile_contribs = std::min<uint32_t>(std::max(atoi(e), 512), a.tile_contribs); // A/B runs
 	a.tile_samples = a.tile_contribs >> meta.n_pos_dims; // nearest: the LDS arrays are simply not filled
 	a.n_tiles = div_round_up(n, a.tile_samples);
 	uint32_t max_chunks = 0;
@@ -525,7 +526,7 @@ void launch_binned(hipStream_t s, const BinLayout& l, MatView x, const void* dy,
 	const uint32_t fill_lds = a.tile_contribs * (F * 2 + 4) + 3 * a.stride * 4;
 	static bool configured = false;
 	if (!configured) { // more than 64 KiB of dynamic LDS has to be opted into once per kernel
-		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_bin_fill<D, F>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_TILE_CONTRIBS * (F * 2 + 4) + 3 * BIN_MAX_CHUNKS * 4));
+		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_bin_fill<D, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (F == 8 ? BIN_TILE_CONTRIBS / 2 : BIN_TILE_CONTRIBS) * (F * 2 + 4) + 3 * BIN_MAX_CHUNKS * 4));
 		HIP_CHECK_THROW(hipFuncSetAttribute((const void*)k_bin_accum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_ACC_BYTES_MAX));
 		configured = true;
 	}
@@ -569,7 +570,7 @@ uint32_t grid_bin_acc_bytes() {
 
 bool grid_bin_supported(const GridMeta& meta) {
 	const uint32_t D = meta.n_pos_dims, F = meta.n_features_per_level;
-	return (F == 2 || F == 4) && D >= 2 && D <= 4;
+	return (F == 2 || F == 4 || F == 8) && D >= 2 && D <= 4;
 }
 
 size_t grid_bin_workspace_bytes(const GridMeta& meta, uint32_t n) { return bin_layout(meta, nullptr, n).bytes; }
@@ -588,7 +589,8 @@ void grid_backward_binned(hipStream_t stream, const GridMeta& meta, const GridMe
 	char* ws = (char*)workspace;
 #define TCNN_BIN(D) \
 	if (F == 2) launch_binned<D, 2>(stream, l, x, dL_dy, dy_stride_sample, dy_stride_level, grad, accumulate, ws, fallback_count); \
-	else launch_binned<D, 4>(stream, l, x, dL_dy, dy_stride_sample, dy_stride_level, grad, accumulate, ws, fallback_count);
+	else if (F == 4) launch_binned<D, 4>(stream, l, x, dL_dy, dy_stride_sample, dy_stride_level, grad, accumulate, ws, fallback_count); \
+	else launch_binned<D, 8>(stream, l, x, dL_dy, dy_stride_sample, dy_stride_level, grad, accumulate, ws, fallback_count);
 	switch (meta.n_pos_dims) {
 		case 2: TCNN_BIN(2) break;
 		case 3: TCNN_BIN(3) break;
