@@ -207,6 +207,31 @@ def test_encoded_matrix_through_the_plane_kernel(tcnn, oracle, monkeypatch, n_in
     assert np.array_equal(out.reshape(n, width), want_out)
 
 
+def test_encoded_matrix_backward_of_an_earlier_forward_pass(tcnn, oracle):
+    """Two forward passes of one Encoding module, then their backward passes in either order (a caller evaluating the grid at two point sets
+    per iteration): the hit lists' straggler counters belong to the LATEST forward pass of the stream, so the earlier context must notice and
+    take the bit-plane kernel -- same exact gradients (grid.h:215-320 with one final rounding), one list-fed launch counted, not two."""
+    n_in, enc_cfg, n = ROWS_CASES[2][:3]
+    ref = oracle.create_encoding(n_in, enc_cfg, alignment=0)
+    params_h = oracle.half_bits(oracle.Pcg32(3).uniform_strided(ref.n_params, -1.0, 1.0))
+    width = ref.padded_output_width
+    native = tcnn.Encoding(n_in, enc_cfg).native_tcnn_module
+    pt = _t(params_h.view(np.float16)).requires_grad_(True)
+    batches = []
+    for seed in (42, 43):
+        x = oracle.Pcg32(seed).uniform_strided(n * n_in).reshape(n, n_in)
+        dy = oracle.half_bits(oracle.Pcg32(seed + 10).uniform_strided(n * width, -2.0, 2.0).reshape(n, width))
+        want = np.zeros(ref.n_params, dtype=np.uint16)
+        ref.backward_exact(x, dy, want)
+        xt = _t(x)
+        ctx, out = native.fwd(xt, pt)
+        batches.append((xt, ctx, out, _t(dy.view(np.float16)), want))
+    for xt, ctx, out, dyt, want in (batches[1], batches[0]):
+        _, g = native.bwd(ctx, xt, pt, out, dyt)
+        assert np.array_equal(_bits(g), want)
+    assert native.list_scatters() == 1
+
+
 @pytest.mark.parametrize("n_in,enc_cfg,n", SCATTER_CASES)
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_grid_gradient_exact(tcnn, oracle, n_in, enc_cfg, n, accumulate):
