@@ -427,7 +427,12 @@ def test_network_forward_backward(tcnn, oracle, n_in, n_out, net_cfg):
 
 
 # ---------------------------------------------------------------------------------------------------- full training step
-@pytest.mark.parametrize("cfg,n_in,n", [(CONFIG_C3B, 2, 4096), (CONFIG_C3A, 2, 1024), (CONFIG_C2, 2, 1024), (CONFIG_C1, 2, 4096), (CONFIG_C5_SMALL, 3, 1024)])
+CONFIG_PADDED_2D = dict(CONFIG_C3B, encoding={"otype": "HashGrid", "n_levels": 12, "n_features_per_level": 2, "log2_hashmap_size": 15, "base_resolution": 16, "per_level_scale": 1.5})  # 24 features in front of a 16-aligned network: 8 columns of zeros (grid.h:749-759)
+CONFIG_PADDED_3D = dict(CONFIG_C3B, encoding={"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 2, "log2_hashmap_size": 17, "base_resolution": 8, "per_level_scale": 2.0})  # 12 -> 16, hit lists
+
+
+@pytest.mark.parametrize("cfg,n_in,n", [(CONFIG_C3B, 2, 4096), (CONFIG_C3A, 2, 1024), (CONFIG_C2, 2, 1024), (CONFIG_C1, 2, 4096), (CONFIG_C5_SMALL, 3, 1024),
+                                        (CONFIG_PADDED_2D, 2, 1024), (CONFIG_PADDED_3D, 3, 2048)])
 def test_training_step_matches_oracle(tcnn, oracle, cfg, n_in, n):
     """One trainer->training_step(): forward output, loss values, dL/doutput, parameter gradients, Adam update."""
     ref = oracle.Trainer(n_in, 3, cfg, seed=1337)
@@ -931,11 +936,13 @@ LIST_SCATTER_CASES = [
     (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 17, "base_resolution": 16, "per_level_scale": 2.0}),
     (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 4, "log2_hashmap_size": 17, "base_resolution": 16, "per_level_scale": 1.5}),  # (a level of 6724 entries: more than the 4096 one chunk holds at F = 4, fewer than 8192)
     (2, 4096, {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 8, "log2_hashmap_size": 14, "base_resolution": 16, "per_level_scale": 2.0}),
-    (2, 8192, {"otype": "DenseGrid", "n_levels": 8, "n_features_per_level": 2, "base_resolution": 16, "per_level_scale": 1.5}),  # (8 levels: 16 features, no padding -- a padded encoding has no level planes and hence no lists)
+    (2, 8192, {"otype": "DenseGrid", "n_levels": 8, "n_features_per_level": 2, "base_resolution": 16, "per_level_scale": 1.5}),
     (2, 8192, {"otype": "TiledGrid", "n_levels": 8, "n_features_per_level": 2, "base_resolution": 128, "per_level_scale": 1.5}),
     (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 16, "per_level_scale": 2.0, "interpolation": "Nearest"}),
     (3, 4096, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 8, "per_level_scale": 1.5, "interpolation": "Smoothstep"}),
     (2, 8192, {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 16, "per_level_scale": 2.0, "hash": "Prime"}),
+    (3, 4096, {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 2, "log2_hashmap_size": 17, "base_resolution": 8, "per_level_scale": 2.0}),  # 12 features padded to 16: planes of zeros behind the levels'
+    (2, 8192, {"otype": "HashGrid", "n_levels": 12, "n_features_per_level": 2, "log2_hashmap_size": 16, "base_resolution": 16, "per_level_scale": 1.5}),  # 24 -> 32
 ]
 
 

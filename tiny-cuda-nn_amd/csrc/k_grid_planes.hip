@@ -539,20 +539,19 @@ __global__ void __launch_bounds__(PR_THREADS) k_rows_to_planes(const uint32_t* _
 }
 } // namespace
 
-bool grid_planes_to_rows_supported(const GridMeta& meta, uint32_t n) {
-	return n > 0 && n % PR_SAMPLES == 0 && meta.n_features_per_level % 2 == 0 && meta.n_levels * meta.n_features_per_level / 2 <= PR_MAX_WORDS;
+bool grid_planes_to_rows_supported(const GridMeta& meta, uint32_t n, uint32_t width) {
+	const uint32_t F = meta.n_features_per_level;
+	return n > 0 && n % PR_SAMPLES == 0 && F % 2 == 0 && width > 0 && width % F == 0 && width / 2 <= PR_MAX_WORDS;
 }
 
-void grid_planes_to_rows(hipStream_t stream, const GridMeta& meta, uint32_t n, const void* planes, void* rows, uint32_t row_stride) {
-	CHECK_THROW(grid_planes_to_rows_supported(meta, n) && row_stride % 2 == 0 && row_stride >= meta.n_levels * meta.n_features_per_level);
-	const uint32_t wpl = meta.n_features_per_level / 2;
-	hipLaunchKernelGGL(k_planes_to_rows, dim3(n / PR_SAMPLES), dim3(PR_THREADS), 0, stream, (const uint32_t*)planes, (uint32_t*)rows, n, wpl, meta.n_levels * wpl, row_stride / 2);
+void grid_planes_to_rows(hipStream_t stream, const GridMeta& meta, uint32_t n, uint32_t width, const void* planes, void* rows, uint32_t row_stride) {
+	CHECK_THROW(grid_planes_to_rows_supported(meta, n, width) && row_stride % 2 == 0 && row_stride >= width);
+	hipLaunchKernelGGL(k_planes_to_rows, dim3(n / PR_SAMPLES), dim3(PR_THREADS), 0, stream, (const uint32_t*)planes, (uint32_t*)rows, n, meta.n_features_per_level / 2, width / 2, row_stride / 2);
 }
 
-void grid_rows_to_planes(hipStream_t stream, const GridMeta& meta, uint32_t n, const void* rows, uint32_t row_stride, void* planes) {
-	CHECK_THROW(grid_planes_to_rows_supported(meta, n) && row_stride % 2 == 0 && row_stride >= meta.n_levels * meta.n_features_per_level);
-	const uint32_t wpl = meta.n_features_per_level / 2;
-	hipLaunchKernelGGL(k_rows_to_planes, dim3(n / PR_SAMPLES), dim3(PR_THREADS), 0, stream, (const uint32_t*)rows, (uint32_t*)planes, n, wpl, meta.n_levels * wpl, row_stride / 2);
+void grid_rows_to_planes(hipStream_t stream, const GridMeta& meta, uint32_t n, uint32_t width, const void* rows, uint32_t row_stride, void* planes) {
+	CHECK_THROW(grid_planes_to_rows_supported(meta, n, width) && row_stride % 2 == 0 && row_stride >= width);
+	hipLaunchKernelGGL(k_rows_to_planes, dim3(n / PR_SAMPLES), dim3(PR_THREADS), 0, stream, (const uint32_t*)rows, (uint32_t*)planes, n, meta.n_features_per_level / 2, width / 2, row_stride / 2);
 }
 
 } // namespace tcnn_amd

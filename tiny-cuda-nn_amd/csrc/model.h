@@ -424,10 +424,10 @@ public:
 		// The encoded batch as a matrix (callers with their own network: the PyTorch Encoding module, a grid nested in a Composite): the level-plane
 		// kernel -- XCD-aware, and the one that writes the hit lists the fast gradient kernel reads -- and a transposition behind it, instead of
 		// the AoS kernel and the bit-plane gradient kernel (3-D, F = 2, 2^18 samples through the PyTorch module: 1.74 -> 0.42 ms forward + backward; a Composite of such a grid and spherical harmonics in front of a 64x2 network: 1.89 -> 0.49 ms per training step).
-		if (out && !prepare_input_gradients && switches().grid_rows_planes && forward_plane_features(n) > 0 && grid_planes_to_rows_supported(m_meta, n)) {
-			ArenaBuf planes{stream, (size_t)n * m_n_features * sizeof(uint16_t)};
+		if (out && !prepare_input_gradients && switches().grid_rows_planes && forward_plane_features(n) > 0 && grid_planes_to_rows_supported(m_meta, n, padded_output_width())) {
+			ArenaBuf planes{stream, (size_t)n * padded_output_width() * sizeof(uint16_t)};
 			ctx = forward_planes(stream, n, x, params, planes.data(), prepare_param_gradients);
-			grid_planes_to_rows(stream, m_meta, n, planes.data(), out, padded_output_width());
+			grid_planes_to_rows(stream, m_meta, n, padded_output_width(), planes.data(), out, padded_output_width()); // (the planes of zeros behind the levels' included)
 			return ctx;
 		}
 		if (prepare_input_gradients) ctx.dy_dx = ArenaBuf{stream, (size_t)n * m_n_features * m_meta.n_pos_dims * sizeof(float)};
@@ -446,7 +446,8 @@ public:
 	// TCNN_AMD_GRID_PLANES=0 keeps the AoS forward kernel inside the fused training step (A/B runs)
 	static bool use_planes() { return switches().grid_planes; }
 	uint32_t forward_plane_features(uint32_t n) override {
-		return (!m_fp32 && use_planes() && m_n_to_pad == 0 && grid_planes_supported(m_meta, n)) ? m_meta.n_features_per_level : 0;
+		// (a padded encoding -- 12 levels x 2 features in front of a 16-aligned network -- has whole planes of zeros behind its levels' planes)
+		return (!m_fp32 && use_planes() && m_n_to_pad % m_meta.n_features_per_level == 0 && grid_planes_supported(m_meta, n)) ? m_meta.n_features_per_level : 0;
 	}
 
 	struct PlanesPlan {
@@ -504,6 +505,7 @@ public:
 		PlanesPlan& plan = planes_plan(n, want_lists);
 		grid_forward_planes(stream, m_meta, dev_meta(), plan.dev_work.as<uint32_t>(), plan.max_items, plan.blocks_per_xcd, n, x, params, out_planes, ctx.chunk_mask.as<uint64_t>(), prep_job,
 		                    want_lists ? &ctx.hit_lists : nullptr);
+		if (m_n_to_pad) HIP_CHECK_THROW(hipMemsetAsync((uint16_t*)out_planes + (size_t)n * m_n_features, 0, (size_t)n * m_n_to_pad * sizeof(uint16_t), stream)); // grid.h:749-759: the grid pads with zeros
 		return ctx;
 	}
 
@@ -530,9 +532,9 @@ public:
 					// dL/dy as rows (a caller's own network): into level planes first -- the streamed tasks read a level's gradients sample after
 					// sample, 4 bytes out of every row's 64 otherwise (2^18 samples: the owners 82 us from rows, 42 from planes; the transposition 12)
 					ArenaBuf dy_as_planes;
-					if (!dy_planes && grid_planes_to_rows_supported(m_meta, n)) {
+					if (!dy_planes && grid_planes_to_rows_supported(m_meta, n, m_n_features)) {
 						dy_as_planes = ArenaBuf{stream, (size_t)n * m_n_features * sizeof(uint16_t)};
-						grid_rows_to_planes(stream, m_meta, n, dL_dy, padded_output_width(), dy_as_planes.data());
+						grid_rows_to_planes(stream, m_meta, n, m_n_features, dL_dy, padded_output_width(), dy_as_planes.data());
 					}
 					const bool planes_now = dy_planes || dy_as_planes;
 					const void* dy_src = dy_as_planes ? dy_as_planes.data() : dL_dy;

@@ -115,10 +115,11 @@ void grid_forward(hipStream_t stream, const GridMeta& meta, const GridMeta* dev_
 // ---- training-step forward (k_grid_planes.hip): half, F >= 2, D in {2, 3}; level-major and XCD-aware.
 // out_planes: half [n_levels][n][F]; chunk_bits (optional): uint64 [n_levels][GRID_FILTER_MAX_CHUNKS][n / 64], written for levels with 2 .. GRID_FILTER_MAX_CHUNKS scatter chunks.
 bool grid_planes_supported(const GridMeta& meta, uint32_t n);
-bool grid_planes_to_rows_supported(const GridMeta& meta, uint32_t n);
-// level planes [level][n][F] -> rows [n][row_stride] (halves; the callers that want the encoded batch as a matrix, k_grid_planes.hip)
-void grid_planes_to_rows(hipStream_t stream, const GridMeta& meta, uint32_t n, const void* planes, void* rows, uint32_t row_stride);
-void grid_rows_to_planes(hipStream_t stream, const GridMeta& meta, uint32_t n, const void* rows, uint32_t row_stride, void* planes);
+bool grid_planes_to_rows_supported(const GridMeta& meta, uint32_t n, uint32_t width);
+// planes [width / F][n][F] -> the first `width` columns of rows [n][row_stride] and back (halves; the callers that want the encoded batch as a
+// matrix, k_grid_planes.hip; width: the levels' features, or the padded width with its planes of zeros)
+void grid_planes_to_rows(hipStream_t stream, const GridMeta& meta, uint32_t n, uint32_t width, const void* planes, void* rows, uint32_t row_stride);
+void grid_rows_to_planes(hipStream_t stream, const GridMeta& meta, uint32_t n, uint32_t width, const void* rows, uint32_t row_stride, void* planes);
 uint32_t grid_planes_spt(const GridMeta& meta);        // samples per thread of the kernel shape used for this grid
 void grid_planes_plan(const GridMeta& meta, uint32_t n, bool hit_lists, std::vector<uint32_t>& work, uint32_t& max_items, uint32_t& blocks_per_xcd); // hit_lists: the shape of the kernel that writes them (larger work items)
 // prep_job (optional, mlp_side_jobs.h; passed to the kernel by value): the kernel also builds the MLP's fragment images
