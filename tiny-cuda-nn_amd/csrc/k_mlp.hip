@@ -529,6 +529,94 @@ __global__ void __launch_bounds__(256) k_wgrad(
 	}
 }
 
+// The same product for the shapes whose tile rows divide over the four waves (R = 64 or 128 output features, C <= 128 input features: every
+// hidden layer of a 64- or 128-wide network).  Round 5: the kernel above re-reads both operands of every tile from LDS (four transposing reads
+// per matrix instruction) and loads a chunk, waits, multiplies, waits: 91 us for 128 x 128 over 2^18 samples, a quarter of what the 134 MB it
+// reads allow.  Here wave w owns TRW tile rows x all TC tile columns: a tile row's operand is read once per k-step and a tile column's once for
+// all of the wave's rows (40 reads for 32 matrix instructions at 128 x 128 instead of 128), and the next chunk's global loads are in flight
+// while this chunk is multiplied (through registers: one LDS image, two barriers per chunk).  Every tile still sums its chunks and k-steps
+// in the same order: bit-identical slabs.
+template <int TRW, int TC>
+__global__ void __launch_bounds__(256) k_wgrad_rows(
+	const uint32_t n, const half_t* __restrict__ dO, const uint32_t ldo, const half_t* __restrict__ In, const uint32_t ldi, float* __restrict__ slabs
+) {
+	constexpr uint32_t R = 4 * TRW * 16, C = TC * 16;
+	constexpr uint32_t rp = R + WG_PAD, cp = C + WG_PAD;
+	constexpr uint32_t ppr = R / 8, pqr = C / 8;                                      // 16-byte pieces per row
+	constexpr uint32_t NP = WG_CHUNK * ppr / 256, NQ = WG_CHUNK * pqr / 256;           // pieces per thread
+	static_assert(WG_CHUNK * ppr % 256 == 0 && WG_CHUNK * pqr % 256 == 0, "whole pieces per thread");
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	half_t* P = (half_t*)smem;             // [WG_CHUNK][rp]
+	half_t* Q = P + (size_t)WG_CHUNK * rp; // [WG_CHUNK][cp]
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63, w = tid >> 6;
+	const uint32_t grp = lane >> 4, li = lane & 15;
+	f4 acc[TRW][TC];
+#pragma unroll
+	for (int i = 0; i < TRW; ++i)
+#pragma unroll
+		for (int j = 0; j < TC; ++j) acc[i][j] = f4{0, 0, 0, 0};
+
+	const uint32_t n_chunks = n / WG_CHUNK;
+	h8 pv[NP], qv[NQ];
+	auto fetch = [&](const uint32_t ch) { // (a chunk past the end: the last one again, never stored)
+		const size_t base = (size_t)min(ch, n_chunks - 1) * WG_CHUNK;
+#pragma unroll
+		for (uint32_t k = 0; k < NP; ++k) {
+			const uint32_t p = tid + k * 256, row = p / ppr, col = (p - row * ppr) * 8;
+			pv[k] = *(const h8*)(dO + (base + row) * ldo + col);
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < NQ; ++k) {
+			const uint32_t p = tid + k * 256, row = p / pqr, col = (p - row * pqr) * 8;
+			qv[k] = *(const h8*)(In + (base + row) * ldi + col);
+		}
+	};
+	if (blockIdx.x < n_chunks) fetch(blockIdx.x);
+	for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+#pragma unroll
+		for (uint32_t k = 0; k < NP; ++k) {
+			const uint32_t p = tid + k * 256, row = p / ppr, col = (p - row * ppr) * 8;
+			*(h8*)(P + (size_t)row * rp + col) = pv[k];
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < NQ; ++k) {
+			const uint32_t p = tid + k * 256, row = p / pqr, col = (p - row * pqr) * 8;
+			*(h8*)(Q + (size_t)row * cp + col) = qv[k];
+		}
+		__syncthreads();
+		fetch(ch + gridDim.x); // in flight while this chunk is multiplied
+#pragma unroll
+		for (int ks = 0; ks < WG_CHUNK / 32; ++ks) {
+			const uint32_t row_lo = 32 * ks + 8 * grp + (li >> 2), colo = 4 * (li & 3); // (the lane map of k_wgrad)
+			h8 af[TRW];
+#pragma unroll
+			for (int i = 0; i < TRW; ++i) {
+				const uint32_t tr = w * TRW + i;
+				const h4 lo = lds_read_tr(P + (size_t)row_lo * rp + 16 * tr + colo), hi = lds_read_tr(P + (size_t)(row_lo + 4) * rp + 16 * tr + colo);
+				af[i] = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+			}
+#pragma unroll
+			for (int tc = 0; tc < TC; ++tc) {
+				const h4 lo = lds_read_tr(Q + (size_t)row_lo * cp + 16 * tc + colo), hi = lds_read_tr(Q + (size_t)(row_lo + 4) * cp + 16 * tc + colo);
+				const h8 bf = h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+				for (int i = 0; i < TRW; ++i) acc[i][tc] = mfma(af[i], bf, acc[i][tc]);
+			}
+		}
+		__syncthreads();
+	}
+
+	float* slab = slabs + (size_t)blockIdx.x * R * C;
+#pragma unroll
+	for (int i = 0; i < TRW; ++i)
+#pragma unroll
+		for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) slab[(size_t)(16 * (w * TRW + i) + 4 * grp + r) * C + 16 * tc + li] = acc[i][tc][r];
+}
+
 // Sum of the per-workgroup slabs.  64 elements x 16 slab groups per workgroup: group g adds slabs g, g + 16, ... with four
 // loads in flight, the 16 group sums are combined through LDS in a fixed order (bitwise reproducible, no atomics).
 constexpr int WR_ELEMS = SLAB_REDUCE_ELEMS, WR_GROUPS = SLAB_REDUCE_GROUPS;
@@ -723,7 +811,18 @@ void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uin
 	CHECK_THROW((rows / 16) * (cols / 16) <= 4 * WG_MAX_TILES);
 	const uint32_t grid = wgrad_grid(n);
 	const size_t shmem = (size_t)WG_CHUNK * ((rows + WG_PAD) + (cols + WG_PAD)) * sizeof(half_t);
-	hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, (const half_t*)dO, ldo, rows, (const half_t*)In, ldi, cols, workspace);
+	const half_t* a = (const half_t*)dO;
+	const half_t* b = (const half_t*)In;
+	static const bool rows_form = [] { const char* e = getenv("TCNN_AMD_WGRAD_ROWS"); return !(e && e[0] == '0'); }(); // =0: k_wgrad for every shape (A/B runs)
+#define TCNN_WGRAD_ROWS(TRW, TC) hipLaunchKernelGGL((k_wgrad_rows<TRW, TC>), dim3(grid), dim3(256), shmem, stream, n, a, ldo, b, ldi, workspace)
+	if (rows_form && rows == 128 && cols == 128) TCNN_WGRAD_ROWS(2, 8);
+	else if (rows_form && rows == 128 && cols == 64) TCNN_WGRAD_ROWS(2, 4);
+	else if (rows_form && rows == 128 && cols == 32) TCNN_WGRAD_ROWS(2, 2);
+	else if (rows_form && rows == 64 && cols == 128) TCNN_WGRAD_ROWS(1, 8);
+	else if (rows_form && rows == 64 && cols == 64) TCNN_WGRAD_ROWS(1, 4);
+	else if (rows_form && rows == 64 && cols == 32) TCNN_WGRAD_ROWS(1, 2);
+	else hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, a, ldo, rows, b, ldi, cols, workspace);
+#undef TCNN_WGRAD_ROWS
 	const uint32_t n_elems = rows * cols;
 	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_elems, (uint32_t)WR_ELEMS)), dim3(WR_ELEMS * WR_GROUPS), 0, stream, n_elems, cols, ldg, grid, workspace, (half_t*)grad_half, accumulate ? 1 : 0);
 }

@@ -40,6 +40,8 @@ ROWS = [
     ("grid + CutlassMLP 64x2", 2, 3, GRID, net(64, 2, otype="CutlassMLP"), "RelativeL2"),
     ("grid + CutlassMLP 256x2", 2, 3, GRID, net(256, 2, otype="CutlassMLP"), "RelativeL2"),
     ("OneBlob 64 + 64x2", 2, 3, {"otype": "OneBlob", "n_bins": 64}, net(), "RelativeL2"),
+    ("OneBlob 64 + 128x5 (the reference's data/config.json, config_oneblob.json)", 2, 3, {"otype": "OneBlob", "n_bins": 64}, net(128, 5), "RelativeL2"),
+    ("OneBlob 64 + 128x2", 2, 3, {"otype": "OneBlob", "n_bins": 64}, net(128, 2), "RelativeL2"),
     ("OneBlob 32 + 64x2", 3, 3, {"otype": "OneBlob", "n_bins": 32}, net(), "RelativeL2"),
     ("Identity 32 + 64x2", 32, 3, {"otype": "Identity"}, net(), "RelativeL2"),
     ("Identity 3 + 64x2", 3, 3, {"otype": "Identity"}, net(), "RelativeL2"),
