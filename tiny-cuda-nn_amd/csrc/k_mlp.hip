@@ -617,6 +617,72 @@ __global__ void __launch_bounds__(256) k_wgrad_rows(
 			for (int r = 0; r < 4; ++r) slab[(size_t)(16 * (w * TRW + i) + 4 * grp + r) * C + 16 * tc + li] = acc[i][tc][r];
 }
 
+// ... and for the output layer's product (R = 16 padded outputs: ONE tile row): wave w owns TCW tile columns.  Same lane maps, same order
+// of a tile's sums, same prefetch; 54 -> 17 us for 16 x 128 over 2^18 samples.
+template <int TCW>
+__global__ void __launch_bounds__(256) k_wgrad_cols(
+	const uint32_t n, const half_t* __restrict__ dO, const uint32_t ldo, const half_t* __restrict__ In, const uint32_t ldi, float* __restrict__ slabs
+) {
+	constexpr uint32_t R = 16, C = 4 * TCW * 16;
+	constexpr uint32_t rp = R + WG_PAD, cp = C + WG_PAD;
+	constexpr uint32_t ppr = R / 8, pqr = C / 8;
+	constexpr uint32_t NQ = WG_CHUNK * pqr / 256;
+	static_assert(WG_CHUNK * ppr <= 256 && WG_CHUNK * pqr % 256 == 0, "one piece of dO per thread at most, whole pieces of In per thread");
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	half_t* P = (half_t*)smem;
+	half_t* Q = P + (size_t)WG_CHUNK * rp;
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63, w = tid >> 6;
+	const uint32_t grp = lane >> 4, li = lane & 15;
+	f4 acc[TCW];
+#pragma unroll
+	for (int j = 0; j < TCW; ++j) acc[j] = f4{0, 0, 0, 0};
+
+	const uint32_t n_chunks = n / WG_CHUNK;
+	const bool has_p = tid < WG_CHUNK * ppr;
+	const uint32_t prow = tid / ppr, pcol = (tid - prow * ppr) * 8;
+	h8 pv = h8{0, 0, 0, 0, 0, 0, 0, 0}, qv[NQ];
+	auto fetch = [&](const uint32_t ch) {
+		const size_t base = (size_t)min(ch, n_chunks - 1) * WG_CHUNK;
+		if (has_p) pv = *(const h8*)(dO + (base + prow) * ldo + pcol);
+#pragma unroll
+		for (uint32_t k = 0; k < NQ; ++k) {
+			const uint32_t p = tid + k * 256, row = p / pqr, col = (p - row * pqr) * 8;
+			qv[k] = *(const h8*)(In + (base + row) * ldi + col);
+		}
+	};
+	if (blockIdx.x < n_chunks) fetch(blockIdx.x);
+	for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+		if (has_p) *(h8*)(P + (size_t)prow * rp + pcol) = pv;
+#pragma unroll
+		for (uint32_t k = 0; k < NQ; ++k) {
+			const uint32_t p = tid + k * 256, row = p / pqr, col = (p - row * pqr) * 8;
+			*(h8*)(Q + (size_t)row * cp + col) = qv[k];
+		}
+		__syncthreads();
+		fetch(ch + gridDim.x);
+#pragma unroll
+		for (int ks = 0; ks < WG_CHUNK / 32; ++ks) {
+			const uint32_t row_lo = 32 * ks + 8 * grp + (li >> 2), colo = 4 * (li & 3);
+			const h4 alo = lds_read_tr(P + (size_t)row_lo * rp + colo), ahi = lds_read_tr(P + (size_t)(row_lo + 4) * rp + colo);
+			const h8 af = h8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+			for (int j = 0; j < TCW; ++j) {
+				const uint32_t tc = w * TCW + j;
+				const h4 lo = lds_read_tr(Q + (size_t)row_lo * cp + 16 * tc + colo), hi = lds_read_tr(Q + (size_t)(row_lo + 4) * cp + 16 * tc + colo);
+				acc[j] = mfma(af, h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, acc[j]);
+			}
+		}
+		__syncthreads();
+	}
+	float* slab = slabs + (size_t)blockIdx.x * R * C;
+#pragma unroll
+	for (int j = 0; j < TCW; ++j)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) slab[(size_t)(4 * grp + r) * C + 16 * (w * TCW + j) + li] = acc[j][r];
+}
+
 // Sum of the per-workgroup slabs.  64 elements x 16 slab groups per workgroup: group g adds slabs g, g + 16, ... with four
 // loads in flight, the 16 group sums are combined through LDS in a fixed order (bitwise reproducible, no atomics).
 constexpr int WR_ELEMS = SLAB_REDUCE_ELEMS, WR_GROUPS = SLAB_REDUCE_GROUPS;
@@ -821,6 +887,8 @@ void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uin
 	else if (rows_form && rows == 64 && cols == 128) TCNN_WGRAD_ROWS(1, 8);
 	else if (rows_form && rows == 64 && cols == 64) TCNN_WGRAD_ROWS(1, 4);
 	else if (rows_form && rows == 64 && cols == 32) TCNN_WGRAD_ROWS(1, 2);
+	else if (rows_form && rows == 16 && cols == 128) hipLaunchKernelGGL((k_wgrad_cols<2>), dim3(grid), dim3(256), shmem, stream, n, a, ldo, b, ldi, workspace);
+	else if (rows_form && rows == 16 && cols == 64) hipLaunchKernelGGL((k_wgrad_cols<1>), dim3(grid), dim3(256), shmem, stream, n, a, ldo, b, ldi, workspace);
 	else hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, a, ldo, rows, b, ldi, cols, workspace);
 #undef TCNN_WGRAD_ROWS
 	const uint32_t n_elems = rows * cols;
