@@ -129,7 +129,9 @@ __device__ inline void activate_pack(const f4 (&acc)[T][NB], h8 (&hf)[KS][NB], u
 #define TCNN_MLP_FWD_PF 3
 #endif
 template <int W, int NB, int ACT, bool IMG_LDS = false, int THREADS = 256, bool OB = false>
-__global__ void __launch_bounds__(THREADS) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
+// (W = 128 with the fragments in the L2: the 120 + 64 registers the compiler took on its own left two waves per SIMD to hide every fragment's
+// and input's latency; held to 168 -- no spills -- it is three: 158 -> 143 us for 128 x 5 at 2^18 samples, round 5)
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((W == 128 && !IMG_LDS) ? 3 : 1, 8))) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
 	const uint32_t lane = threadIdx.x & 63;
@@ -325,7 +327,7 @@ struct BwdArgs {
 };
 
 template <int W, int NB, int ACT>
-__global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs a) {
+__global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs a) { // (three waves per SIMD, as k_mlp_fwd has them at W = 128, cost 24 spilled registers here: 227 -> 255 us)
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
 	const uint32_t lane = threadIdx.x & 63;
@@ -384,6 +386,17 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 		}
 
 		h8 hf[KS][NB];
+		// The stored forward outputs of layer l are requested a whole layer ahead -- before the products that lead to dH_l -- and the weight
+		// fragments one ahead of the matrix instructions that use them (round 5: written as "load, use" every one of a layer's 16 + 32 loads
+		// exposed its latency to a wave that has only one partner on its SIMD: 270 us for 128 x 5 at 2^18 samples).  Same arithmetic, same order.
+		h4 hv[T][NB];
+		auto request_hidden = [&](const int l) {
+#pragma unroll
+			for (int t = 0; t < T; ++t)
+#pragma unroll
+				for (int b = 0; b < NB; ++b) hv[t][b] = *(const h4*)(a.hidden + ((size_t)l * a.n + s0 + 16 * b + c) * W + 16 * t + 4 * q);
+		};
+		request_hidden((int)nh - 1);
 		for (int l = (int)nh - 1; l >= 0; --l) {
 			// acc = W_{l+1}^T dH_{l+1}; multiply by act'(H_l) (from the stored forward output), store, pack
 #pragma unroll
@@ -391,14 +404,14 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					const size_t off = ((size_t)l * a.n + s0 + 16 * b + c) * W + 16 * t + 4 * q;
-					const h4 hv = *(const h4*)(a.hidden + off);
 					h4 g;
 #pragma unroll
-					for (int r = 0; r < 4; ++r) g[r] = act_bwd_t<ACT>(d.activation, (half_t)acc[t][b][r], hv[r]);
+					for (int r = 0; r < 4; ++r) g[r] = act_bwd_t<ACT>(d.activation, (half_t)acc[t][b][r], hv[t][b][r]);
 					*(h4*)(a.dhidden + off) = g;
 #pragma unroll
 					for (int r = 0; r < 4; ++r) hf[t / 2][b][(t & 1) * 4 + r] = g[r];
 				}
+			if (l > 0) request_hidden(l - 1);
 			if constexpr (T & 1) {
 #pragma unroll
 				for (int b = 0; b < NB; ++b)
@@ -411,14 +424,15 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 				for (int t = 0; t < T; ++t)
 #pragma unroll
 					for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
+				auto frag_of = [&](const int i) -> h8 { return img[(size_t)((i % T) * KS + i / T) * 64]; };
+				h8 af[2];
+				af[0] = frag_of(0);
 #pragma unroll
-				for (int s = 0; s < KS; ++s) {
+				for (int i = 0; i < KS * T; ++i) {
+					const int s = i / T, t = i % T;
+					if (i + 1 < KS * T) af[(i + 1) & 1] = frag_of(i + 1);
 #pragma unroll
-					for (int t = 0; t < T; ++t) {
-						const h8 af = img[(size_t)(t * KS + s) * 64];
-#pragma unroll
-						for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
-					}
+					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af[i & 1], hf[s][b], acc[t][b]);
 				}
 			}
 		}
