@@ -550,10 +550,22 @@ __global__ void __launch_bounds__(256) k_wgrad(
 // all of the wave's rows (40 reads for 32 matrix instructions at 128 x 128 instead of 128), and the next chunk's global loads are in flight
 // while this chunk is multiplied (through registers: one LDS image, two barriers per chunk).  Every tile still sums its chunks and k-steps
 // in the same order: bit-identical slabs.
+// (blockIdx.y: which product of the launch -- the hidden layers of a network are as many products of one shape, independent of each other)
+constexpr uint32_t WG_MAX_JOBS = 8;
+struct WgradJobs {
+	const half_t* dO[WG_MAX_JOBS];
+	const half_t* In[WG_MAX_JOBS];
+	float* slabs[WG_MAX_JOBS];
+	half_t* grad[WG_MAX_JOBS];
+	uint32_t ldo[WG_MAX_JOBS], ldi[WG_MAX_JOBS], ldg[WG_MAX_JOBS];
+};
+
 template <int TRW, int TC>
-__global__ void __launch_bounds__(256) k_wgrad_rows(
-	const uint32_t n, const half_t* __restrict__ dO, const uint32_t ldo, const half_t* __restrict__ In, const uint32_t ldi, float* __restrict__ slabs
-) {
+__global__ void __launch_bounds__(256) k_wgrad_rows(const uint32_t n, const WgradJobs jobs) {
+	const half_t* __restrict__ dO = jobs.dO[blockIdx.y];
+	const half_t* __restrict__ In = jobs.In[blockIdx.y];
+	float* __restrict__ slabs = jobs.slabs[blockIdx.y];
+	const uint32_t ldo = jobs.ldo[blockIdx.y], ldi = jobs.ldi[blockIdx.y];
 	constexpr uint32_t R = 4 * TRW * 16, C = TC * 16;
 	constexpr uint32_t rp = R + WG_PAD, cp = C + WG_PAD;
 	constexpr uint32_t ppr = R / 8, pqr = C / 8;                                      // 16-byte pieces per row
@@ -634,9 +646,11 @@ __global__ void __launch_bounds__(256) k_wgrad_rows(
 // ... and for the output layer's product (R = 16 padded outputs: ONE tile row): wave w owns TCW tile columns.  Same lane maps, same order
 // of a tile's sums, same prefetch; 54 -> 17 us for 16 x 128 over 2^18 samples.
 template <int TCW>
-__global__ void __launch_bounds__(256) k_wgrad_cols(
-	const uint32_t n, const half_t* __restrict__ dO, const uint32_t ldo, const half_t* __restrict__ In, const uint32_t ldi, float* __restrict__ slabs
-) {
+__global__ void __launch_bounds__(256) k_wgrad_cols(const uint32_t n, const WgradJobs jobs) {
+	const half_t* __restrict__ dO = jobs.dO[blockIdx.y];
+	const half_t* __restrict__ In = jobs.In[blockIdx.y];
+	float* __restrict__ slabs = jobs.slabs[blockIdx.y];
+	const uint32_t ldo = jobs.ldo[blockIdx.y], ldi = jobs.ldi[blockIdx.y];
 	constexpr uint32_t R = 16, C = 4 * TCW * 16;
 	constexpr uint32_t rp = R + WG_PAD, cp = C + WG_PAD;
 	constexpr uint32_t ppr = R / 8, pqr = C / 8;
@@ -703,6 +717,12 @@ constexpr int WR_ELEMS = SLAB_REDUCE_ELEMS, WR_GROUPS = SLAB_REDUCE_GROUPS;
 __global__ void __launch_bounds__(WR_ELEMS * WR_GROUPS) k_wgrad_reduce(const uint32_t n_elems, const uint32_t cols, const uint32_t ldg, const uint32_t n_slabs, const float* __restrict__ slabs, half_t* __restrict__ grad, const int accumulate) {
 	__shared__ float part[WR_GROUPS * WR_ELEMS];
 	mlp_reduce_block(part, blockIdx.x, threadIdx.x, n_elems, cols, ldg, n_slabs, slabs, grad, accumulate); // mlp_side_jobs.h: the grid scatter can carry this along
+}
+
+// ... for the products of one launch of k_wgrad_rows / k_wgrad_cols (blockIdx.y: which)
+__global__ void __launch_bounds__(WR_ELEMS * WR_GROUPS) k_wgrad_reduce_jobs(const uint32_t n_elems, const uint32_t cols, const uint32_t n_slabs, const WgradJobs jobs, const int accumulate) {
+	__shared__ float part[WR_GROUPS * WR_ELEMS];
+	mlp_reduce_block(part, blockIdx.x, threadIdx.x, n_elems, cols, jobs.ldg[blockIdx.y], n_slabs, jobs.slabs[blockIdx.y], jobs.grad[blockIdx.y], accumulate);
 }
 
 // The same reduction with the optimizer's update behind it (AdamInFlush, tcnn_common.h): a matrix weight's gradient is final the moment
@@ -884,29 +904,86 @@ void mlp_reduce_slabs(hipStream_t stream, uint32_t n_params, uint32_t n_slabs, c
 
 size_t wgrad_workspace_floats(uint32_t rows, uint32_t cols, uint32_t n) { return (size_t)wgrad_grid(n) * rows * cols; }
 
-void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uint32_t rows, const void* In, uint32_t ldi, uint32_t cols,
-               void* grad_half, uint32_t ldg, bool accumulate, float* workspace) {
-	CHECK_THROW(n % WG_CHUNK == 0);
-	CHECK_THROW(rows % 16 == 0 && cols % 16 == 0);
-	CHECK_THROW((rows / 16) * (cols / 16) <= 4 * WG_MAX_TILES);
+// the shapes k_wgrad_rows / k_wgrad_cols are instantiated for; TCNN_AMD_WGRAD_ROWS=0: k_wgrad for every shape (A/B runs)
+static bool wgrad_fast_shape(uint32_t rows, uint32_t cols) {
+	static const bool rows_form = [] { const char* e = getenv("TCNN_AMD_WGRAD_ROWS"); return !(e && e[0] == '0'); }();
+	return rows_form && ((rows == 128 || rows == 64) && (cols == 128 || cols == 64 || cols == 32) || (rows == 16 && (cols == 128 || cols == 64)));
+}
+
+static void launch_wgrad_jobs(hipStream_t stream, uint32_t n, uint32_t rows, uint32_t cols, const WgradJobs& jobs, uint32_t n_jobs, bool accumulate) {
 	const uint32_t grid = wgrad_grid(n);
 	const size_t shmem = (size_t)WG_CHUNK * ((rows + WG_PAD) + (cols + WG_PAD)) * sizeof(half_t);
-	const half_t* a = (const half_t*)dO;
-	const half_t* b = (const half_t*)In;
-	static const bool rows_form = [] { const char* e = getenv("TCNN_AMD_WGRAD_ROWS"); return !(e && e[0] == '0'); }(); // =0: k_wgrad for every shape (A/B runs)
-#define TCNN_WGRAD_ROWS(TRW, TC) hipLaunchKernelGGL((k_wgrad_rows<TRW, TC>), dim3(grid), dim3(256), shmem, stream, n, a, ldo, b, ldi, workspace)
-	if (rows_form && rows == 128 && cols == 128) TCNN_WGRAD_ROWS(2, 8);
-	else if (rows_form && rows == 128 && cols == 64) TCNN_WGRAD_ROWS(2, 4);
-	else if (rows_form && rows == 128 && cols == 32) TCNN_WGRAD_ROWS(2, 2);
-	else if (rows_form && rows == 64 && cols == 128) TCNN_WGRAD_ROWS(1, 8);
-	else if (rows_form && rows == 64 && cols == 64) TCNN_WGRAD_ROWS(1, 4);
-	else if (rows_form && rows == 64 && cols == 32) TCNN_WGRAD_ROWS(1, 2);
-	else if (rows_form && rows == 16 && cols == 128) hipLaunchKernelGGL((k_wgrad_cols<2>), dim3(grid), dim3(256), shmem, stream, n, a, ldo, b, ldi, workspace);
-	else if (rows_form && rows == 16 && cols == 64) hipLaunchKernelGGL((k_wgrad_cols<1>), dim3(grid), dim3(256), shmem, stream, n, a, ldo, b, ldi, workspace);
-	else hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, a, ldo, rows, b, ldi, cols, workspace);
+	const dim3 g(grid, n_jobs), b(256);
+#define TCNN_WGRAD_ROWS(TRW, TC) hipLaunchKernelGGL((k_wgrad_rows<TRW, TC>), g, b, shmem, stream, n, jobs)
+	if (rows == 128 && cols == 128) TCNN_WGRAD_ROWS(2, 8);
+	else if (rows == 128 && cols == 64) TCNN_WGRAD_ROWS(2, 4);
+	else if (rows == 128 && cols == 32) TCNN_WGRAD_ROWS(2, 2);
+	else if (rows == 64 && cols == 128) TCNN_WGRAD_ROWS(1, 8);
+	else if (rows == 64 && cols == 64) TCNN_WGRAD_ROWS(1, 4);
+	else if (rows == 64 && cols == 32) TCNN_WGRAD_ROWS(1, 2);
+	else if (rows == 16 && cols == 128) hipLaunchKernelGGL((k_wgrad_cols<2>), g, b, shmem, stream, n, jobs);
+	else if (rows == 16 && cols == 64) hipLaunchKernelGGL((k_wgrad_cols<1>), g, b, shmem, stream, n, jobs);
+	else throw std::runtime_error{"launch_wgrad_jobs: no kernel for this shape"};
 #undef TCNN_WGRAD_ROWS
 	const uint32_t n_elems = rows * cols;
-	hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_elems, (uint32_t)WR_ELEMS)), dim3(WR_ELEMS * WR_GROUPS), 0, stream, n_elems, cols, ldg, grid, workspace, (half_t*)grad_half, accumulate ? 1 : 0);
+	hipLaunchKernelGGL(k_wgrad_reduce_jobs, dim3(div_round_up(n_elems, (uint32_t)WR_ELEMS), n_jobs), dim3(WR_ELEMS * WR_GROUPS), 0, stream, n_elems, cols, grid, jobs, accumulate ? 1 : 0);
+	HIP_CHECK_THROW(hipGetLastError());
+}
+
+void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uint32_t rows, const void* In, uint32_t ldi, uint32_t cols,
+               void* grad_half, uint32_t ldg, bool accumulate, float* workspace) {
+	const WgradPanel p{dO, ldo, rows, In, ldi, cols, grad_half, ldg};
+	mlp_wgrad_panels(stream, n, &p, 1, accumulate, workspace);
+}
+
+size_t wgrad_panels_workspace_floats(const WgradPanel* panels, uint32_t count, uint32_t n) {
+	size_t total = 0;
+	for (uint32_t i = 0; i < count; ++i) total += wgrad_workspace_floats(panels[i].rows, panels[i].cols, n);
+	return total;
+}
+
+// Several products over the same n samples (a network's layers): those of one shape the fast kernels take share a launch (and one launch of
+// the slab reduction) -- they are independent, and 2 x 6 launches of ~5 - 35 us were a fifth of a 128 x 5 step at 2^16 samples.  Every
+// product keeps its own slabs, its chunks and their order: the same bits as one launch per product.
+void mlp_wgrad_panels(hipStream_t stream, uint32_t n, const WgradPanel* panels, uint32_t count, bool accumulate, float* workspace) {
+	CHECK_THROW(n % WG_CHUNK == 0);
+	std::vector<bool> done(count, false);
+	std::vector<float*> slabs(count);
+	size_t at = 0;
+	for (uint32_t i = 0; i < count; ++i) {
+		slabs[i] = workspace + at;
+		at += wgrad_workspace_floats(panels[i].rows, panels[i].cols, n);
+	}
+	for (uint32_t i = 0; i < count; ++i) {
+		if (done[i]) continue;
+		const WgradPanel& p = panels[i];
+		CHECK_THROW(p.rows % 16 == 0 && p.cols % 16 == 0);
+		CHECK_THROW((p.rows / 16) * (p.cols / 16) <= 4 * WG_MAX_TILES);
+		if (wgrad_fast_shape(p.rows, p.cols)) {
+			WgradJobs jobs{};
+			uint32_t n_jobs = 0;
+			for (uint32_t j = i; j < count && n_jobs < WG_MAX_JOBS; ++j) {
+				if (done[j] || panels[j].rows != p.rows || panels[j].cols != p.cols) continue;
+				jobs.dO[n_jobs] = (const half_t*)panels[j].dO;
+				jobs.In[n_jobs] = (const half_t*)panels[j].In;
+				jobs.slabs[n_jobs] = slabs[j];
+				jobs.grad[n_jobs] = (half_t*)panels[j].grad;
+				jobs.ldo[n_jobs] = panels[j].ldo;
+				jobs.ldi[n_jobs] = panels[j].ldi;
+				jobs.ldg[n_jobs] = panels[j].ldg;
+				done[j] = true;
+				++n_jobs;
+			}
+			launch_wgrad_jobs(stream, n, p.rows, p.cols, jobs, n_jobs, accumulate);
+			continue;
+		}
+		const uint32_t grid = wgrad_grid(n);
+		const size_t shmem = (size_t)WG_CHUNK * ((p.rows + WG_PAD) + (p.cols + WG_PAD)) * sizeof(half_t);
+		hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, (const half_t*)p.dO, p.ldo, p.rows, (const half_t*)p.In, p.ldi, p.cols, slabs[i]);
+		const uint32_t n_elems = p.rows * p.cols;
+		hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_elems, (uint32_t)WR_ELEMS)), dim3(WR_ELEMS * WR_GROUPS), 0, stream, n_elems, p.cols, p.ldg, grid, slabs[i], (half_t*)p.grad, accumulate ? 1 : 0);
+		done[i] = true;
+	}
 }
 
 } // namespace tcnn_amd

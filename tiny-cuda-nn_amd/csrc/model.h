@@ -1504,11 +1504,9 @@ public:
 		if (mode == GradientMode::Ignore) return;
 		CHECK_THROW(gradients != nullptr);
 
-		size_t ws_floats = 0;
-		for (uint32_t l = 0; l < m_desc.n_layers; ++l) ws_floats = std::max(ws_floats, wgrad_workspace_floats(m_desc.layers[l].rows, std::min(m_desc.layers[l].cols, 128u), n));
-		ArenaBuf ws{stream, ws_floats * sizeof(float)};
 		const bool accumulate = mode == GradientMode::Accumulate;
 		const size_t hstride = (size_t)n * m_width; // elements per hidden layer
+		std::vector<WgradPanel> panels;
 		for (uint32_t l = 0; l < m_desc.n_layers; ++l) {
 			const MlpLayer& L = m_desc.layers[l];
 			const _Float16* dO = l == m_desc.n_layers - 1 ? (const _Float16*)dY : dhidden.as<_Float16>() + hstride * l;
@@ -1520,10 +1518,12 @@ public:
 				const uint32_t rr = std::min(128u, L.rows - r0);
 				for (uint32_t c0 = 0; c0 < L.cols; c0 += 128) { // column panels of at most 128
 					const uint32_t cc = std::min(128u, L.cols - c0);
-					mlp_wgrad(stream, n, dO + r0, ldo, rr, In + c0, ldi, cc, g + (size_t)r0 * L.cols + c0, L.cols, accumulate, ws.as<float>());
+					panels.push_back(WgradPanel{dO + r0, ldo, rr, In + c0, ldi, cc, g + (size_t)r0 * L.cols + c0, L.cols});
 				}
 			}
 		}
+		ArenaBuf ws{stream, wgrad_panels_workspace_floats(panels.data(), (uint32_t)panels.size(), n) * sizeof(float)};
+		mlp_wgrad_panels(stream, n, panels.data(), (uint32_t)panels.size(), accumulate, ws.as<float>()); // (layers of one shape share a launch)
 	}
 
 	Json hyperparams() const { // fully_fused_mlp.h:137-145
