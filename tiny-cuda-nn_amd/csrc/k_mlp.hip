@@ -128,6 +128,15 @@ __device__ inline void activate_pack(const f4 (&acc)[T][NB], h8 (&hf)[KS][NB], u
 #ifndef TCNN_MLP_FWD_PF
 #define TCNN_MLP_FWD_PF 3
 #endif
+// The stored activations of the hidden layers and their gradients (k_mlp_fwd -> k_mlp_bwd -> the weight-gradient products; nobody else sees
+// them) are TILED: [layer][16 samples][16 features] blocks of 512 contiguous bytes, a layer's blocks sample-tile major.  One block is exactly
+// what a wave's 64 lanes x 8 bytes hold of one result tile, so every such load or store is four whole 128-byte lines; as rows [n][W] the
+// same instruction touched 32 bytes in each of 16 rows (round 5: the forward kernel's stores cost 72 of its 143 us at 128 x 5, 2^18 samples).
+// Returns the offset in halves of block (samples sample16 .. +15, features 16 t .. +15) of layer l.
+__device__ __host__ inline size_t hidden_tile_off(const uint32_t n, const uint32_t W, const uint32_t l, const uint32_t sample16, const uint32_t t) {
+	return ((size_t)l * n + sample16) * W + (size_t)t * 256;
+}
+
 template <int W, int NB, int ACT, bool IMG_LDS = false, int THREADS = 256, bool OB = false>
 // (W = 128 with the fragments in the L2: the 120 + 64 registers the compiler took on its own left two waves per SIMD to hide every fragment's
 // and input's latency; held to 168 -- no spills -- it is three: 158 -> 143 us for 128 x 5 at 2^18 samples, round 5)
@@ -248,7 +257,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((W
 					h4 v;
 #pragma unroll
 					for (int r = 0; r < 4; ++r) v[r] = hf[t / 2][b][(t & 1) * 4 + r];
-					*(h4*)(a.hidden + ((size_t)l * a.n + s0 + 16 * b + c) * W + 16 * t + 4 * q) = v;
+					*(h4*)(a.hidden + hidden_tile_off(a.n, W, l, s0 + 16 * b, t) + 16 * c + 4 * q) = v; // (the wave's 64 x 8 bytes: one tile, 512 contiguous bytes)
 				}
 		};
 		store_hidden(0);
@@ -394,7 +403,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 #pragma unroll
 			for (int t = 0; t < T; ++t)
 #pragma unroll
-				for (int b = 0; b < NB; ++b) hv[t][b] = *(const h4*)(a.hidden + ((size_t)l * a.n + s0 + 16 * b + c) * W + 16 * t + 4 * q);
+				for (int b = 0; b < NB; ++b) hv[t][b] = *(const h4*)(a.hidden + hidden_tile_off(a.n, W, l, s0 + 16 * b, t) + 16 * c + 4 * q);
 		};
 		request_hidden((int)nh - 1);
 		for (int l = (int)nh - 1; l >= 0; --l) {
@@ -403,7 +412,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 			for (int t = 0; t < T; ++t)
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
-					const size_t off = ((size_t)l * a.n + s0 + 16 * b + c) * W + 16 * t + 4 * q;
+					const size_t off = hidden_tile_off(a.n, W, l, s0 + 16 * b, t) + 16 * c + 4 * q;
 					h4 g;
 #pragma unroll
 					for (int r = 0; r < 4; ++r) g[r] = act_bwd_t<ACT>(d.activation, (half_t)acc[t][b][r], hv[t][b][r]);
@@ -467,13 +476,32 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 // Each workgroup accumulates a private partial in registers over its chunks and writes one fp32 slab; k_wgrad_reduce
 // sums the slabs in a fixed order (bitwise reproducible, no atomics).
 // ------------------------------------------------------------------------------------------------------------------
+// Piece p (8 halves) of a chunk of WG_CHUNK samples x 8 per_row features: where it lies in memory (offset in halves from the operand's
+// pointer) and in the LDS image [sample][feature].  Rows [n][ld], or the tiled form above (ld: the tiled matrix's full width; a panel's first
+// column is absorbed by the pointer: + (column / 16) * 256).  Consecutive p are consecutive in memory either way.
+struct WgPiece { size_t src; uint32_t row, col; };
+__device__ inline WgPiece wg_piece(const uint32_t p, const uint32_t per_row, const size_t base_sample, const uint32_t ld, const bool tiled) {
+	WgPiece r;
+	if (!tiled) {
+		r.row = p / per_row;
+		r.col = (p - r.row * per_row) * 8;
+		r.src = (base_sample + r.row) * ld + r.col;
+	} else {
+		const uint32_t half = p & 1u, c = (p >> 1) & 15u, rest = p >> 5, tiles = per_row / 2, st = rest / tiles, t = rest - st * tiles;
+		r.row = st * 16 + c;
+		r.col = t * 16 + half * 8;
+		r.src = (base_sample + st * 16) * ld + (size_t)t * 256 + c * 16 + half * 8;
+	}
+	return r;
+}
+
 constexpr int WG_CHUNK = 64;       // samples per staged chunk (2 k-steps)
 constexpr int WG_MAX_TILES = 16;   // accumulator tiles per wave: R*C <= 128*128 with 4 waves
 constexpr int WG_PAD = 8;          // halfs of row padding in LDS (keeps rows 16-byte aligned, breaks the power-of-2 stride)
 
 __global__ void __launch_bounds__(256) k_wgrad(
 	const uint32_t n, const half_t* __restrict__ dO, const uint32_t ldo, const uint32_t R,
-	const half_t* __restrict__ In, const uint32_t ldi, const uint32_t C, float* __restrict__ slabs
+	const half_t* __restrict__ In, const uint32_t ldi, const uint32_t C, float* __restrict__ slabs, const uint32_t tiled
 ) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const uint32_t rp = R + WG_PAD, cp = C + WG_PAD; // padded row lengths (halfs)
@@ -498,12 +526,12 @@ __global__ void __launch_bounds__(256) k_wgrad(
 		// stage: 16-byte pieces, rows are contiguous in global memory
 		const uint32_t ppr = R / 8, pqr = C / 8;
 		for (uint32_t p = tid; p < WG_CHUNK * ppr; p += 256) {
-			const uint32_t row = p / ppr, col = (p - row * ppr) * 8;
-			*(h8*)(P + (size_t)row * rp + col) = *(const h8*)(dO + (base + row) * ldo + col);
+			const WgPiece w = wg_piece(p, ppr, base, ldo, (tiled & 1u) != 0);
+			*(h8*)(P + (size_t)w.row * rp + w.col) = *(const h8*)(dO + w.src);
 		}
 		for (uint32_t p = tid; p < WG_CHUNK * pqr; p += 256) {
-			const uint32_t row = p / pqr, col = (p - row * pqr) * 8;
-			*(h8*)(Q + (size_t)row * cp + col) = *(const h8*)(In + (base + row) * ldi + col);
+			const WgPiece w = wg_piece(p, pqr, base, ldi, (tiled & 2u) != 0);
+			*(h8*)(Q + (size_t)w.row * cp + w.col) = *(const h8*)(In + w.src);
 		}
 		__syncthreads();
 
@@ -558,6 +586,7 @@ struct WgradJobs {
 	float* slabs[WG_MAX_JOBS];
 	half_t* grad[WG_MAX_JOBS];
 	uint32_t ldo[WG_MAX_JOBS], ldi[WG_MAX_JOBS], ldg[WG_MAX_JOBS];
+	uint32_t tiled[WG_MAX_JOBS]; // bit 0: dO, bit 1: In in the tiled form (hidden_tile_off)
 };
 
 template <int TRW, int TC>
@@ -566,6 +595,7 @@ __global__ void __launch_bounds__(256) k_wgrad_rows(const uint32_t n, const Wgra
 	const half_t* __restrict__ In = jobs.In[blockIdx.y];
 	float* __restrict__ slabs = jobs.slabs[blockIdx.y];
 	const uint32_t ldo = jobs.ldo[blockIdx.y], ldi = jobs.ldi[blockIdx.y];
+	const bool p_tiled = (jobs.tiled[blockIdx.y] & 1u) != 0, q_tiled = (jobs.tiled[blockIdx.y] & 2u) != 0;
 	constexpr uint32_t R = 4 * TRW * 16, C = TC * 16;
 	constexpr uint32_t rp = R + WG_PAD, cp = C + WG_PAD;
 	constexpr uint32_t ppr = R / 8, pqr = C / 8;                                      // 16-byte pieces per row
@@ -589,27 +619,21 @@ __global__ void __launch_bounds__(256) k_wgrad_rows(const uint32_t n, const Wgra
 	auto fetch = [&](const uint32_t ch) { // (a chunk past the end: the last one again, never stored)
 		const size_t base = (size_t)min(ch, n_chunks - 1) * WG_CHUNK;
 #pragma unroll
-		for (uint32_t k = 0; k < NP; ++k) {
-			const uint32_t p = tid + k * 256, row = p / ppr, col = (p - row * ppr) * 8;
-			pv[k] = *(const h8*)(dO + (base + row) * ldo + col);
-		}
+		for (uint32_t k = 0; k < NP; ++k) pv[k] = *(const h8*)(dO + wg_piece(tid + k * 256, ppr, base, ldo, p_tiled).src);
 #pragma unroll
-		for (uint32_t k = 0; k < NQ; ++k) {
-			const uint32_t p = tid + k * 256, row = p / pqr, col = (p - row * pqr) * 8;
-			qv[k] = *(const h8*)(In + (base + row) * ldi + col);
-		}
+		for (uint32_t k = 0; k < NQ; ++k) qv[k] = *(const h8*)(In + wg_piece(tid + k * 256, pqr, base, ldi, q_tiled).src);
 	};
 	if (blockIdx.x < n_chunks) fetch(blockIdx.x);
 	for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
 #pragma unroll
 		for (uint32_t k = 0; k < NP; ++k) {
-			const uint32_t p = tid + k * 256, row = p / ppr, col = (p - row * ppr) * 8;
-			*(h8*)(P + (size_t)row * rp + col) = pv[k];
+			const WgPiece w = wg_piece(tid + k * 256, ppr, 0, ldo, p_tiled);
+			*(h8*)(P + (size_t)w.row * rp + w.col) = pv[k];
 		}
 #pragma unroll
 		for (uint32_t k = 0; k < NQ; ++k) {
-			const uint32_t p = tid + k * 256, row = p / pqr, col = (p - row * pqr) * 8;
-			*(h8*)(Q + (size_t)row * cp + col) = qv[k];
+			const WgPiece w = wg_piece(tid + k * 256, pqr, 0, ldi, q_tiled);
+			*(h8*)(Q + (size_t)w.row * cp + w.col) = qv[k];
 		}
 		__syncthreads();
 		fetch(ch + gridDim.x); // in flight while this chunk is multiplied
@@ -651,6 +675,7 @@ __global__ void __launch_bounds__(256) k_wgrad_cols(const uint32_t n, const Wgra
 	const half_t* __restrict__ In = jobs.In[blockIdx.y];
 	float* __restrict__ slabs = jobs.slabs[blockIdx.y];
 	const uint32_t ldo = jobs.ldo[blockIdx.y], ldi = jobs.ldi[blockIdx.y];
+	const bool p_tiled = (jobs.tiled[blockIdx.y] & 1u) != 0, q_tiled = (jobs.tiled[blockIdx.y] & 2u) != 0;
 	constexpr uint32_t R = 16, C = 4 * TCW * 16;
 	constexpr uint32_t rp = R + WG_PAD, cp = C + WG_PAD;
 	constexpr uint32_t ppr = R / 8, pqr = C / 8;
@@ -669,24 +694,21 @@ __global__ void __launch_bounds__(256) k_wgrad_cols(const uint32_t n, const Wgra
 
 	const uint32_t n_chunks = n / WG_CHUNK;
 	const bool has_p = tid < WG_CHUNK * ppr;
-	const uint32_t prow = tid / ppr, pcol = (tid - prow * ppr) * 8;
+	const WgPiece pw = wg_piece(has_p ? tid : 0u, ppr, 0, ldo, p_tiled);
 	h8 pv = h8{0, 0, 0, 0, 0, 0, 0, 0}, qv[NQ];
 	auto fetch = [&](const uint32_t ch) {
 		const size_t base = (size_t)min(ch, n_chunks - 1) * WG_CHUNK;
-		if (has_p) pv = *(const h8*)(dO + (base + prow) * ldo + pcol);
+		if (has_p) pv = *(const h8*)(dO + base * ldo + pw.src); // (rows and tiles alike: a chunk starts base * ld halves in)
 #pragma unroll
-		for (uint32_t k = 0; k < NQ; ++k) {
-			const uint32_t p = tid + k * 256, row = p / pqr, col = (p - row * pqr) * 8;
-			qv[k] = *(const h8*)(In + (base + row) * ldi + col);
-		}
+		for (uint32_t k = 0; k < NQ; ++k) qv[k] = *(const h8*)(In + wg_piece(tid + k * 256, pqr, base, ldi, q_tiled).src);
 	};
 	if (blockIdx.x < n_chunks) fetch(blockIdx.x);
 	for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-		if (has_p) *(h8*)(P + (size_t)prow * rp + pcol) = pv;
+		if (has_p) *(h8*)(P + (size_t)pw.row * rp + pw.col) = pv;
 #pragma unroll
 		for (uint32_t k = 0; k < NQ; ++k) {
-			const uint32_t p = tid + k * 256, row = p / pqr, col = (p - row * pqr) * 8;
-			*(h8*)(Q + (size_t)row * cp + col) = qv[k];
+			const WgPiece w = wg_piece(tid + k * 256, pqr, 0, ldi, q_tiled);
+			*(h8*)(Q + (size_t)w.row * cp + w.col) = qv[k];
 		}
 		__syncthreads();
 		fetch(ch + gridDim.x);
@@ -932,7 +954,7 @@ static void launch_wgrad_jobs(hipStream_t stream, uint32_t n, uint32_t rows, uin
 
 void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uint32_t rows, const void* In, uint32_t ldi, uint32_t cols,
                void* grad_half, uint32_t ldg, bool accumulate, float* workspace) {
-	const WgradPanel p{dO, ldo, rows, In, ldi, cols, grad_half, ldg};
+	const WgradPanel p{dO, ldo, rows, In, ldi, cols, grad_half, ldg, false, false};
 	mlp_wgrad_panels(stream, n, &p, 1, accumulate, workspace);
 }
 
@@ -971,6 +993,7 @@ void mlp_wgrad_panels(hipStream_t stream, uint32_t n, const WgradPanel* panels, 
 				jobs.ldo[n_jobs] = panels[j].ldo;
 				jobs.ldi[n_jobs] = panels[j].ldi;
 				jobs.ldg[n_jobs] = panels[j].ldg;
+				jobs.tiled[n_jobs] = (panels[j].dO_tiled ? 1u : 0u) | (panels[j].In_tiled ? 2u : 0u);
 				done[j] = true;
 				++n_jobs;
 			}
@@ -979,7 +1002,7 @@ void mlp_wgrad_panels(hipStream_t stream, uint32_t n, const WgradPanel* panels, 
 		}
 		const uint32_t grid = wgrad_grid(n);
 		const size_t shmem = (size_t)WG_CHUNK * ((p.rows + WG_PAD) + (p.cols + WG_PAD)) * sizeof(half_t);
-		hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, (const half_t*)p.dO, p.ldo, p.rows, (const half_t*)p.In, p.ldi, p.cols, slabs[i]);
+		hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), shmem, stream, n, (const half_t*)p.dO, p.ldo, p.rows, (const half_t*)p.In, p.ldi, p.cols, slabs[i], (p.dO_tiled ? 1u : 0u) | (p.In_tiled ? 2u : 0u));
 		const uint32_t n_elems = p.rows * p.cols;
 		hipLaunchKernelGGL(k_wgrad_reduce, dim3(div_round_up(n_elems, (uint32_t)WR_ELEMS)), dim3(WR_ELEMS * WR_GROUPS), 0, stream, n_elems, p.cols, p.ldg, grid, slabs[i], (half_t*)p.grad, accumulate ? 1 : 0);
 		done[i] = true;

@@ -1518,7 +1518,10 @@ public:
 				const uint32_t rr = std::min(128u, L.rows - r0);
 				for (uint32_t c0 = 0; c0 < L.cols; c0 += 128) { // column panels of at most 128
 					const uint32_t cc = std::min(128u, L.cols - c0);
-					panels.push_back(WgradPanel{dO + r0, ldo, rr, In + c0, ldi, cc, g + (size_t)r0 * L.cols + c0, L.cols});
+					// (the hidden layers' activations and gradients are tiled, k_mlp.hip hidden_tile_off: a panel's first column is whole tiles in)
+					const bool dO_tiled = l != m_desc.n_layers - 1, In_tiled = l != 0;
+					panels.push_back(WgradPanel{dO_tiled ? dO + (size_t)(r0 / 16) * 256 : dO + r0, ldo, rr, In_tiled ? In + (size_t)(c0 / 16) * 256 : In + c0, ldi, cc,
+					                            g + (size_t)r0 * L.cols + c0, L.cols, dO_tiled, In_tiled});
 				}
 			}
 		}

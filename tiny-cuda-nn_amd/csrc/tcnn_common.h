@@ -388,7 +388,9 @@ void mlp_activation_backward_output(hipStream_t stream, uint32_t n_elems, uint32
 // dW[rows x cols] = sum_i dO[i][rows]^T In[i][cols]; result written as half into grad (overwrite or accumulate). workspace: float[wgrad_workspace_floats()]
 size_t wgrad_workspace_floats(uint32_t rows, uint32_t cols, uint32_t n);
 // several such products over the same n samples (a network's layers): same results as one mlp_wgrad() each, fewer launches
-struct WgradPanel { const void* dO; uint32_t ldo, rows; const void* In; uint32_t ldi, cols; void* grad; uint32_t ldg; };
+// (dO_tiled / In_tiled: the operand is a hidden layer's stored activations or gradients in k_mlp_fwd / k_mlp_bwd's tiled form, ld = the full
+// width of that matrix and a panel's first column c0 absorbed by the pointer as + (c0 / 16) * 256 halves; k_mlp.hip hidden_tile_off)
+struct WgradPanel { const void* dO; uint32_t ldo, rows; const void* In; uint32_t ldi, cols; void* grad; uint32_t ldg; bool dO_tiled, In_tiled; };
 size_t wgrad_panels_workspace_floats(const WgradPanel* panels, uint32_t count, uint32_t n);
 void mlp_wgrad_panels(hipStream_t stream, uint32_t n, const WgradPanel* panels, uint32_t count, bool accumulate, float* workspace);
 void mlp_wgrad(hipStream_t stream, uint32_t n, const void* dO, uint32_t ldo, uint32_t rows, const void* In, uint32_t ldi, uint32_t cols,
