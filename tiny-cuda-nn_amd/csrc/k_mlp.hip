@@ -398,12 +398,15 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 		// The stored forward outputs of layer l are requested a whole layer ahead -- before the products that lead to dH_l -- and the weight
 		// fragments one ahead of the matrix instructions that use them (round 5: written as "load, use" every one of a layer's 16 + 32 loads
 		// exposed its latency to a wave that has only one partner on its SIMD: 270 us for 128 x 5 at 2^18 samples).  Same arithmetic, same order.
-		h4 hv[T][NB];
+		// (W = 256: the 32 registers this takes push the kernel past 256 -- one wave per SIMD, 497 against ~300 us -- so there the values are read where they are used)
+		constexpr bool AHEAD = W <= 128;
+		h4 hv[AHEAD ? T : 1][AHEAD ? NB : 1];
 		auto request_hidden = [&](const int l) {
+			if constexpr (!AHEAD) return;
 #pragma unroll
 			for (int t = 0; t < T; ++t)
 #pragma unroll
-				for (int b = 0; b < NB; ++b) hv[t][b] = *(const h4*)(a.hidden + hidden_tile_off(a.n, W, l, s0 + 16 * b, t) + 16 * c + 4 * q);
+				for (int b = 0; b < NB; ++b) hv[AHEAD ? t : 0][AHEAD ? b : 0] = *(const h4*)(a.hidden + hidden_tile_off(a.n, W, l, s0 + 16 * b, t) + 16 * c + 4 * q);
 		};
 		request_hidden((int)nh - 1);
 		for (int l = (int)nh - 1; l >= 0; --l) {
@@ -413,9 +416,11 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					const size_t off = hidden_tile_off(a.n, W, l, s0 + 16 * b, t) + 16 * c + 4 * q;
-					h4 g;
+					h4 g, hvv;
+					if constexpr (AHEAD) hvv = hv[t][b];
+					else hvv = *(const h4*)(a.hidden + off);
 #pragma unroll
-					for (int r = 0; r < 4; ++r) g[r] = act_bwd_t<ACT>(d.activation, (half_t)acc[t][b][r], hv[t][b][r]);
+					for (int r = 0; r < 4; ++r) g[r] = act_bwd_t<ACT>(d.activation, (half_t)acc[t][b][r], hvv[r]);
 					*(h4*)(a.dhidden + off) = g;
 #pragma unroll
 					for (int r = 0; r < 4; ++r) hf[t / 2][b][(t & 1) * 4 + r] = g[r];
@@ -497,7 +502,7 @@ __device__ inline WgPiece wg_piece(const uint32_t p, const uint32_t per_row, con
 
 constexpr int WG_CHUNK = 64;       // samples per staged chunk (2 k-steps)
 constexpr int WG_MAX_TILES = 16;   // accumulator tiles per wave: R*C <= 128*128 with 4 waves
-constexpr int WG_PAD = 8;          // halfs of row padding in LDS (keeps rows 16-byte aligned, breaks the power-of-2 stride)
+constexpr int WG_PAD = 16;         // halfs of row padding in LDS (keeps rows 16-byte aligned, breaks the power-of-2 stride)
 
 __global__ void __launch_bounds__(256) k_wgrad(
 	const uint32_t n, const half_t* __restrict__ dO, const uint32_t ldo, const uint32_t R,
