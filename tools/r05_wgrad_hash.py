@@ -1,5 +1,9 @@
+"""usage (GPU box): python tools/r05_wgrad_hash.py WIDTH HIDDEN_LAYERS   [TCNN_AMD_WGRAD_ROWS=0 / TCNN_AMD_FUSED_STEP=0 in the environment]
+
+SHA-256 over the half parameter gradients of OneBlob + WIDTH x HIDDEN_LAYERS after three training steps (no optimizer) on one batch of 2^16
+samples: the A/B check that a change to the unfused step's kernels (forward, backward, weight-gradient products) left every sum's order alone."""
 import os, sys, hashlib, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tiny-cuda-nn_amd"))
 import torch, numpy as np
 import bench
