@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((W
 		activate_pack<T, KS, NB, ACT>(acc, hf, d.activation);
 
 		auto store_hidden = [&](uint32_t l) {
+			if constexpr (IMG_LDS) return; // (inference only, launched with hidden == nullptr: the dead stores' addresses cost this form's 254 registers eleven spills)
 			if (!a.hidden) return;
 #pragma unroll
 			for (int t = 0; t < T; ++t)
