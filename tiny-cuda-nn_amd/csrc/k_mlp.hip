@@ -140,7 +140,7 @@ __device__ __host__ inline size_t hidden_tile_off(const uint32_t n, const uint32
 template <int W, int NB, int ACT, bool IMG_LDS = false, int THREADS = 256, bool OB = false>
 // (W = 128 with the fragments in the L2: the 120 + 64 registers the compiler took on its own left two waves per SIMD to hide every fragment's
 // and input's latency; held to 168 -- no spills -- it is three: 158 -> 143 us for 128 x 5 at 2^18 samples, round 5)
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((W == 128 && !IMG_LDS) ? 3 : 1, 8))) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((W >= 128 && !IMG_LDS) ? 3 : 1, 8))) k_mlp_fwd(const MlpDesc d, const FwdArgs a) {
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
 	const uint32_t lane = threadIdx.x & 63;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((W
 		activate_pack<T, KS, NB, ACT>(acc, hf, d.activation);
 
 		auto store_hidden = [&](uint32_t l) {
-			if constexpr (IMG_LDS) return; // (inference only, launched with hidden == nullptr: the dead stores' addresses cost this form's 254 registers eleven spills)
+			if constexpr (IMG_LDS || OB) return; // (inference only, launched with hidden == nullptr: the dead stores' addresses cost the LDS form's 254 registers eleven spills)
 			if (!a.hidden) return;
 #pragma unroll
 			for (int t = 0; t < T; ++t)
@@ -337,7 +337,7 @@ struct BwdArgs {
 };
 
 template <int W, int NB, int ACT>
-__global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs a) { // (three waves per SIMD, as k_mlp_fwd has them at W = 128, cost 24 spilled registers here: 227 -> 255 us)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 32 ? 3 : 1, 8))) k_mlp_bwd(const MlpDesc d, const BwdArgs a) { // (three waves per SIMD, as k_mlp_fwd has them at W = 128, cost 24 spilled registers here: 227 -> 255 us)
 	constexpr int T = W / 16;
 	constexpr int KS = (T + 1) / 2;
 	const uint32_t lane = threadIdx.x & 63;
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 		// fragments one ahead of the matrix instructions that use them (round 5: written as "load, use" every one of a layer's 16 + 32 loads
 		// exposed its latency to a wave that has only one partner on its SIMD: 270 us for 128 x 5 at 2^18 samples).  Same arithmetic, same order.
 		// (W = 256: the 32 registers this takes push the kernel past 256 -- one wave per SIMD, 497 against ~300 us -- so there the values are read where they are used)
-		constexpr bool AHEAD = W <= 128;
+		constexpr bool AHEAD = W == 64 || W == 128; // (W = 32 with its four column blocks: three waves per SIMD without, two with)
 		h4 hv[AHEAD ? T : 1][AHEAD ? NB : 1];
 		auto request_hidden = [&](const int l) {
 			if constexpr (!AHEAD) return;
@@ -440,14 +440,24 @@ __global__ void __launch_bounds__(256) k_mlp_bwd(const MlpDesc d, const BwdArgs 
 #pragma unroll
 					for (int b = 0; b < NB; ++b) acc[t][b] = f4{0, 0, 0, 0};
 				auto frag_of = [&](const int i) -> h8 { return img[(size_t)((i % T) * KS + i / T) * 64]; };
-				h8 af[2];
-				af[0] = frag_of(0);
+				if constexpr (AHEAD) {
+					h8 af[2];
+					af[0] = frag_of(0);
 #pragma unroll
-				for (int i = 0; i < KS * T; ++i) {
-					const int s = i / T, t = i % T;
-					if (i + 1 < KS * T) af[(i + 1) & 1] = frag_of(i + 1);
+					for (int i = 0; i < KS * T; ++i) {
+						const int s = i / T, t = i % T;
+						if (i + 1 < KS * T) af[(i + 1) & 1] = frag_of(i + 1);
 #pragma unroll
-					for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af[i & 1], hf[s][b], acc[t][b]);
+						for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af[i & 1], hf[s][b], acc[t][b]);
+					}
+				} else {
+#pragma unroll
+					for (int i = 0; i < KS * T; ++i) {
+						const int s = i / T, t = i % T;
+						const h8 af = frag_of(i);
+#pragma unroll
+						for (int b = 0; b < NB; ++b) acc[t][b] = mfma(af, hf[s][b], acc[t][b]);
+					}
 				}
 			}
 		}
