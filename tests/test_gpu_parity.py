@@ -426,6 +426,36 @@ def test_network_forward_backward(tcnn, oracle, n_in, n_out, net_cfg):
     assert rel_err(got_dx, want_dx) < 2e-2
 
 
+@pytest.mark.parametrize("width,hidden,n_bins", [(128, 5, 64), (128, 2, 32), (128, 2, 16), (64, 2, 16), (64, 3, 32)])
+def test_weight_gradient_kernels_agree(tcnn, oracle, monkeypatch, width, hidden, n_bins):
+    """The unfused step's weight-gradient products (fully_fused_mlp.cu:785-828): k_wgrad_rows / k_wgrad_cols -- operand reuse, prefetch, the
+    layers' products in one launch, operands in the tiled form k_mlp_fwd / k_mlp_bwd store -- against k_wgrad (TCNN_AMD_WGRAD_ROWS=0) on
+    OneBlob + width x hidden (2 n_bins inputs: products of 128 / 64 rows by 128 / 64 / 32 columns and the 16-row output layer): the same
+    bits, every tile sums its chunks and k-steps in the same order; and the gradients against the oracle within the MLP tolerance."""
+    cfg = dict(CONFIG_C2, encoding={"otype": "OneBlob", "n_bins": n_bins},
+               network={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": width, "n_hidden_layers": hidden})
+    n = 8192
+    x, t = oracle.synthetic_batch(n, 2, 3, seed=31)
+    monkeypatch.setenv("TCNN_AMD_FUSED_STEP", "0")
+
+    def grads(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = tcnn.Trainer(2, 3, cfg, seed=1337)
+        tr.training_step(_t(x), _t(t), run_optimizer=False)
+        g = _bits(tr.param_gradients()).copy()
+        for k in env:
+            monkeypatch.delenv(k)
+        return g
+
+    g, g0 = grads({}), grads({"TCNN_AMD_WGRAD_ROWS": "0"})
+    assert np.any(g != 0) and np.array_equal(g, g0)
+    ref = oracle.Trainer(2, 3, cfg, seed=1337)
+    grads32 = np.zeros(ref.model.n_params, dtype=np.float32)
+    ref.training_step(x, t, run_optimizer=False, grads_f32=grads32)
+    assert rel_err(_f32(g), grads32) < 3e-2
+
+
 # ---------------------------------------------------------------------------------------------------- full training step
 CONFIG_PADDED_2D = dict(CONFIG_C3B, encoding={"otype": "HashGrid", "n_levels": 12, "n_features_per_level": 2, "log2_hashmap_size": 15, "base_resolution": 16, "per_level_scale": 1.5})  # 24 features in front of a 16-aligned network: 8 columns of zeros (grid.h:749-759)
 CONFIG_PADDED_3D = dict(CONFIG_C3B, encoding={"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 2, "log2_hashmap_size": 17, "base_resolution": 8, "per_level_scale": 2.0})  # 12 -> 16, hit lists

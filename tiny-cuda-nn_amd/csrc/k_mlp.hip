@@ -944,7 +944,8 @@ size_t wgrad_workspace_floats(uint32_t rows, uint32_t cols, uint32_t n) { return
 
 // the shapes k_wgrad_rows / k_wgrad_cols are instantiated for; TCNN_AMD_WGRAD_ROWS=0: k_wgrad for every shape (A/B runs)
 static bool wgrad_fast_shape(uint32_t rows, uint32_t cols) {
-	static const bool rows_form = [] { const char* e = getenv("TCNN_AMD_WGRAD_ROWS"); return !(e && e[0] == '0'); }();
+	const char* e = getenv("TCNN_AMD_WGRAD_ROWS"); // (read per call: a test compares the two settings in one process)
+	const bool rows_form = !(e && e[0] == '0');
 	return rows_form && ((rows == 128 || rows == 64) && (cols == 128 || cols == 64 || cols == 32) || (rows == 16 && (cols == 128 || cols == 64)));
 }
 
