@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage (GPU box): python tools/determinism_soak.py WORKLOAD STEPS   (WORKLOAD: c3a | c3b | c2 | c5)
+"""usage (GPU box): python tools/determinism_soak.py WORKLOAD STEPS   (WORKLOAD: c3a | c3b | c2 | c5 | oneblob128x5 | grid3d)
 
 Two trainers created from the same seed take the same STEPS training steps on the same four batches; prints the last loss, the SHA-256 of the
 fp32 master parameters, how many backward passes ran the list-fed gradient kernel and how many of its tasks fell back to 64-bit sums, and
@@ -21,8 +21,15 @@ import tinycudann as tcnn  # noqa: E402
 from tinycudann import _C  # noqa: E402
 
 
+EXTRA = {
+    # the reference's shipped data/config.json / config_oneblob.json (the unfused step) and a NeRF-shaped 3-D grid (hit lists in 3-D)
+    "oneblob128x5": (2, 3, 1 << 18, dict(bench.WORKLOADS["c2"][3], network={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 5})),
+    "grid3d": (3, 3, 1 << 18, dict(bench.WORKLOADS["c3a"][3], encoding={"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 1.5})),
+}
+
+
 def run(name, steps):
-    n_in, n_out, batch, cfg = bench.WORKLOADS[name]
+    n_in, n_out, batch, cfg = (EXTRA.get(name) or bench.WORKLOADS[name])
     gen = torch.Generator(device="cuda")
     gen.manual_seed(7)
     xs = [torch.rand((batch, n_in), device="cuda", generator=gen) for _ in range(4)]
