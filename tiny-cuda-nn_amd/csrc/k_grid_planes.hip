@@ -395,7 +395,12 @@ uint32_t grid_planes_spt(const GridMeta& meta) {
 	forced = dev_forced;
 #endif
 	if (max_scatter_chunks(meta) > (uint32_t)FP_MAX_CHUNKS) return 2u;
-	return forced == 8 ? 8u : 4u;
+	if (forced == 8 || forced == 4 || forced == 2) return forced;
+	// 3-D grids that write hit lists: four cell rows per sample make an item of 1024 samples 4096 list elements -- 40 KB of LDS staging, three
+	// workgroups per CU.  Items of 512 samples (round 5, L = 16, F = 2, T = 2^19 at 2^18 samples): forward 151-161 -> 117-123 us, the gradient
+	// kernels 86-89 -> 92-94 (twice the items per chunk), step 0.340 -> 0.307 ms.  In 2-D the same halving loses (C3a: gradient 55 -> 63 us).
+	if (meta.n_pos_dims == 3 && grid_scatter_prefers_lists(meta)) return 2u;
+	return 4u;
 }
 
 bool grid_planes_supported(const GridMeta& meta, uint32_t n) {
